@@ -1,0 +1,222 @@
+/* llamarec_mi355x.h -- C ABI of libllamarec_mi355x.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the two-stage retrieve-then-rerank scoring path of GarciaLnk/LlamaRec.
+ * The reference has no FFI: its seams are Python nn.Module.forward calls. Each entry point below
+ * names the reference call site it replaces (paths are into the reference tree).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / C++ types cross the boundary.
+ *  - the CALLER owns every buffer (weights, workspaces, inputs, outputs; normally torch tensors);
+ *    the library owns nothing but small host-side handles. No entry point allocates device
+ *    memory or synchronises the device, so every call is hipGraph-capturable.
+ *  - all device work is enqueued on the caller's hipStream_t (passed as void*); the caller
+ *    synchronises.
+ *  - return value: 0 = LR_OK, negative = LR_E*; lr_last_error() gives a thread-local message.
+ *  - re-entrant across handles; one in-flight call per handle+workspace.
+ */
+#ifndef LLAMAREC_MI355X_H
+#define LLAMAREC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_OK 0
+#define LR_EINVAL (-1)   /* bad argument (null pointer, shape out of range) */
+#define LR_EUNSUPPORTED (-2) /* configuration outside what the kernels implement */
+#define LR_EHIP (-3)     /* HIP runtime error (launch failure, wrong device, ...) */
+#define LR_EWORKSPACE (-4) /* caller-provided workspace too small */
+
+#define LR_MAX_LRU_BLOCKS 4
+#define LR_MAX_TOPK 64
+
+const char* lr_last_error(void);
+/* "llamarec_mi355x <semver> gfx950" */
+const char* lr_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 1: LRURec retriever  (model/lru.py:8-175, trainer/lru.py:30-42,44-138)
+ * ------------------------------------------------------------------------------------------ */
+
+/* One LRUBlock's tensors exactly as in the reference state_dict (model/lru.py:89-175);
+ * complex64 tensors are passed as interleaved (re,im) float pairs (torch.view_as_real). */
+typedef struct LrLruBlockWeights {
+  const float* params_log;  /* [3][128]      lru_layer.params_log (nu_log, theta_log, gamma_log) */
+  const float* in_proj_w;   /* [128][64][2]  lru_layer.in_proj.weight  (complex64) */
+  const float* in_proj_b;   /* [128][2]      lru_layer.in_proj.bias    (complex64) */
+  const float* out_proj_w;  /* [64][128][2]  lru_layer.out_proj.weight (complex64) */
+  const float* out_proj_b;  /* [64][2]       lru_layer.out_proj.bias   (complex64) */
+  const float* ln1_w;       /* [64]          lru_layer.layer_norm.weight */
+  const float* ln1_b;       /* [64]          lru_layer.layer_norm.bias */
+  const float* ffn_w1;      /* [256][64]     feed_forward.w_1.weight */
+  const float* ffn_b1;      /* [256]         feed_forward.w_1.bias */
+  const float* ffn_w2;      /* [64][256]     feed_forward.w_2.weight */
+  const float* ffn_b2;      /* [64]          feed_forward.w_2.bias */
+  const float* ln2_w;       /* [64]          feed_forward.layer_norm.weight */
+  const float* ln2_b;       /* [64]          feed_forward.layer_norm.bias */
+} LrLruBlockWeights;
+
+/* LRURec state_dict (SURVEY.md 8(a) a-W). All pointers are HOST pointers, fp32. */
+typedef struct LrLruWeightsDesc {
+  int32_t num_items;        /* V; the item table has V+1 rows (row 0 = pad id, a learned row) */
+  int32_t hidden;           /* bert_hidden_units; must be 64 */
+  int32_t num_blocks;       /* bert_num_blocks; 1..LR_MAX_LRU_BLOCKS */
+  int32_t reserved;
+  const float* item_emb;    /* [V+1][64]  embedding.token.weight (tied output table) */
+  const float* item_bias;   /* [V+1]      model.bias */
+  const float* emb_ln_w;    /* [64]       embedding.layer_norm.weight */
+  const float* emb_ln_b;    /* [64]       embedding.layer_norm.bias */
+  LrLruBlockWeights blocks[LR_MAX_LRU_BLOCKS];
+} LrLruWeightsDesc;
+
+typedef struct lr_lru lr_lru_t;
+
+/* Bytes of the packed device image for a model with num_items = V, num_blocks blocks. */
+size_t lr_lru_packed_bytes(int32_t num_items, int32_t num_blocks);
+
+/* Host-side packer: state_dict layout -> the kernels' device layout (transposed projection
+ * matrices, split re/im, recurrence coefficients lambda/gamma derived once). Pure CPU; writes
+ * lr_lru_packed_bytes() bytes to host_out. The caller then copies the image to the GPU. */
+int lr_lru_pack(const LrLruWeightsDesc* desc, void* host_out, size_t host_out_bytes);
+
+/* Bind a handle to a packed image resident in DEVICE memory (kept alive by the caller).
+ * Replaces LRURec.__init__ + load_state_dict (model/lru.py:8-14, trainer/base.py:158-161). */
+int lr_lru_create(const void* packed_dev, size_t packed_bytes, int32_t num_items, int32_t num_blocks,
+                  lr_lru_t** out);
+void lr_lru_destroy(lr_lru_t* h);
+
+/* Workspace (device) bytes needed by lr_lru_retrieve_topk / lr_lru_scores_last for up to
+ * max_users histories per call. */
+size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k);
+
+/* Encode B histories and return the hidden state of the LAST position, q[B][64] (fp32).
+ * Replaces LRURec.forward up to (not including) the item GEMM, last position only
+ * (model/lru.py:38-41,57-60,73-83; consumers slice [:, -1, :]: trainer/lru.py:33,67,105,
+ * demo/inference.py:48).
+ *   ids: DEVICE int64 [B][L] row-major, 0 = pad (left padded by the reference's datasets,
+ *        dataloader/lru.py:142-151; zeros anywhere are honoured: mask = ids > 0). */
+int lr_lru_encode_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, float* out_q,
+                       void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Fused retrieve: encode -> item GEMM on the last position -> optional history/pad mask
+ * (-1e9, trainer/lru.py:35-38,72-74,110-112) -> ordered top-K.
+ * Replaces `model(seqs)[:, -1, :]` + masking loop + torch.topk / argsort
+ * (trainer/lru.py:33-38,67-84,105-126).
+ *   out_idx  : DEVICE int32 [B][K], score descending, ties -> lower item id first
+ *   out_score: DEVICE fp32  [B][K] (may be NULL)
+ *   K <= LR_MAX_TOPK. The [B][V+1] score matrix is never written to memory. */
+int lr_lru_retrieve_topk(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, int32_t K,
+                         int32_t exclude_history, int32_t* out_idx, float* out_score,
+                         void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Compatibility path: materialise last-position scores [B][V+1] (fp32), optionally masked.
+ * Replaces `self.model(seqs)[:, -1, :]` for callers that need the full score row
+ * (trainer/lru.py:33, demo/inference.py:48). */
+int lr_lru_scores_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L,
+                       int32_t exclude_history, float* out_scores, void* workspace,
+                       size_t workspace_bytes, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ranking metrics  (trainer/utils.py:43-90 with preprocessed ranks)
+ * ------------------------------------------------------------------------------------------ */
+
+/* ranked: DEVICE int32 [B][Kmax] item ids (or class ids) best-first; labels: DEVICE int64 [B].
+ * sums  : DEVICE double [3*nk] = for each k in ks (given order): Recall@k, MRR@k, NDCG@k
+ *         NUMERATORS summed over the B rows (ADDED to what is there; zero it first), so that
+ *         data-parallel ranks can all-reduce sums and divide once. ks: HOST int32[nk], each
+ *         <= Kmax, nk <= 8. */
+int lr_rank_metrics(const int32_t* ranked, int32_t Kmax, const int64_t* labels, int32_t B,
+                    const int32_t* ks, int32_t nk, double* sums, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 2: Llama-2 ranker -- single prefill + verbalizer gather
+ * (model/llm.py:35-145, HF LlamaModel, trainer/verb.py:524-544, trainer/llm.py:63-72)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct LrLlamaConfig {
+  int32_t vocab_size;
+  int32_t hidden_size;
+  int32_t intermediate_size;
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t num_kv_heads;          /* == num_heads for Llama-2-7b; GQA is supported */
+  int32_t head_dim;              /* hidden_size / num_heads */
+  int32_t max_positions;         /* RoPE table length (>= llm_max_text_len = 1536) */
+  float rms_eps;
+  float rope_theta;
+} LrLlamaConfig;
+
+/* All pointers are DEVICE pointers to bf16 (uint16) row-major [out][in] matrices, as stored
+ * by HF (nn.Linear.weight). LoRA adapters must be merged into q_proj/v_proj beforehand
+ * (W + (alpha/r) B A; config.py:257-260, train_ranker.py:71-79). */
+typedef struct LrLlamaLayerWeights {
+  const uint16_t* input_norm;    /* [hidden]                input_layernorm.weight */
+  const uint16_t* wqkv;          /* [(nh+2*nkv)*hd][hidden] q_proj;k_proj;v_proj stacked */
+  const uint16_t* wo;            /* [hidden][nh*hd]         o_proj */
+  const uint16_t* post_norm;     /* [hidden]                post_attention_layernorm.weight */
+  const uint16_t* wgu;           /* [2*inter][hidden]       gate_proj / up_proj, interleaved in
+                                    blocks of 16 rows: rows [32t,32t+16) = gate[16t..16t+16),
+                                    rows [32t+16,32t+32) = up[16t..16t+16)  (lr_llama_pack_gate_up) */
+  const uint16_t* wdown;         /* [hidden][inter]         down_proj */
+} LrLlamaLayerWeights;
+
+typedef struct LrLlamaWeightsDesc {
+  const uint16_t* embed;         /* [vocab][hidden]  model.embed_tokens.weight */
+  const uint16_t* final_norm;    /* [hidden]         model.norm.weight */
+  const uint16_t* lm_head;       /* [vocab][hidden]  lm_head.weight */
+  const LrLlamaLayerWeights* layers; /* HOST array [num_layers] of device pointers */
+} LrLlamaWeightsDesc;
+
+typedef struct lr_llama lr_llama_t;
+
+int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_llama_t** out);
+void lr_llama_destroy(lr_llama_t* h);
+
+/* Device workspace bytes for up to max_tokens packed tokens and max_seqs sequences per call. */
+size_t lr_llama_workspace_bytes(const lr_llama_t* h, int32_t max_tokens, int32_t max_seqs);
+
+/* One prefill over B packed (unpadded) prompts + verbalizer gather at each prompt's last token.
+ * Replaces LlamaForCausalLM.forward (patched, model/llm.py:35-145: logits[:, -1] in fp32) followed
+ * by ManualVerbalizer.process_logits (trainer/verb.py:546-586 == logits[:, label_token_ids],
+ * SURVEY.md 8(a) a17) -- only the C verbalizer rows of lm_head are evaluated.
+ *   packed_ids     : DEVICE int32 [total_tokens]; prompt b occupies [cu_seqlens[b], cu_seqlens[b+1])
+ *   cu_seqlens     : DEVICE int32 [B+1] AND the same values in host memory (cu_seqlens_host),
+ *                    used only for launch geometry
+ *   label_token_ids: DEVICE int32 [C]  (tokenizer.encode(chr(65+c)), trainer/verb.py:494)
+ *   out_scores     : DEVICE fp32 [B][C]
+ */
+int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                               const int32_t* cu_seqlens_host, int32_t B,
+                               const int32_t* label_token_ids, int32_t C, float* out_scores,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Compatibility: full last-position logits fp32 [B][vocab] (model/llm.py:131). */
+int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                         const int32_t* cu_seqlens_host, int32_t B, float* out_logits,
+                         void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Host helper: interleave gate_proj / up_proj rows ([inter][hidden] each, bf16) into the wgu
+ * layout above. Pure CPU. */
+int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,
+                          uint16_t* out);
+
+/* Stand-alone bf16 GEMM used by the prefill (exposed for parity tests and roofline runs):
+ * C[M][N] = A[M][K] * B[N][K]^T, bf16 in, fp32 accumulate, bf16 out; all DEVICE pointers,
+ * row-major, leading dimensions = K, K, N. variant: 0 = auto, 1 = generic (any shape),
+ * 2 = 256x256x64 MFMA tile (needs M%256==0 or padded buffers, N%256==0, K%64==0). */
+int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
+                    int32_t K, int32_t variant, void* hip_stream);
+
+/* Stand-alone varlen causal attention (exposed for parity tests):
+ * qkv: DEVICE bf16 [total][(nh+2*nkv)*hd] (RoPE already applied), out: bf16 [total][nh*hd]. */
+int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,
+                        const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads,
+                        int32_t num_kv_heads, int32_t head_dim, int32_t variant, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAMAREC_MI355X_H */
