@@ -123,13 +123,26 @@ int lr_lru_scores_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L,
  * Ranking metrics  (trainer/utils.py:43-90 with preprocessed ranks)
  * ------------------------------------------------------------------------------------------ */
 
-/* ranked: DEVICE int32 [B][Kmax] item ids (or class ids) best-first; labels: DEVICE int64 [B].
- * sums  : DEVICE double [3*nk] = for each k in ks (given order): Recall@k, MRR@k, NDCG@k
- *         NUMERATORS summed over the B rows (ADDED to what is there; zero it first), so that
- *         data-parallel ranks can all-reduce sums and divide once. ks: HOST int32[nk], each
- *         <= Kmax, nk <= 8. */
-int lr_rank_metrics(const int32_t* ranked, int32_t Kmax, const int64_t* labels, int32_t B,
-                    const int32_t* ks, int32_t nk, double* sums, void* hip_stream);
+/* Rank histogram (integer work on the GPU, exact and order-independent):
+ *   ranked: DEVICE int32 [B][Kmax] ids best-first (item ids for stage 1, class ids 0..C-1 for
+ *           stage 2); labels: DEVICE int64 [B]; hist: DEVICE int64 [Kmax+1].
+ *   hist[p] += number of rows whose label sits at rank p (0-based); hist[Kmax] += rows whose
+ *   label is not among the Kmax ranked ids. The caller zeroes hist first. Data-parallel ranks
+ *   all-reduce (sum) the histogram: every metric below is a function of it. */
+int lr_rank_histogram(const int32_t* ranked, int32_t Kmax, const int64_t* labels, int32_t B,
+                      int64_t* hist, void* hip_stream);
+
+/* Full descending ranking of C <= 64 class scores per row (ties -> lower class id first).
+ * Replaces `(-scores).argsort(dim=1)` (trainer/utils.py:55) for the reranker's [N][20]
+ * verbalizer scores (trainer/llm.py:63-72). scores: DEVICE fp32 [B][C]; out: DEVICE int32 [B][C]. */
+int lr_rank_classes(const float* scores, int32_t B, int32_t C, int32_t* out_ranked, void* hip_stream);
+
+/* Pure CPU: Recall@k / MRR@k / NDCG@k NUMERATORS (sums over users, float64) from a HOST
+ * histogram: sums[3*j+0..2] for k = ks[j]. One relevant item per user, so Recall's denominator
+ * min(k, 1) and the ideal DCG are 1 (trainer/utils.py:63-88). Divide by the user count for the
+ * reference's batch-mean (trainer/utils.py:68,76,87) / per-user average (trainer/lru.py:134-137). */
+int lr_metrics_from_histogram(const int64_t* hist, int32_t Kmax, const int32_t* ks, int32_t nk,
+                              double* sums);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2: Llama-2 ranker -- single prefill + verbalizer gather

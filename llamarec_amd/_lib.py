@@ -1,0 +1,83 @@
+"""Loader for libllamarec_mi355x.so (the C-ABI HIP library). There is NO fallback: if the
+library is missing or a call fails, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libllamarec_mi355x.so")
+_lib = None
+
+
+class LlamaRecError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/llamarec_mi355x.h declares
+PROTOTYPES = {
+    "lr_last_error": (C.c_char_p, []),
+    "lr_version": (C.c_char_p, []),
+    "lr_lru_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "lr_lru_pack": (C.c_int, [C.POINTER(A.LrLruWeightsDesc), C.c_void_p, C.c_size_t]),
+    "lr_lru_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "lr_lru_destroy": (None, [C.c_void_p]),
+    "lr_lru_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "lr_lru_encode_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_lru_retrieve_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_lru_scores_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_rank_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lr_rank_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lr_metrics_from_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "lr_llama_create": (C.c_int, [C.POINTER(A.LrLlamaConfig), C.POINTER(A.LrLlamaWeightsDesc),
+                                  C.POINTER(C.c_void_p)]),
+    "lr_llama_destroy": (None, [C.c_void_p]),
+    "lr_llama_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "lr_llama_prefill_verbalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p]),
+    "lr_llama_last_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_llama_pack_gate_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lr_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
+    "lr_attention_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+
+def lib():
+    """The loaded library with prototypes set. Raises LlamaRecError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LlamaRecError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().lr_last_error().decode("utf-8", "replace")
+        raise LlamaRecError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr(stream=None) -> int:
+    import torch
+
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)

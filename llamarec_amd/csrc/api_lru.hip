@@ -1,0 +1,149 @@
+// api_lru.hip -- C ABI entry points for stage 1 (declared in include/llamarec_mi355x.h) plus the
+// library-wide error plumbing.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void lr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* lr_last_error(void) { return g_err; }
+extern "C" const char* lr_version(void) { return "llamarec_mi355x 0.1.0 gfx950"; }
+
+extern "C" size_t lr_lru_packed_bytes(int32_t num_items, int32_t num_blocks) {
+  if (num_items < 0 || num_blocks < 1 || num_blocks > LR_MAX_LRU_BLOCKS) return 0;
+  return lr_lru_layout(num_items, num_blocks).total_floats * sizeof(float);
+}
+
+extern "C" int lr_lru_pack(const LrLruWeightsDesc* d, void* host_out, size_t host_out_bytes) {
+  if (!d || !host_out) LR_FAIL(LR_EINVAL, "lr_lru_pack: null argument");
+  if (d->hidden != LR_D) LR_FAIL(LR_EUNSUPPORTED, "lr_lru_pack: hidden=%d, only 64 is implemented", d->hidden);
+  if (d->num_blocks < 1 || d->num_blocks > LR_MAX_LRU_BLOCKS || d->num_items < 0)
+    LR_FAIL(LR_EINVAL, "lr_lru_pack: num_blocks=%d num_items=%d", d->num_blocks, d->num_items);
+  LrLruLayout L = lr_lru_layout(d->num_items, d->num_blocks);
+  if (host_out_bytes < L.total_floats * sizeof(float))
+    LR_FAIL(LR_EINVAL, "lr_lru_pack: output buffer %zu < %zu bytes", host_out_bytes, L.total_floats * sizeof(float));
+  float* o = (float*)host_out;
+  memset(o, 0, L.total_floats * sizeof(float));
+  const size_t rows = (size_t)d->num_items + 1;
+  memcpy(o + L.item_emb, d->item_emb, rows * 64 * sizeof(float));
+  memcpy(o + L.item_bias, d->item_bias, rows * sizeof(float));
+  memcpy(o + L.emb_ln_w, d->emb_ln_w, 64 * sizeof(float));
+  memcpy(o + L.emb_ln_b, d->emb_ln_b, 64 * sizeof(float));
+  for (int b = 0; b < d->num_blocks; ++b) {
+    const LrLruBlockWeights& w = d->blocks[b];
+    const LrLruBlockLayout& B = L.blk[b];
+    lr_lru_derive(w.params_log, o + B.lam_re, o + B.lam_im, o + B.gamma);
+    for (int c = 0; c < LR_H; ++c) {
+      for (int k = 0; k < 64; ++k) {
+        o[B.in_wt + (size_t)k * 256 + c] = w.in_proj_w[((size_t)c * 64 + k) * 2];
+        o[B.in_wt + (size_t)k * 256 + 128 + c] = w.in_proj_w[((size_t)c * 64 + k) * 2 + 1];
+      }
+      o[B.in_b + c] = w.in_proj_b[2 * c];
+      o[B.in_b + 128 + c] = w.in_proj_b[2 * c + 1];
+    }
+    for (int oo = 0; oo < 64; ++oo) {
+      for (int k = 0; k < LR_H; ++k) {
+        o[B.out_wt + (size_t)k * 64 + oo] = w.out_proj_w[((size_t)oo * LR_H + k) * 2];
+        o[B.out_wt + (size_t)(128 + k) * 64 + oo] = -w.out_proj_w[((size_t)oo * LR_H + k) * 2 + 1];
+      }
+      o[B.out_b + oo] = w.out_proj_b[2 * oo];
+    }
+    memcpy(o + B.ln1_w, w.ln1_w, 64 * sizeof(float));
+    memcpy(o + B.ln1_b, w.ln1_b, 64 * sizeof(float));
+    for (int j = 0; j < LR_FF; ++j)
+      for (int k = 0; k < 64; ++k) o[B.w1t + (size_t)k * 256 + j] = w.ffn_w1[(size_t)j * 64 + k];
+    memcpy(o + B.b1, w.ffn_b1, LR_FF * sizeof(float));
+    for (int oo = 0; oo < 64; ++oo)
+      for (int k = 0; k < LR_FF; ++k) o[B.w2t + (size_t)k * 64 + oo] = w.ffn_w2[(size_t)oo * LR_FF + k];
+    memcpy(o + B.b2, w.ffn_b2, 64 * sizeof(float));
+    memcpy(o + B.ln2_w, w.ln2_w, 64 * sizeof(float));
+    memcpy(o + B.ln2_b, w.ln2_b, 64 * sizeof(float));
+  }
+  return LR_OK;
+}
+
+extern "C" int lr_lru_create(const void* packed_dev, size_t packed_bytes, int32_t num_items,
+                             int32_t num_blocks, lr_lru_t** out) {
+  if (!packed_dev || !out) LR_FAIL(LR_EINVAL, "lr_lru_create: null argument");
+  size_t need = lr_lru_packed_bytes(num_items, num_blocks);
+  if (need == 0 || packed_bytes < need)
+    LR_FAIL(LR_EINVAL, "lr_lru_create: image is %zu bytes, layout needs %zu", packed_bytes, need);
+  hipPointerAttribute_t attr;
+  LR_CHECK_HIP(hipPointerGetAttributes(&attr, packed_dev));
+  if (attr.type != hipMemoryTypeDevice)
+    LR_FAIL(LR_EINVAL, "lr_lru_create: packed image must live in device memory");
+  lr_lru* h = (lr_lru*)calloc(1, sizeof(lr_lru));
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_create: out of host memory");
+  h->img = (const float*)packed_dev;
+  h->lay = lr_lru_layout(num_items, num_blocks);
+  h->device = attr.device;
+  *out = h;
+  return LR_OK;
+}
+
+extern "C" void lr_lru_destroy(lr_lru_t* h) { free(h); }
+
+static size_t q_bytes(int B) { return lr_align_up((size_t)B * 64 * sizeof(float), 256); }
+
+extern "C" size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k) {
+  (void)h;
+  if (max_users < 1) max_users = 1;
+  if (max_k < 1) max_k = 1;
+  return q_bytes(max_users) + lr_topk_workspace_bytes(max_users, max_k);
+}
+
+static int check_ids(const char* fn, const lr_lru_t* h, const void* ids, int B, int L) {
+  if (!h || !ids) LR_FAIL(LR_EINVAL, "%s: null argument", fn);
+  if (B < 0 || L < 1) LR_FAIL(LR_EINVAL, "%s: B=%d L=%d", fn, B, L);
+  return LR_OK;
+}
+
+extern "C" int lr_lru_encode_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, float* out_q,
+                                  void* workspace, size_t workspace_bytes, void* hip_stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  int rc = check_ids("lr_lru_encode_last", h, ids, B, L);
+  if (rc) return rc;
+  if (!out_q) LR_FAIL(LR_EINVAL, "lr_lru_encode_last: out_q is null");
+  return lr_launch_lru_encode(h, ids, B, L, out_q, (hipStream_t)hip_stream);
+}
+
+extern "C" int lr_lru_retrieve_topk(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, int32_t K,
+                                    int32_t exclude_history, int32_t* out_idx, float* out_score,
+                                    void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_ids("lr_lru_retrieve_topk", h, ids, B, L);
+  if (rc) return rc;
+  if (!out_idx || !workspace) LR_FAIL(LR_EINVAL, "lr_lru_retrieve_topk: null output/workspace");
+  if (K < 1 || K > LR_MAX_TOPK) LR_FAIL(LR_EINVAL, "lr_lru_retrieve_topk: K=%d outside 1..%d", K, LR_MAX_TOPK);
+  if (workspace_bytes < q_bytes(B)) LR_FAIL(LR_EWORKSPACE, "lr_lru_retrieve_topk: workspace too small");
+  float* q = (float*)workspace;
+  hipStream_t st = (hipStream_t)hip_stream;
+  rc = lr_launch_lru_encode(h, ids, B, L, q, st);
+  if (rc) return rc;
+  return lr_launch_item_topk(h, q, ids, B, L, K, exclude_history, out_idx, out_score,
+                             (char*)workspace + q_bytes(B), workspace_bytes - q_bytes(B), st);
+}
+
+extern "C" int lr_lru_scores_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L,
+                                  int32_t exclude_history, float* out_scores, void* workspace,
+                                  size_t workspace_bytes, void* hip_stream) {
+  int rc = check_ids("lr_lru_scores_last", h, ids, B, L);
+  if (rc) return rc;
+  if (!out_scores || !workspace) LR_FAIL(LR_EINVAL, "lr_lru_scores_last: null output/workspace");
+  if (workspace_bytes < q_bytes(B)) LR_FAIL(LR_EWORKSPACE, "lr_lru_scores_last: workspace too small");
+  float* q = (float*)workspace;
+  hipStream_t st = (hipStream_t)hip_stream;
+  rc = lr_launch_lru_encode(h, ids, B, L, q, st);
+  if (rc) return rc;
+  return lr_launch_item_scores(h, q, ids, B, L, exclude_history, out_scores, st);
+}

@@ -102,7 +102,6 @@ LR_HD float lr_item_score(const float* e, const float* q, float bias) {
   return acc + bias;
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 #include <math.h>
 // lambda = exp(-exp(nu_log) + i*exp(theta_log)), gamma = exp(gamma_log)  (model/lru.py:151-152).
 // Host-only (double libm, rounded once to binary32); called by BOTH the oracle and the
@@ -118,6 +117,5 @@ static inline void lr_lru_derive(const float* params_log /*[3][128]*/, float* la
     gamma[c] = (float)exp((double)params_log[2 * LR_H + c]);
   }
 }
-#endif
 
 #endif  // LR_MATH_H
