@@ -188,6 +188,10 @@ typedef struct lr_llama lr_llama_t;
 int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_llama_t** out);
 void lr_llama_destroy(lr_llama_t* h);
 
+/* Kernel selection for parity tests: 0 = auto (default), 1 = generic kernels, 2 = the MFMA
+ * 256x256x64 GEMM / head_dim-128 flash attention (an error if a shape does not fit). */
+int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant);
+
 /* Device workspace bytes for up to max_tokens packed tokens and max_seqs sequences per call. */
 size_t lr_llama_workspace_bytes(const lr_llama_t* h, int32_t max_tokens, int32_t max_seqs);
 

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "lr_llama_create": (C.c_int, [C.POINTER(A.LrLlamaConfig), C.POINTER(A.LrLlamaWeightsDesc),
                                   C.POINTER(C.c_void_p)]),
     "lr_llama_destroy": (None, [C.c_void_p]),
+    "lr_llama_set_variants": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "lr_llama_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "lr_llama_prefill_verbalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,

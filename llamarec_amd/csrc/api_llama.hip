@@ -1,10 +1,186 @@
-// TEMPORARY stubs (replaced by the real stage-2 implementation).
-#include "lr_common.h"
-extern "C" int lr_llama_create(const LrLlamaConfig*, const LrLlamaWeightsDesc*, lr_llama_t**) { LR_FAIL(LR_EUNSUPPORTED, "stub"); }
-extern "C" void lr_llama_destroy(lr_llama_t*) {}
-extern "C" size_t lr_llama_workspace_bytes(const lr_llama_t*, int32_t, int32_t) { return 0; }
-extern "C" int lr_llama_prefill_verbalize(lr_llama_t*, const int32_t*, const int32_t*, const int32_t*, int32_t, const int32_t*, int32_t, float*, void*, size_t, void*) { LR_FAIL(LR_EUNSUPPORTED, "stub"); }
-extern "C" int lr_llama_last_logits(lr_llama_t*, const int32_t*, const int32_t*, const int32_t*, int32_t, float*, void*, size_t, void*) { LR_FAIL(LR_EUNSUPPORTED, "stub"); }
-extern "C" int lr_llama_pack_gate_up(const uint16_t*, const uint16_t*, int32_t, int32_t, uint16_t*) { LR_FAIL(LR_EUNSUPPORTED, "stub"); }
-extern "C" int lr_gemm_bf16_nt(const uint16_t*, const uint16_t*, uint16_t*, int32_t, int32_t, int32_t, int32_t, void*) { LR_FAIL(LR_EUNSUPPORTED, "stub"); }
-extern "C" int lr_attention_varlen(const uint16_t*, uint16_t*, const int32_t*, const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t, void*) { LR_FAIL(LR_EUNSUPPORTED, "stub"); }
+// api_llama.hip -- C ABI entry points for stage 2 (declared in include/llamarec_mi355x.h):
+// one Llama prefill over packed prompts + verbalizer gather at each prompt's last token.
+#include <stdlib.h>
+#include <string.h>
+
+#include "llama_kernels.h"
+
+typedef unsigned short u16;
+
+extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_llama_t** out) {
+  if (!cfg || !w || !out || !w->layers) LR_FAIL(LR_EINVAL, "lr_llama_create: null argument");
+  if (cfg->num_layers < 1 || cfg->num_heads < 1 || cfg->num_kv_heads < 1 || cfg->vocab_size < 1)
+    LR_FAIL(LR_EINVAL, "lr_llama_create: bad config");
+  if (cfg->hidden_size % 8 != 0 || cfg->intermediate_size % 16 != 0)
+    LR_FAIL(LR_EUNSUPPORTED, "lr_llama_create: hidden_size %% 8 and intermediate_size %% 16 must be 0");
+  if (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim < 2 || cfg->head_dim % 2 != 0 ||
+      cfg->head_dim > 256)
+    LR_FAIL(LR_EUNSUPPORTED, "lr_llama_create: heads=%d kv_heads=%d head_dim=%d", cfg->num_heads,
+            cfg->num_kv_heads, cfg->head_dim);
+  if (cfg->max_positions < 1) LR_FAIL(LR_EINVAL, "lr_llama_create: max_positions");
+  if (!w->embed || !w->final_norm || !w->lm_head) LR_FAIL(LR_EINVAL, "lr_llama_create: null weight");
+  for (int i = 0; i < cfg->num_layers; ++i) {
+    const LrLlamaLayerWeights& l = w->layers[i];
+    if (!l.input_norm || !l.wqkv || !l.wo || !l.post_norm || !l.wgu || !l.wdown)
+      LR_FAIL(LR_EINVAL, "lr_llama_create: layer %d has a null weight", i);
+  }
+  lr_llama* h = (lr_llama*)calloc(1, sizeof(lr_llama));
+  if (!h) LR_FAIL(LR_EINVAL, "lr_llama_create: out of host memory");
+  h->cfg = *cfg;
+  h->embed = w->embed;
+  h->final_norm = w->final_norm;
+  h->lm_head = w->lm_head;
+  h->layers = (LrLlamaLayerWeights*)malloc(sizeof(LrLlamaLayerWeights) * cfg->num_layers);
+  memcpy(h->layers, w->layers, sizeof(LrLlamaLayerWeights) * cfg->num_layers);
+  LR_CHECK_HIP(hipGetDevice(&h->device));
+  *out = h;
+  return LR_OK;
+}
+
+extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
+  if (!h || gemm_variant < 0 || gemm_variant > 2 || attention_variant < 0 || attention_variant > 2)
+    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: bad argument");
+  h->gemm_variant = gemm_variant;
+  h->attn_variant = attention_variant;
+  return LR_OK;
+}
+
+extern "C" void lr_llama_destroy(lr_llama_t* h) {
+  if (!h) return;
+  free(h->layers);
+  free(h);
+}
+
+struct LlamaWs {
+  int32_t *tok_pos, *tok_seq;
+  float* rope;
+  u16 *x, *xn, *qkv, *att, *hmid;
+  size_t total;
+};
+
+static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, char* base) {
+  LlamaWs w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o += lr_align_up(bytes, 256);
+    return base + at;
+  };
+  const size_t n = (size_t)max_tokens;
+  const size_t qkv_w = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
+  w.tok_pos = (int32_t*)take(n * 4);
+  w.tok_seq = (int32_t*)take(n * 4);
+  w.rope = (float*)take((size_t)c.max_positions * (c.head_dim / 2) * 2 * sizeof(float));
+  w.x = (u16*)take(n * c.hidden_size * 2);
+  w.xn = (u16*)take(n * c.hidden_size * 2);
+  w.qkv = (u16*)take(n * qkv_w * 2);
+  w.att = (u16*)take(n * (size_t)c.num_heads * c.head_dim * 2);
+  w.hmid = (u16*)take(n * c.intermediate_size * 2);
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t lr_llama_workspace_bytes(const lr_llama_t* h, int32_t max_tokens, int32_t max_seqs) {
+  (void)max_seqs;
+  if (!h || max_tokens < 1) return 0;
+  return carve(h->cfg, max_tokens, nullptr).total;
+}
+
+// Runs the transformer body; leaves the residual stream (before the final norm) in ws.x.
+static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const int32_t* cu_host, int B,
+                    void* workspace, size_t workspace_bytes, hipStream_t st, LlamaWs* out_ws) {
+  if (!h || !ids || !cu || !cu_host || !workspace) LR_FAIL(LR_EINVAL, "llama prefill: null argument");
+  if (B < 1) LR_FAIL(LR_EINVAL, "llama prefill: B=%d", B);
+  const LrLlamaConfig& c = h->cfg;
+  if (cu_host[0] != 0) LR_FAIL(LR_EINVAL, "llama prefill: cu_seqlens[0] must be 0");
+  int maxT = 0;
+  for (int b = 0; b < B; ++b) {
+    int t = cu_host[b + 1] - cu_host[b];
+    if (t < 1) LR_FAIL(LR_EINVAL, "llama prefill: prompt %d is empty", b);
+    if (t > maxT) maxT = t;
+  }
+  if (maxT > c.max_positions)
+    LR_FAIL(LR_EINVAL, "llama prefill: prompt of %d tokens exceeds max_positions %d", maxT, c.max_positions);
+  const int n = cu_host[B];
+  LlamaWs ws = carve(c, n, (char*)workspace);
+  if (ws.total > workspace_bytes)
+    LR_FAIL(LR_EWORKSPACE, "llama prefill: workspace needs %zu bytes for %d tokens, have %zu", ws.total, n,
+            workspace_bytes);
+  const int d = c.hidden_size, f = c.intermediate_size, nh = c.num_heads, nkv = c.num_kv_heads,
+            hd = c.head_dim;
+  const int qkv_w = (nh + 2 * nkv) * hd;
+  int rc;
+#define RUN(x)              \
+  do {                      \
+    rc = (x);               \
+    if (rc) return rc;      \
+  } while (0)
+  RUN(lr_launch_token_meta(cu, B, ws.tok_pos, ws.tok_seq, st));
+  RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
+  RUN(lr_launch_embed(ids, h->embed, c.vocab_size, d, ws.x, n, st));
+  for (int l = 0; l < c.num_layers; ++l) {
+    const LrLlamaLayerWeights& w = h->layers[l];
+    RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+    RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_STORE, h->gemm_variant, st));
+    RUN(lr_launch_rope(ws.qkv, ws.tok_pos, ws.rope, n, nh + nkv, qkv_w, hd, st));
+    RUN(lr_launch_attention(ws.qkv, ws.att, cu, cu_host, ws.tok_pos, ws.tok_seq, B, n, nh, nkv, hd,
+                            h->attn_variant, nullptr, st));
+    RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st));
+    RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+    RUN(lr_launch_gemm(ws.xn, w.wgu, ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st));
+    RUN(lr_launch_gemm(ws.hmid, w.wdown, ws.x, ws.x, n, d, f, LR_EPI_RESIDUAL, h->gemm_variant, st));
+  }
+#undef RUN
+  *out_ws = ws;
+  return LR_OK;
+}
+
+extern "C" int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                                          const int32_t* cu_seqlens_host, int32_t B,
+                                          const int32_t* label_token_ids, int32_t C, float* out_scores,
+                                          void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!label_token_ids || !out_scores || C < 1) LR_FAIL(LR_EINVAL, "lr_llama_prefill_verbalize: bad label ids / output");
+  hipStream_t st = (hipStream_t)hip_stream;
+  LlamaWs ws;
+  int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
+  if (rc) return rc;
+  return lr_launch_head(ws.x, cu_seqlens, h->final_norm, h->lm_head, label_token_ids, B, C, h->cfg.hidden_size,
+                        h->cfg.rms_eps, out_scores, st);
+}
+
+extern "C" int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                                    const int32_t* cu_seqlens_host, int32_t B, float* out_logits,
+                                    void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!out_logits) LR_FAIL(LR_EINVAL, "lr_llama_last_logits: null output");
+  hipStream_t st = (hipStream_t)hip_stream;
+  LlamaWs ws;
+  int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
+  if (rc) return rc;
+  return lr_launch_head(ws.x, cu_seqlens, h->final_norm, h->lm_head, nullptr, B, h->cfg.vocab_size,
+                        h->cfg.hidden_size, h->cfg.rms_eps, out_logits, st);
+}
+
+extern "C" int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,
+                                     uint16_t* out) {
+  if (!gate || !up || !out || inter < 16 || inter % 16 != 0 || hidden < 1)
+    LR_FAIL(LR_EINVAL, "lr_llama_pack_gate_up: inter=%d (must be a multiple of 16) hidden=%d", inter, hidden);
+  for (int t = 0; t < inter / 16; ++t) {
+    memcpy(out + (size_t)(32 * t) * hidden, gate + (size_t)(16 * t) * hidden, (size_t)16 * hidden * 2);
+    memcpy(out + (size_t)(32 * t + 16) * hidden, up + (size_t)(16 * t) * hidden, (size_t)16 * hidden * 2);
+  }
+  return LR_OK;
+}
+
+extern "C" int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
+                               int32_t K, int32_t variant, void* hip_stream) {
+  if (!A || !B || !C) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt: null pointer");
+  return lr_launch_gemm(A, B, C, nullptr, M, N, K, LR_EPI_STORE, variant, (hipStream_t)hip_stream);
+}
+
+extern "C" int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,
+                                   const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads,
+                                   int32_t num_kv_heads, int32_t head_dim, int32_t variant, void* hip_stream) {
+  if (!qkv || !out || !cu_seqlens || !cu_seqlens_host || B < 1) LR_FAIL(LR_EINVAL, "lr_attention_varlen: bad argument");
+  return lr_launch_attention(qkv, out, cu_seqlens, cu_seqlens_host, nullptr, nullptr, B, cu_seqlens_host[B],
+                             num_heads, num_kv_heads, head_dim, variant, nullptr, (hipStream_t)hip_stream);
+}

@@ -1,0 +1,312 @@
+// llama_attn.hip -- varlen causal self-attention over packed prompts on gfx950.
+//
+// Replaces flash-attn 2.5.8's CUDA varlen kernel (train_ranker.py:61, attn_implementation=
+// "flash_attention_2") / HF eager attention inside LlamaModel (reached from model/llm.py:89-100).
+// Packed (unpadded) execution is legal because padding is on the left and masked
+// (SURVEY.md 8(a) a15); positions restart at 0 in every prompt.
+//
+//  attn_generic_kernel : any head_dim <= 256, GQA, one wave per (token, head). Test models.
+//  attn_mfma128_kernel : head_dim = 128, flash-style online softmax on v_mfma_f32_16x16x32_bf16.
+//    Everything is computed transposed so that no cross-lane data movement is needed:
+//      S^T = K Q^T   (A = K rows from LDS, B = Q rows held in registers)  -> lane owns ONE query
+//                     row (lane&15) and 16 of the block's 64 keys: row max/sum = 2 shuffles
+//      O^T = V^T P^T (A = V read with ds_read_b64_tr_b16 from the row-major LDS tile,
+//                     B = P straight from the S^T accumulators, packed to bf16 in-lane)
+//                     -> the O accumulator's column is again the lane's query row, so the
+//                     online-softmax rescale is lane-local.
+//    A workgroup = 4 wave64 = 128 query rows of one (prompt, head); each wave 32 rows, so every K/V
+//    fragment read from LDS feeds two MFMA column tiles. K tile XOR-swizzled by (row&15) for
+//    ds_read_b128; V tile by the dual-use swizzle (row reads + transposed reads).
+#include "llama_kernels.h"
+
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+
+// =============================================================================================
+// generic
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_generic_kernel(const u16* qkv, u16* out, const int32_t* cu, int B,
+                                                           int n_tok, int nh, int nkv, int hd) {
+  __shared__ float qs[4][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;  // (token, head)
+  if (item >= n_tok * nh) return;
+  const int tok = item / nh, h = item % nh;
+  const int kvh = h / (nh / nkv);
+  const int stride = (nh + 2 * nkv) * hd;
+  int lo = 0, hi = B;  // prompt index: largest b with cu[b] <= tok
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (cu[mid] <= tok) lo = mid; else hi = mid;
+  }
+  const int s0 = cu[lo];
+  const int pos = tok - s0;
+  const u16* qp = qkv + (size_t)tok * stride + h * hd;
+  for (int d = lane; d < hd; d += 64) qs[wave][d] = bf2f(qp[d]);
+  __builtin_amdgcn_wave_barrier();
+  const float scale = 1.0f / sqrtf((float)hd);
+  float m = -__builtin_inff(), l = 0.f;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};  // dims lane, lane+64, lane+128, lane+192
+  for (int k0 = 0; k0 <= pos; k0 += 64) {
+    const int key = k0 + lane;
+    float s = -__builtin_inff();
+    if (key <= pos) {
+      const u16* kp = qkv + (size_t)(s0 + key) * stride + (nh + kvh) * hd;
+      float acc = 0.f;
+      for (int d = 0; d < hd; ++d) acc = __builtin_fmaf(qs[wave][d], bf2f(kp[d]), acc);
+      s = acc * scale;
+    }
+    float mx = s;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sft, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __expf(m - m_new);
+    const float p = (key <= pos) ? __expf(s - m_new) : 0.f;
+    float ps = p;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) ps += __shfl_xor(ps, sft, 64);
+    l = l * alpha + ps;
+    m = m_new;
+    const float pb = bf2f(f2bf(p));  // P enters the PV product in bf16, like the MFMA path
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    const int nk = min(64, pos - k0 + 1);
+    for (int j = 0; j < nk; ++j) {
+      const float pj = __shfl(pb, j, 64);
+      const u16* vp = qkv + (size_t)(s0 + k0 + j) * stride + (nh + nkv + kvh) * hd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int d = lane + 64 * i;
+        if (d < hd) o[i] = __builtin_fmaf(pj, bf2f(vp[d]), o[i]);
+      }
+    }
+  }
+  u16* op = out + (size_t)tok * nh * hd + h * hd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int d = lane + 64 * i;
+    if (d < hd) op[d] = f2bf(o[i] / l);
+  }
+}
+
+// =============================================================================================
+// MFMA, head_dim 128
+// =============================================================================================
+#define FA_QROWS 128  // query rows per workgroup
+#define FA_KB 64      // keys per block
+
+__device__ __forceinline__ int v_off(int row, int ch) {  // dual-use swizzle, 256-byte rows
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__global__ __launch_bounds__(256) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
+                                                           const int32_t* cu, int nh, int nkv,
+                                                           int max_qblocks) {
+  __shared__ __attribute__((aligned(16))) char Ks[FA_KB * 256];
+  __shared__ __attribute__((aligned(16))) char Vs[FA_KB * 256];
+  const int hd = 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qb = max_qblocks - 1 - (int)blockIdx.x;  // heavy (late) query blocks first
+  const int tok0 = cu[b];
+  const int T = cu[b + 1] - tok0;
+  if (qb * FA_QROWS >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = lane >> 4, li = lane & 15;
+  const int kvh = h / (nh / nkv);
+  const int stride = (nh + 2 * nkv) * hd;
+  const u16* kbase = qkv + (size_t)tok0 * stride + (nh + kvh) * hd;
+  const u16* vbase = qkv + (size_t)tok0 * stride + (nh + nkv + kvh) * hd;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): row q, d = 32*ks + 8*quad + 0..7
+  bf16x8 qf[2][4];
+  int qabs[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qabs[qt] = qb * FA_QROWS + wave * 32 + qt * 16 + li;
+    const int qr = min(qabs[qt], T - 1);
+    const u16* qp = qkv + (size_t)(tok0 + qr) * stride + h * hd + quad * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+  }
+
+  floatx4 ot[2][8];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
+  float l_run[2] = {0.f, 0.f};
+
+  const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);
+  const int kb_last = q_last / FA_KB;
+  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+
+  // staging: 1024 16-byte chunks per tile, 4 per thread
+  u16x8 kreg[4], vreg[4];
+  auto load_block = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, ch = c & 15;
+      const int key = min(kb * FA_KB + row, T - 1);
+      kreg[i] = *reinterpret_cast<const u16x8*>(kbase + (size_t)key * stride + ch * 8);
+      vreg[i] = *reinterpret_cast<const u16x8*>(vbase + (size_t)key * stride + ch * 8);
+    }
+  };
+  auto store_block = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, ch = c & 15;
+      *reinterpret_cast<u16x8*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
+      *reinterpret_cast<u16x8*>(Vs + v_off(row, ch)) = vreg[i];
+    }
+  };
+
+  load_block(0);
+  store_block();
+  __syncthreads();
+
+  for (int kb = 0; kb <= kb_last; ++kb) {
+    if (kb < kb_last) load_block(kb + 1);
+
+    // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
+    floatx4 st[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = nt * 16 + li;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 256 + (((ks * 4 + quad) ^ (row & 15)) << 4));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][nt], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
+    bf16x8 pa[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -__builtin_inff();
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
+          float t = st[qt][nt][r] * sl2;
+          t = (key <= qabs[qt]) ? t : -__builtin_inff();
+          st[qt][nt][r] = t;
+          mx = fmaxf(mx, t);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+      m_run[qt] = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(st[qt][nt][r] - m_new);
+          ps += p;
+          pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
+        }
+      l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const int qp = li >> 2, p = li & 3;
+        const int row0 = ks2 * 32 + quad * 4 + qp;
+        const int ch = dt * 2 + (p >> 1);
+        const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0, ch) + 8 * (p & 1)));
+        const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0 + 16, ch) + 8 * (p & 1)));
+        bf16x8 vf;
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vf[r] = b0[r];
+          vf[4 + r] = b1[r];
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          ot[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa[qt][ks2], ot[qt][dt], 0, 0, 0);
+      }
+    }
+
+    __syncthreads();
+    if (kb < kb_last) {
+      store_block();
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qabs[qt] < T) {
+      u16* op = out + (size_t)(tok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(ot[qt][dt][r] * inv);
+        *reinterpret_cast<u16x4*>(op + dt * 16) = o;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32_t* cu_host,
+                        const int32_t* tok_pos, const int32_t* tok_seq, int B, int n_tok, int nh, int nkv,
+                        int hd, int variant, void* scratch, hipStream_t st) {
+  (void)scratch;
+  (void)tok_pos;
+  (void)tok_seq;
+  if (n_tok <= 0 || B <= 0) return LR_OK;
+  if (nh % nkv != 0) LR_FAIL(LR_EINVAL, "attention: num_heads %d not a multiple of num_kv_heads %d", nh, nkv);
+  if (variant == 0) variant = (hd == 128) ? 2 : 1;
+  if (variant == 2) {
+    if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 2 needs head_dim 128 (got %d)", hd);
+    int maxT = 0;
+    for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
+    const int mq = (maxT + FA_QROWS - 1) / FA_QROWS;
+    if (mq == 0) return LR_OK;
+    hipLaunchKernelGGL(attn_mfma128_kernel, dim3(mq, nh, B), dim3(256), 0, st, qkv, out, cu, nh, nkv, mq);
+    LR_CHECK_LAUNCH("attn_mfma128_kernel");
+  } else if (variant == 1) {
+    if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
+    const int items = n_tok * nh;
+    hipLaunchKernelGGL(attn_generic_kernel, dim3((items + 3) / 4), dim3(256), 0, st, qkv, out, cu, B,
+                       n_tok, nh, nkv, hd);
+    LR_CHECK_LAUNCH("attn_generic_kernel");
+  } else {
+    LR_FAIL(LR_EINVAL, "attention: unknown variant %d", variant);
+  }
+  return LR_OK;
+}

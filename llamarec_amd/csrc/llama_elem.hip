@@ -1,0 +1,232 @@
+// llama_elem.hip -- memory-bound pieces of the Llama prefill on gfx950: token-embedding gather,
+// RMSNorm, rotary embedding, SwiGLU (stand-alone form), final norm + verbalizer GEMV.
+//
+// Replaces the ATen kernels reached from HF LlamaModel (transformers modeling_llama.py: RMSNorm
+// with fp32 statistics, rotate_half RoPE, SiLU*mul) and, for the head, `lm_head` over ALL
+// positions + `.float()` + `[:, -1]` (model/llm.py:113-114,131) followed by the verbalizer's
+// column gather (trainer/verb.py:524-544): here only the LAST token of each prompt is normalised
+// and only the C label-word rows of lm_head are multiplied.
+//
+// All activations are bf16 with fp32 arithmetic inside a kernel; 16-byte vector accesses.
+#include "llama_kernels.h"
+
+typedef unsigned short u16;
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- token positions inside their prompt, and prompt index, for packed layouts ---------------
+__global__ void token_meta_kernel(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq) {
+  int b = blockIdx.x;
+  int s = cu[b], e = cu[b + 1];
+  for (int t = s + threadIdx.x; t < e; t += blockDim.x) {
+    tok_pos[t] = t - s;
+    tok_seq[t] = b;
+  }
+}
+
+// ---- embedding gather ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t* ids, const u16* table, int vocab,
+                                                    int d, u16* out) {
+  const int tok = blockIdx.x;
+  int id = ids[tok];
+  if (id < 0 || id >= vocab) id = 0;
+  const u16x8* src = reinterpret_cast<const u16x8*>(table + (size_t)id * d);
+  u16x8* dst = reinterpret_cast<u16x8*>(out + (size_t)tok * d);
+  for (int i = threadIdx.x; i < d / 8; i += 256) dst[i] = src[i];
+}
+
+// ---- RMSNorm: out = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) ) --------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* x, const u16* w, u16* out, int d,
+                                                      float eps, const int32_t* row_map) {
+  __shared__ float red[4];
+  const int row = row_map ? row_map[blockIdx.x] : blockIdx.x;
+  const u16x8* xr = reinterpret_cast<const u16x8*>(x + (size_t)row * d);
+  const u16x8* wr = reinterpret_cast<const u16x8*>(w);
+  u16x8* orow = reinterpret_cast<u16x8*>(out + (size_t)blockIdx.x * d);
+  const int nv = d / 8;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    u16x8 v = xr[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = bf2f(v[j]);
+      ss = __builtin_fmaf(f, f, ss);
+    }
+  }
+  ss = block_sum_256(ss, red);
+  const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    u16x8 v = xr[i], wv = wr[i], o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(f2bf(bf2f(v[j]) * rstd)));
+    orow[i] = o;
+  }
+}
+
+// ---- RoPE table: cos/sin(pos * theta^(-2i/hd)) rounded to bf16 like HF's bf16 rotary ---------
+__global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, float theta) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int half = hd / 2;
+  if (i >= T * half) return;
+  int pos = i / half, j = i % half;
+  float inv = 1.0f / powf(theta, (float)(2 * j) / (float)hd);
+  float ang = (float)pos * inv;
+  cs[2 * i + 0] = bf2f(f2bf(cosf(ang)));
+  cs[2 * i + 1] = bf2f(f2bf(sinf(ang)));
+}
+
+// rotate-half RoPE in place on the q and k heads of a packed qkv buffer [N][(nh+2nkv)*hd]
+__global__ __launch_bounds__(256) void rope_kernel(u16* qkv, const int32_t* tok_pos, const float* cs,
+                                                   int n_rot_heads, int row_stride, int hd) {
+  const int tok = blockIdx.x;
+  const int half = hd / 2;
+  const int pos = tok_pos[tok];
+  u16* row = qkv + (size_t)tok * row_stride;
+  const int per_head = half / 8;  // 8 pairs per thread-iteration
+  for (int i = threadIdx.x; i < n_rot_heads * per_head; i += 256) {
+    int h = i / per_head, c = (i % per_head) * 8;
+    u16x8* p1 = reinterpret_cast<u16x8*>(row + h * hd + c);
+    u16x8* p2 = reinterpret_cast<u16x8*>(row + h * hd + half + c);
+    u16x8 a = *p1, b = *p2, oa, ob;
+    const float* t = cs + ((size_t)pos * half + c) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float co = t[2 * j], si = t[2 * j + 1];
+      float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+      oa[j] = f2bf(x1 * co - x2 * si);
+      ob[j] = f2bf(x2 * co + x1 * si);
+    }
+    *p1 = oa;
+    *p2 = ob;
+  }
+}
+
+// generic (hd not a multiple of 16) scalar variant
+__global__ void rope_scalar_kernel(u16* qkv, const int32_t* tok_pos, const float* cs, int n_rot_heads,
+                                   int row_stride, int hd) {
+  const int tok = blockIdx.x;
+  const int half = hd / 2;
+  const int pos = tok_pos[tok];
+  u16* row = qkv + (size_t)tok * row_stride;
+  for (int i = threadIdx.x; i < n_rot_heads * half; i += blockDim.x) {
+    int h = i / half, j = i % half;
+    float co = cs[((size_t)pos * half + j) * 2], si = cs[((size_t)pos * half + j) * 2 + 1];
+    float x1 = bf2f(row[h * hd + j]), x2 = bf2f(row[h * hd + half + j]);
+    row[h * hd + j] = f2bf(x1 * co - x2 * si);
+    row[h * hd + half + j] = f2bf(x2 * co + x1 * si);
+  }
+}
+
+// ---- stand-alone SwiGLU on the interleaved gate/up layout (generic GEMM path) ---------------
+// gu [M][2f]: columns [32t,32t+16) = gate[16t..], [32t+16,32t+32) = up[16t..];  out [M][f]
+__global__ __launch_bounds__(256) void swiglu_kernel(const u16* gu, u16* out, int M, int f) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * f) return;
+  int m = (int)(i / f), c = (int)(i % f);
+  const u16* row = gu + (size_t)m * 2 * f + (c / 16) * 32 + (c % 16);
+  out[i] = swiglu_bf16(bf2f(row[0]), bf2f(row[16]));
+}
+
+// ---- final RMSNorm on each prompt's last token + dot with selected lm_head rows -------------
+// grid (B, ceil(C/32)); out[b][c] = float(bf16(sum_k xn[k] * W[row_c][k])), row_c = ids ? ids[c] : c
+__global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* cu, const u16* norm_w,
+                                                   const u16* lm_head, const int32_t* class_ids, int C,
+                                                   int d, float eps, float* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  u16* xn = reinterpret_cast<u16*>(smem_raw);  // [d]
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const int row = cu[b + 1] - 1;
+  const u16* xr = x + (size_t)row * d;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float f = bf2f(xr[i]);
+    ss = __builtin_fmaf(f, f, ss);
+  }
+  ss = block_sum_256(ss, red);
+  const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
+  for (int i = threadIdx.x; i < d; i += 256)
+    xn[i] = f2bf(bf2f(norm_w[i]) * bf2f(f2bf(bf2f(xr[i]) * rstd)));
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int cc = wave; cc < 32; cc += 4) {
+    int c = blockIdx.y * 32 + cc;
+    if (c >= C) break;
+    int r = class_ids ? class_ids[c] : c;
+    const u16* wr = lm_head + (size_t)r * d;
+    float acc = 0.f;
+    for (int k = lane * 8; k < d; k += 512) {
+      u16x8 wv = *reinterpret_cast<const u16x8*>(wr + k);
+      u16x8 xv = *reinterpret_cast<const u16x8*>(xn + k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(bf2f(wv[j]), bf2f(xv[j]), acc);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (lane == 0) out[(size_t)b * C + c] = bf2f(f2bf(acc));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, hipStream_t st) {
+  hipLaunchKernelGGL(token_meta_kernel, dim3(B), dim3(256), 0, st, cu, B, tok_pos, tok_seq);
+  LR_CHECK_LAUNCH("token_meta_kernel");
+  return LR_OK;
+}
+
+int lr_launch_embed(const int32_t* ids, const u16* table, int vocab, int d, u16* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(embed_kernel, dim3(n), dim3(256), 0, st, ids, table, vocab, d, out);
+  LR_CHECK_LAUNCH("embed_kernel");
+  return LR_OK;
+}
+
+int lr_launch_rmsnorm(const u16* x, const u16* w, u16* out, int rows, int d, float eps,
+                      const int32_t* row_map, hipStream_t st) {
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, w, out, d, eps, row_map);
+  LR_CHECK_LAUNCH("rmsnorm_kernel");
+  return LR_OK;
+}
+
+int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st) {
+  int n = T * (hd / 2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cs, T, hd, theta);
+  LR_CHECK_LAUNCH("rope_table_kernel");
+  return LR_OK;
+}
+
+int lr_launch_rope(u16* qkv, const int32_t* tok_pos, const float* cs, int n_tok, int n_rot_heads,
+                   int row_stride, int hd, hipStream_t st) {
+  if (hd % 16 == 0) {
+    hipLaunchKernelGGL(rope_kernel, dim3(n_tok), dim3(256), 0, st, qkv, tok_pos, cs, n_rot_heads, row_stride, hd);
+  } else {
+    hipLaunchKernelGGL(rope_scalar_kernel, dim3(n_tok), dim3(256), 0, st, qkv, tok_pos, cs, n_rot_heads,
+                       row_stride, hd);
+  }
+  LR_CHECK_LAUNCH("rope_kernel");
+  return LR_OK;
+}
+
+int lr_launch_swiglu(const u16* gu, u16* out, int M, int f, hipStream_t st) {
+  size_t n = (size_t)M * f;
+  hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gu, out, M, f);
+  LR_CHECK_LAUNCH("swiglu_kernel");
+  return LR_OK;
+}
+
+int lr_launch_head(const u16* x, const int32_t* cu, const u16* norm_w, const u16* lm_head,
+                   const int32_t* class_ids, int B, int C, int d, float eps, float* out, hipStream_t st) {
+  dim3 grid(B, (C + 31) / 32);
+  hipLaunchKernelGGL(head_kernel, grid, dim3(256), (size_t)d * sizeof(u16), st, x, cu, norm_w, lm_head,
+                     class_ids, C, d, eps, out);
+  LR_CHECK_LAUNCH("head_kernel");
+  return LR_OK;
+}

@@ -1,0 +1,305 @@
+// llama_gemm.hip -- bf16 GEMMs of the Llama prefill on gfx950 (CDNA4 MFMA, LDS-tiled, no BLAS).
+//   C[M][N] = A[M][K] * B[N][K]^T   (A = packed activations, B = HF nn.Linear weight [out][in])
+// with fused epilogues: plain store, residual add (o_proj / down_proj), SwiGLU (gate/up).
+//
+// Replaces (reference): every Linear of HF LlamaModel reached from model/llm.py:89-100 -- in the
+// reference bitsandbytes NF4 dequant-GEMMs with bf16 compute (train_ranker.py:49-62); here bf16
+// weights (LoRA merged offline) on v_mfma_f32_16x16x32_bf16.
+//
+// Two kernels:
+//  gemm_generic_kernel : 64x64x32 tile, any M/N/K (bounds-checked) -- tiny test models, odd shapes,
+//                        and the in-library reference for the fast kernel.
+//  gemm256_kernel      : 256x256x64 tile, 8 wave64 (2 x 4), each wave 128x64 = 8x4 MFMA tiles.
+//     * both operands stream global -> LDS with global_load_lds_dwordx4 (no VGPR staging): every
+//       wave-instruction moves 8 rows x 128 B = full cache lines; the LDS image is lane-linear
+//       (the DMA's constraint) and the 16-byte chunk a lane FETCHES is XOR-permuted
+//       (chunk ^ ((row>>1)&7)), so the ds_read_b128 fragment reads are bank-conflict free.
+//     * double-buffered K tiles (2 x 64 KiB LDS): the DMA of tile k+1 is in flight while tile k
+//       is multiplied.
+//     * MFMA operands are swapped (D = B_frag x A_frag) so each lane ends up with 4 CONSECUTIVE
+//       output columns -> 8-byte epilogue accesses, and gate/up of one SwiGLU output meet in a lane.
+//     * workgroup -> tile map: bijective XCD remap (each XCD's L2 sees a compact set of tiles)
+//       followed by a grouped (8 M-tiles) raster so neighbours share A and B panels.
+#include "llama_kernels.h"
+
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+
+// ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
+template <int EPI>
+__device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off) {
+  u16x4 o;
+  if (EPI == LR_EPI_STORE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+  } else if (EPI == LR_EPI_RESIDUAL) {
+    u16x4 r = *reinterpret_cast<const u16x4*>(R + off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(f2bf(v[j])) + bf2f(r[j]));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = swiglu_bf16(bf2f(f2bf(v[j])), bf2f(f2bf(up[j])));
+  }
+  *reinterpret_cast<u16x4*>(C + off) = o;
+}
+
+// =============================================================================================
+// generic kernel
+// =============================================================================================
+#define GG_BM 64
+#define GG_BN 64
+#define GG_BK 32
+#define GG_LD 40  // padded row length (elements): 80-byte rows keep 16-byte alignment
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const u16* __restrict__ A,
+                                                           const u16* __restrict__ B, u16* C,
+                                                           const u16* R, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) u16 As[GG_BM * GG_LD];
+  __shared__ __attribute__((aligned(16))) u16 Bs[GG_BN * GG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GG_BM, n0 = blockIdx.x * GG_BN;
+  const bool vec_ok = (K % 8 == 0);
+  floatx4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = tid >> 2, lc = (tid & 3) * 8;  // staging: row, first k of an 8-element chunk
+  for (int k0 = 0; k0 < K; k0 += GG_BK) {
+    u16x8 va, vb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) va[j] = vb[j] = 0;
+    {
+      int gr = m0 + lr, gk = k0 + lc;
+      if (gr < M) {
+        if (vec_ok && gk + 8 <= K) va = *reinterpret_cast<const u16x8*>(A + (size_t)gr * K + gk);
+        else
+          for (int j = 0; j < 8; ++j)
+            if (gk + j < K) va[j] = A[(size_t)gr * K + gk + j];
+      }
+      int gn = n0 + lr;
+      if (gn < N) {
+        if (vec_ok && gk + 8 <= K) vb = *reinterpret_cast<const u16x8*>(B + (size_t)gn * K + gk);
+        else
+          for (int j = 0; j < 8; ++j)
+            if (gk + j < K) vb[j] = B[(size_t)gn * K + gk + j];
+      }
+    }
+    __syncthreads();  // previous tile fully consumed
+    *reinterpret_cast<u16x8*>(As + lr * GG_LD + lc) = va;
+    *reinterpret_cast<u16x8*>(Bs + lr * GG_LD + lc) = vb;
+    __syncthreads();
+    bf16x8 af[2], bfr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      af[t] = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + t * 16 + (lane & 15)) * GG_LD + (lane >> 4) * 8);
+      bfr[t] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 + t * 16 + (lane & 15)) * GG_LD + (lane >> 4) * 8);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+  }
+  // epilogue (element-wise, bounds-checked): lane holds row m = lane&15, cols 4*(lane>>4)+j
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int row = m0 + wm * 32 + mt * 16 + (lane & 15);
+    if (row >= M) continue;
+    if (EPI == LR_EPI_SWIGLU) {
+      int ocol = (n0 + wn * 32) / 2 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + wn * 32 + 16 + (lane >> 4) * 4 + j < N)
+          C[(size_t)row * (N / 2) + ocol + j] =
+              swiglu_bf16(bf2f(f2bf(acc[mt][0][j])), bf2f(f2bf(acc[mt][1][j])));
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int col = n0 + wn * 32 + nt * 16 + (lane >> 4) * 4 + j;
+          if (col < N) {
+            size_t off = (size_t)row * N + col;
+            float v = bf2f(f2bf(acc[mt][nt][j]));
+            C[off] = (EPI == LR_EPI_RESIDUAL) ? f2bf(v + bf2f(R[off])) : f2bf(acc[mt][nt][j]);
+          }
+        }
+    }
+  }
+}
+
+// =============================================================================================
+// 256 x 256 x 64 kernel
+// =============================================================================================
+#define G2_STAGE_BYTES 65536  // A tile 32 KiB + B tile 32 KiB
+#define G2_GROUP_M 8
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
+                                                      const u16* __restrict__ B, u16* C,
+                                                      const u16* R, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- workgroup -> output tile
+  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
+  const int nwg = tilesM * tilesN;
+  int id;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int per_group = G2_GROUP_M * tilesN;
+    const int g = id / per_group, rem = id % per_group;
+    const int first_m = g * G2_GROUP_M;
+    const int gsz = min(G2_GROUP_M, tilesM - first_m);
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
+  }
+  const int m0 = tm << 8, n0 = tn << 8;
+
+  // ---- staging addresses: wave w moves pieces 4w..4w+3 (8 rows x 128 B each) of A and of B
+  const int srow = lane >> 3;  // row inside a piece
+  const int spos = lane & 7;   // 16-byte slot inside the 128-byte LDS row
+  const char* asrc[4];
+  const char* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + srow;
+    const int chunk = spos ^ ((row >> 1) & 7);
+    const int arow = min(m0 + row, M - 1);
+    asrc[i] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
+    bsrc[i] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* lA = smem + buf * G2_STAGE_BYTES + wave * 4096;
+    char* lB = lA + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(asrc[i] + (size_t)kt * 128, lA + i * 1024);
+      glds16(bsrc[i] + (size_t)kt * 128, lB + i * 1024);
+    }
+  };
+
+  // ---- fragment read offsets: row r of a tile lives at r*128, chunk c at ((c ^ ((r>>1)&7)) * 16)
+  const int frow = lane & 15;
+  const int fsw = frow >> 1;
+  const int foff0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);        // k-step 0: chunk = lane>>4
+  const int foff1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);  // k-step 1: chunk = 4 + lane>>4
+  const int a_base = wm * 128 * 128;
+  const int b_base = 32768 + wn * 64 * 128;
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * G2_STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = ks ? foff1 : foff0;
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        bfr[nt] = *reinterpret_cast<const bf16x8*>(base + b_base + nt * 16 * 128 + fo);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        bf16x8 afr = *reinterpret_cast<const bf16x8*>(base + a_base + mt * 16 * 128 + fo);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], afr, acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nkt = K >> 6;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds row m = lane&15 of each m-tile, 4 consecutive columns per n-tile
+  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
+    if (row < M) {
+      if (EPI == LR_EPI_SWIGLU) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
+          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+template <int EPI>
+static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
+                      hipStream_t st) {
+  if (variant == 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
+      attr_set = true;
+    }
+    const int nwg = ((M + 255) / 256) * (N / 256);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
+    LR_CHECK_LAUNCH("gemm256_kernel");
+  } else {
+    dim3 grid((N + GG_BN - 1) / GG_BN, (M + GG_BM - 1) / GG_BM);
+    hipLaunchKernelGGL(gemm_generic_kernel<EPI>, grid, dim3(256), 0, st, A, B, C, R, M, N, K);
+    LR_CHECK_LAUNCH("gemm_generic_kernel");
+  }
+  return LR_OK;
+}
+
+int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
+                   int variant, hipStream_t st) {
+  if (M <= 0) return LR_OK;
+  if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
+  const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
+  if (variant == 0) variant = (fast_ok && M >= 128) ? 2 : 1;
+  if (variant == 2 && !fast_ok)
+    LR_FAIL(LR_EUNSUPPORTED, "gemm variant 2 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
+  if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
+  if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
+  if (variant != 1 && variant != 2) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
+  switch (epi) {
+    case LR_EPI_STORE: return launch_epi<LR_EPI_STORE>(A, B, C, R, M, N, K, variant, st);
+    case LR_EPI_RESIDUAL: return launch_epi<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, variant, st);
+    case LR_EPI_SWIGLU: return launch_epi<LR_EPI_SWIGLU>(A, B, C, R, M, N, K, variant, st);
+  }
+  LR_FAIL(LR_EINVAL, "gemm: unknown epilogue %d", epi);
+}

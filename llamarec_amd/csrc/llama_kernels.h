@@ -1,0 +1,48 @@
+// llama_kernels.h -- internal launcher declarations and bf16 helpers for the stage-2 kernels.
+#ifndef LLAMA_KERNELS_H
+#define LLAMA_KERNELS_H
+
+#include "lr_common.h"
+
+__device__ __forceinline__ float bf2f(unsigned short b) {
+  return __builtin_bit_cast(float, (unsigned int)b << 16);
+}
+// round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950; NaN stays NaN)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+// HF: down_proj(act_fn(gate) * up) with bf16 tensors: gate/up already bf16-valued floats here;
+// silu output is rounded to bf16, then the product is rounded to bf16.
+__device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
+  float s = bf2f(f2bf(g / (1.0f + __expf(-g))));
+  return f2bf(s * u);
+}
+
+// epilogue modes of the GEMMs
+#define LR_EPI_STORE 0     // C = bf16(acc)
+#define LR_EPI_RESIDUAL 1  // C = bf16( bf16(acc) + R )      (R may alias C)
+#define LR_EPI_SWIGLU 2    // C[M][N/2] = swiglu over interleaved gate/up 16-column groups
+
+int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, hipStream_t st);
+int lr_launch_embed(const int32_t* ids, const unsigned short* table, int vocab, int d, unsigned short* out,
+                    int n, hipStream_t st);
+int lr_launch_rmsnorm(const unsigned short* x, const unsigned short* w, unsigned short* out, int rows, int d,
+                      float eps, const int32_t* row_map, hipStream_t st);
+int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st);
+int lr_launch_rope(unsigned short* qkv, const int32_t* tok_pos, const float* cs, int n_tok, int n_rot_heads,
+                   int row_stride, int hd, hipStream_t st);
+int lr_launch_swiglu(const unsigned short* gu, unsigned short* out, int M, int f, hipStream_t st);
+int lr_launch_head(const unsigned short* x, const int32_t* cu, const unsigned short* norm_w,
+                   const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
+                   float* out, hipStream_t st);
+
+// C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 2 256x256x64 MFMA tile.
+int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned short* C,
+                   const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st);
+
+// varlen causal attention over packed qkv (RoPE applied). variant: 0 auto, 1 generic, 2 MFMA hd=128.
+int lr_launch_attention(const unsigned short* qkv, unsigned short* out, const int32_t* cu,
+                        const int32_t* cu_host, const int32_t* tok_pos, const int32_t* tok_seq, int B,
+                        int n_tok, int nh, int nkv, int hd, int variant, void* scratch, hipStream_t st);
+
+#endif

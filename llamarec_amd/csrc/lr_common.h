@@ -123,6 +123,8 @@ struct lr_llama {
   const uint16_t* lm_head;
   LrLlamaLayerWeights* layers;  // host array
   int device;
+  int gemm_variant;  // 0 auto, 1 generic, 2 256x256x64 (falls back to generic per shape when 0)
+  int attn_variant;  // 0 auto, 1 generic, 2 MFMA head_dim 128
 };
 
 #endif  // LR_COMMON_H

@@ -1,0 +1,268 @@
+"""Llama-2 ranker -- host-side mirror of the reference's patched `LlamaForCausalLM` for the
+SCORING path, backed by the HIP prefill kernels (no torch compute in the forward, no fallback).
+
+Reference interface being replaced (paths into the reference tree):
+  LlamaForCausalLM.forward(input_ids[B,T], attention_mask[B,T], labels=...) ->
+      CausalLMOutputWithPast(loss=tensor(-1.0), logits=fp32[B,vocab])   model/llm.py:35-145
+  ManualVerbalizer.process_logits(logits) -> fp32[B,20]                 trainer/verb.py:546-586
+  weights: bf16 compute over NF4-quantised base + LoRA(q_proj,v_proj)   train_ranker.py:49-79;
+           here bf16 weights with the adapter merged at load (W + (alpha/r) B A).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from ._lib import check, lib, stream_ptr
+
+LLAMA2_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=4096,
+                 rms_norm_eps=1e-5, rope_theta=10000.0)
+
+
+@dataclass
+class CausalLMOutput:
+    """Subset of transformers' CausalLMOutputWithPast that the scoring path reads."""
+    loss: torch.Tensor | None
+    logits: torch.Tensor
+    past_key_values: None = None
+    hidden_states: None = None
+    attentions: None = None
+
+    def __getitem__(self, i):
+        return ((self.loss, self.logits) if self.loss is not None else (self.logits,))[i]
+
+
+def pack_prompts(seqs) -> tuple[np.ndarray, np.ndarray]:
+    """list of token-id sequences -> (packed int32 ids, cu_seqlens int32 [B+1])."""
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    if (lens < 1).any():
+        raise ValueError("empty prompt")
+    cu = np.zeros(len(seqs) + 1, np.int32)
+    cu[1:] = np.cumsum(lens)
+    ids = np.concatenate([np.asarray(s, dtype=np.int32).reshape(-1) for s in seqs])
+    return ids, cu
+
+
+def unpad_left(input_ids, attention_mask=None):
+    """Left-padded [B,T] batch (trainer/llm.py:34-37 pads ids with 0, mask with 0) -> list of
+    per-prompt id arrays."""
+    ids = np.asarray(input_ids.cpu() if isinstance(input_ids, torch.Tensor) else input_ids)
+    if attention_mask is None:
+        return [row for row in ids]
+    m = np.asarray(attention_mask.cpu() if isinstance(attention_mask, torch.Tensor) else attention_mask)
+    out = []
+    for r, mr in zip(ids, m):
+        n = int(mr.sum())
+        if n and not mr[-n:].all():
+            raise ValueError("attention_mask must be left padding (ones form a suffix)")
+        out.append(r[len(r) - n:])
+    return out
+
+
+class LlamaRanker:
+    """One replica of the ranker's weights on one MI355X + the prefill/verbalizer entry points."""
+
+    def __init__(self, config: dict, device="cuda:0"):
+        self.config = dict(config)
+        self.device = torch.device(device)
+        c = self.config
+        self.hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
+        self._h = C.c_void_p()
+        self._tensors = {}
+        self._ws = None
+        self._layers_arr = None
+        self.training = False
+
+    # -- construction ------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, state_dict, config, device="cuda:0", lora=None):
+        """state_dict: HF LlamaForCausalLM names -> torch tensors / numpy arrays (any float dtype).
+        lora: optional dict(r=8, alpha=32, weights={"...q_proj.lora_A.weight": A, "...lora_B.weight": B})."""
+        self = cls(config, device)
+        dev = self.device
+
+        def t(name):
+            w = state_dict[name]
+            if not isinstance(w, torch.Tensor):
+                w = torch.from_numpy(np.ascontiguousarray(w))
+            return w.to(dev)
+
+        def merged(name):
+            w = t(name).float()
+            if lora is not None:
+                base = name[: -len(".weight")]
+                ka, kb = base + ".lora_A.weight", base + ".lora_B.weight"
+                if ka in lora["weights"]:
+                    a = torch.as_tensor(np.asarray(lora["weights"][ka])).to(dev).float()
+                    b = torch.as_tensor(np.asarray(lora["weights"][kb])).to(dev).float()
+                    w = w + (lora["alpha"] / lora["r"]) * (b @ a)
+            return w
+
+        L = config["num_hidden_layers"]
+        T = self._tensors
+        T["embed"] = t("model.embed_tokens.weight").to(torch.bfloat16).contiguous()
+        T["final_norm"] = t("model.norm.weight").to(torch.bfloat16).contiguous()
+        T["lm_head"] = (t("lm_head.weight") if "lm_head.weight" in state_dict else T["embed"]).to(torch.bfloat16).contiguous()
+        for i in range(L):
+            p = f"model.layers.{i}."
+            q, k, v = (merged(p + f"self_attn.{n}_proj.weight") for n in "qkv")
+            T[f"{i}.wqkv"] = torch.cat([q, k, v], 0).to(torch.bfloat16).contiguous()
+            T[f"{i}.wo"] = t(p + "self_attn.o_proj.weight").to(torch.bfloat16).contiguous()
+            T[f"{i}.wgu"] = self._interleave_gate_up(t(p + "mlp.gate_proj.weight"), t(p + "mlp.up_proj.weight"))
+            T[f"{i}.wdown"] = t(p + "mlp.down_proj.weight").to(torch.bfloat16).contiguous()
+            T[f"{i}.input_norm"] = t(p + "input_layernorm.weight").to(torch.bfloat16).contiguous()
+            T[f"{i}.post_norm"] = t(p + "post_attention_layernorm.weight").to(torch.bfloat16).contiguous()
+        self._create()
+        return self
+
+    @classmethod
+    def random_init(cls, config, seed=42, std=0.02, device="cuda:0"):
+        """Random bf16 weights ~ N(0, std) generated directly on the GPU (BASELINE.md section 3:
+        no checkpoints exist offline). Norm weights are ones."""
+        self = cls(config, device)
+        c, dev = self.config, self.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        d, f, v = c["hidden_size"], c["intermediate_size"], c["vocab_size"]
+        nh, nkv, hd = c["num_attention_heads"], c["num_key_value_heads"], self.hd
+
+        def rnd(*shape):
+            return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * std).to(torch.bfloat16)
+
+        T = self._tensors
+        T["embed"] = rnd(v, d)
+        T["final_norm"] = torch.ones(d, dtype=torch.bfloat16, device=dev)
+        T["lm_head"] = rnd(v, d)
+        for i in range(c["num_hidden_layers"]):
+            T[f"{i}.wqkv"] = rnd((nh + 2 * nkv) * hd, d)
+            T[f"{i}.wo"] = rnd(d, nh * hd)
+            T[f"{i}.wgu"] = rnd(2 * f, d)  # already in the interleaved gate/up layout (random anyway)
+            T[f"{i}.wdown"] = rnd(d, f)
+            T[f"{i}.input_norm"] = torch.ones(d, dtype=torch.bfloat16, device=dev)
+            T[f"{i}.post_norm"] = torch.ones(d, dtype=torch.bfloat16, device=dev)
+        self._create()
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path, device="cuda:0", adapter_path=None):
+        """Local HF directory (config.json + *.safetensors), optionally a PEFT LoRA adapter directory
+        (adapter_config.json + adapter_model.safetensors) merged at load. No network access."""
+        from safetensors import safe_open
+
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        sd = {}
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors"):
+                with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
+                    for k in f.keys():
+                        sd[k] = f.get_tensor(k)
+        lora = None
+        if adapter_path:
+            ac = json.load(open(os.path.join(adapter_path, "adapter_config.json")))
+            w = {}
+            with safe_open(os.path.join(adapter_path, "adapter_model.safetensors"), framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    w[k.replace("base_model.model.", "").replace(".default", "")] = f.get_tensor(k).float().numpy()
+            lora = dict(r=ac["r"], alpha=ac["lora_alpha"], weights=w)
+        return cls.from_state_dict(sd, cfg, device, lora)
+
+    @staticmethod
+    def _interleave_gate_up(gate, up):
+        f, d = gate.shape
+        if f % 16:
+            raise ValueError("intermediate_size must be a multiple of 16")
+        g = gate.to(torch.bfloat16).view(f // 16, 16, d)
+        u = up.to(torch.bfloat16).view(f // 16, 16, d)
+        return torch.stack([g, u], dim=1).reshape(2 * f, d).contiguous()
+
+    def _create(self):
+        c, T = self.config, self._tensors
+        cfg = A.LrLlamaConfig(
+            vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+            num_layers=c["num_hidden_layers"], num_heads=c["num_attention_heads"],
+            num_kv_heads=c["num_key_value_heads"], head_dim=self.hd,
+            max_positions=int(c.get("max_position_embeddings", 4096)), rms_eps=float(c["rms_norm_eps"]),
+            rope_theta=float(c.get("rope_theta", 10000.0)))
+        L = c["num_hidden_layers"]
+        arr = (A.LrLlamaLayerWeights * L)()
+        for i in range(L):
+            for field in ("input_norm", "wqkv", "wo", "post_norm", "wgu", "wdown"):
+                setattr(arr[i], field, T[f"{i}.{field}"].data_ptr())
+        desc = A.LrLlamaWeightsDesc(embed=T["embed"].data_ptr(), final_norm=T["final_norm"].data_ptr(),
+                                    lm_head=T["lm_head"].data_ptr(), layers=arr)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            check(lib().lr_llama_create(C.byref(cfg), C.byref(desc), C.byref(h)), "lr_llama_create")
+        self._h, self._layers_arr = h, arr
+
+    def set_variants(self, gemm=0, attention=0):
+        check(lib().lr_llama_set_variants(self._h, gemm, attention), "lr_llama_set_variants")
+        return self
+
+    def eval(self):
+        return self
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                lib().lr_llama_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- scoring -----------------------------------------------------------------------------
+    def _workspace(self, n_tokens, n_seqs):
+        need = lib().lr_llama_workspace_bytes(self._h, n_tokens, n_seqs)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _packed(self, seqs):
+        ids, cu = pack_prompts(seqs)
+        return (torch.from_numpy(ids).to(self.device), torch.from_numpy(cu).to(self.device), cu)
+
+    def prefill_verbalize_packed(self, ids_dev, cu_dev, cu_host, label_ids_dev, out=None):
+        """Device-resident inputs (the benchmark's timed region starts here)."""
+        B, Cn = len(cu_host) - 1, label_ids_dev.numel()
+        if out is None:
+            out = torch.empty((B, Cn), dtype=torch.float32, device=self.device)
+        ws = self._workspace(int(cu_host[-1]), B)
+        with torch.cuda.device(self.device):
+            check(lib().lr_llama_prefill_verbalize(
+                self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), cu_host.ctypes.data, B, label_ids_dev.data_ptr(),
+                Cn, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()), "lr_llama_prefill_verbalize")
+        return out
+
+    def prefill_verbalize(self, seqs, label_token_ids):
+        """scores[b, c] = logit of label word c at the last token of prompt b (fp32 [B, C])."""
+        ids, cu, cu_host = self._packed(seqs)
+        lab = torch.as_tensor(np.asarray(label_token_ids, dtype=np.int32)).to(self.device)
+        return self.prefill_verbalize_packed(ids, cu, cu_host, lab)
+
+    def last_logits(self, seqs):
+        ids, cu, cu_host = self._packed(seqs)
+        B = len(cu_host) - 1
+        out = torch.empty((B, self.config["vocab_size"]), dtype=torch.float32, device=self.device)
+        ws = self._workspace(int(cu_host[-1]), B)
+        with torch.cuda.device(self.device):
+            check(lib().lr_llama_last_logits(self._h, ids.data_ptr(), cu.data_ptr(), cu_host.ctypes.data, B,
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+                  "lr_llama_last_logits")
+        return out
+
+    def forward(self, input_ids=None, attention_mask=None, labels=None, **_unused):
+        """Patched-forward compatible call (model/llm.py:35-143): last-position logits in fp32;
+        in eval with labels the loss is the constant -1.0 (model/llm.py:128-129)."""
+        logits = self.last_logits(unpad_left(input_ids, attention_mask))
+        loss = torch.tensor(-1.0) if labels is not None else None
+        return CausalLMOutput(loss=loss, logits=logits)
+
+    __call__ = forward

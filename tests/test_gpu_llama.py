@@ -1,0 +1,212 @@
+"""GPU parity for stage 2 (through the C ABI): bf16 MFMA GEMMs, varlen causal attention, the full
+prefill + verbalizer gather, against the numpy oracle and the reference's HF goldens.
+
+Tolerances (bf16 compute, fp32 accumulate; the reference runs bf16_full_eval, trainer/llm.py:113):
+  GEMM / attention outputs : <= 1 bf16 ulp of the fp32-accumulated result (rtol 2^-7)
+  last-position logits     : |gpu - oracle_bf16| <= 3e-2 and |gpu - HF bf16 golden| <= 3e-2 on
+                             tiny models whose logits are O(1)
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from llamarec_amd.synth import bf16_bits_to_f32, bf16_round, f32_to_bf16_bits, hash_uniform, synth_llama_state
+
+
+def dev_bf16(x):
+    return torch.from_numpy(f32_to_bf16_bits(x).view(np.int16)).cuda()
+
+
+def host_f32(t):
+    return bf16_bits_to_f32(t.cpu().numpy().view(np.uint16))
+
+
+def gemm(A, B, variant):
+    from llamarec_amd._lib import check, lib, stream_ptr
+
+    M, K = A.shape
+    N = B.shape[0]
+    a, b = dev_bf16(A), dev_bf16(B)
+    c = torch.full((M, N), 0x7FC0, dtype=torch.int16, device="cuda")  # NaN poison
+    check(lib().lr_gemm_bf16_nt(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, variant, stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    return host_f32(c)
+
+
+def assert_bf16_close(got, ref32, what, absum=None):
+    """<= 1 bf16 ulp of the result, plus fp32 accumulation noise where the sum cancels
+    (absum = sum_k |a||b| bounds the partial sums)."""
+    ref = bf16_round(ref32)
+    err = np.abs(got - ref32)
+    tol = np.maximum(np.abs(ref32), 1e-3) * 2.0 ** -7 + (0 if absum is None else 2e-6 * absum)
+    assert np.isfinite(got).all(), what
+    assert (err <= tol).all(), f"{what}: max err {err.max()} (worst ratio {(err / tol).max()})"
+    assert (got == ref).mean() > 0.9, f"{what}: only {(got == ref).mean():.3f} exactly equal"
+
+
+@pytest.mark.parametrize("M,N,K,variant", [
+    (5, 7, 24, 1), (64, 64, 32, 1), (70, 130, 100, 1), (33, 96, 51, 1),
+    (256, 256, 64, 2), (300, 512, 256, 2), (1, 256, 128, 2), (1000, 256, 4096, 2), (515, 768, 704, 2),
+    (300, 512, 256, 0),
+])
+def test_gemm_vs_numpy(M, N, K, variant):
+    A = bf16_round(hash_uniform(M * 7 + K, (M, K), 1.0))
+    B = bf16_round(hash_uniform(N * 13 + K, (N, K), 1.0))
+    got = gemm(A, B, variant)
+    assert_bf16_close(got, A @ B.T, f"gemm {M}x{N}x{K} v{variant}", np.abs(A) @ np.abs(B).T)
+
+
+def test_gemm_fast_equals_generic_on_integers():
+    """Exact integer data: any tiling / fragment-layout mistake shows up as a wrong integer."""
+    M, N, K = 384, 512, 192
+    A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)   # asymmetric patterns
+    B = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
+    ref = A @ B.T
+    for v in (1, 2):
+        assert np.array_equal(gemm(A, B, v), bf16_round(ref)), v
+
+
+def attention(qkv, cu, nh, nkv, hd, variant):
+    from llamarec_amd._lib import check, lib, stream_ptr
+
+    n = qkv.shape[0]
+    q = dev_bf16(qkv)
+    out = torch.full((n, nh * hd), 0x7FC0, dtype=torch.int16, device="cuda")
+    cu = np.ascontiguousarray(cu, dtype=np.int32)
+    cud = torch.from_numpy(cu).cuda()
+    check(lib().lr_attention_varlen(q.data_ptr(), out.data_ptr(), cud.data_ptr(), cu.ctypes.data, len(cu) - 1,
+                                    nh, nkv, hd, variant, stream_ptr()), "attention")
+    torch.cuda.synchronize()
+    return host_f32(out)
+
+
+def attention_ref(qkv, cu, nh, nkv, hd):
+    n = qkv.shape[0]
+    out = np.zeros((n, nh * hd), np.float32)
+    for b in range(len(cu) - 1):
+        s, e = cu[b], cu[b + 1]
+        T = e - s
+        q = qkv[s:e, : nh * hd].reshape(T, nh, hd)
+        k = qkv[s:e, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd)
+        v = qkv[s:e, (nh + nkv) * hd:].reshape(T, nkv, hd)
+        mask = np.tril(np.ones((T, T), bool))
+        for h in range(nh):
+            sc = (q[:, h] @ k[:, h // (nh // nkv)].T) / np.sqrt(np.float32(hd))
+            sc = np.where(mask, sc, -np.inf)
+            p = np.exp(sc - sc.max(-1, keepdims=True))
+            out[s:e, h * hd:(h + 1) * hd] = (bf16_round(p.astype(np.float32)) @ v[:, h // (nh // nkv)]) / p.sum(-1, keepdims=True)
+    return out
+
+
+@pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 1), (4, 2, 16, 1), (2, 2, 64, 1)])
+def test_attention_vs_numpy(nh, nkv, hd, variant):
+    lens = [1, 63, 64, 65, 128, 129, 300, 2]
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    qkv = bf16_round(hash_uniform(nh * 100 + hd, (cu[-1], (nh + 2 * nkv) * hd), 1.0))
+    got = attention(qkv, cu, nh, nkv, hd, variant)
+    ref = attention_ref(qkv, cu, nh, nkv, hd)
+    err = np.abs(got - ref)
+    assert np.isfinite(got).all()
+    assert err.max() < 1.5e-2, err.max()  # |out| <= 1 here; bf16 P and bf16 output rounding
+
+
+def load_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"llama_{name}.npz"))
+    cfg = json.loads(str(z["config"]))
+    sd = synth_llama_state(cfg, int(z["weight_seed"]))
+    T = z["input_ids"].shape[1]
+    seqs = [z["input_ids"][b, T - n:] for b, n in enumerate(z["lens"])]
+    return z, cfg, sd, seqs
+
+
+@pytest.mark.parametrize("name,variants", [("tiny_hd16", (0, 0)), ("tiny_gqa", (0, 0)), ("tiny_hd128", (1, 1)),
+                                           ("tiny_hd128", (2, 2)), ("tiny_hd128", (0, 0))])
+def test_prefill_logits_vs_oracle_and_reference(golden_dir, name, variants):
+    from llamarec_amd.llm import LlamaRanker
+    from oracle import llama_oracle as LO
+
+    z, cfg, sd, seqs = load_golden(golden_dir, name)
+    model = LlamaRanker.from_state_dict(sd, cfg).set_variants(*variants)
+    got = model.last_logits(seqs).cpu().numpy()
+    orc = LO.last_logits(sd, cfg, seqs, "bf16")
+    assert got.dtype == np.float32 and got.shape == orc.shape
+    assert np.abs(got - orc).max() < 3e-2
+    assert np.abs(got - z["logits_bf16"]).max() < 3e-2   # the reference's own bf16 run
+    assert np.abs(got - z["logits_fp32"]).max() < 3e-2
+    # logits are bf16 values widened to fp32, like `lm_head(h).float()` of a bf16 model
+    assert np.array_equal(got, bf16_round(got))
+
+
+def test_verbalizer_gather_and_patched_forward_interface(golden_dir):
+    from llamarec_amd.llm import LlamaRanker
+
+    z, cfg, sd, seqs = load_golden(golden_dir, "tiny_hd128")
+    model = LlamaRanker.from_state_dict(sd, cfg)
+    logits = model.last_logits(seqs)
+    label_ids = [17, 3, 319, 5, 200, 42, 7, 99, 100, 101, 150, 151, 152, 153, 154, 155, 156, 157, 158, 159]
+    scores = model.prefill_verbalize(seqs, label_ids)
+    assert scores.shape == (len(seqs), 20) and scores.dtype == torch.float32
+    assert torch.equal(scores, logits[:, label_ids])            # trainer/verb.py:524-544 == gather
+    # reference call shape: left-padded ids + mask + labels -> (loss=-1.0, logits[B,vocab])
+    out = model(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+                labels=torch.zeros(len(seqs), 1, dtype=torch.long))
+    assert float(out.loss) == -1.0 and torch.equal(out.logits, logits)
+    assert model(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"])).loss is None
+
+
+def test_lora_merge_and_gate_up_packing(golden_dir):
+    from llamarec_amd._lib import check, lib
+    from llamarec_amd.llm import LlamaRanker
+    from oracle import llama_oracle as LO
+
+    z, cfg, sd, seqs = load_golden(golden_dir, "tiny_hd16")
+    r, alpha = 8, 32
+    lw, sd2 = {}, dict(sd)
+    for i in range(cfg["num_hidden_layers"]):
+        for pj in ("q_proj", "v_proj"):
+            base = f"model.layers.{i}.self_attn.{pj}"
+            a = hash_uniform(900 + i, (r, cfg["hidden_size"]), 0.05)
+            b = hash_uniform(950 + i, (sd[base + ".weight"].shape[0], r), 0.05)
+            lw[base + ".lora_A.weight"], lw[base + ".lora_B.weight"] = a, b
+            sd2[base + ".weight"] = bf16_round(sd[base + ".weight"] + (alpha / r) * (b @ a))
+    model = LlamaRanker.from_state_dict(sd, cfg, lora=dict(r=r, alpha=alpha, weights=lw))
+    got = model.last_logits(seqs).cpu().numpy()
+    assert np.abs(got - LO.last_logits(sd2, cfg, seqs, "bf16")).max() < 3e-2
+    assert np.abs(got - z["logits_bf16"]).max() > 3e-2  # the adapter really changed the model
+    # host packer == the torch interleave used at load
+    g = f32_to_bf16_bits(sd["model.layers.0.mlp.gate_proj.weight"])
+    u = f32_to_bf16_bits(sd["model.layers.0.mlp.up_proj.weight"])
+    out = np.empty((2 * g.shape[0], g.shape[1]), np.uint16)
+    check(lib().lr_llama_pack_gate_up(g.ctypes.data, u.ctypes.data, g.shape[0], g.shape[1], out.ctypes.data), "pack")
+    assert np.array_equal(out.view(np.int16), model._tensors["0.wgu"].view(torch.int16).cpu().numpy())
+
+
+def test_full_width_batch_invariance():
+    """Llama-2-7b layer shapes (d=4096, 32 heads x 128, d_ff=11008, vocab 32000), 1 layer, synthetic
+    weights: a prompt's scores must not depend on what else is in the packed batch or on its
+    position in it (bit-exact), and padding rows of the 256-row GEMM tiles must not leak."""
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+
+    cfg = dict(LLAMA2_7B, num_hidden_layers=1)
+    model = LlamaRanker.random_init(cfg, seed=7)
+    rng = np.random.default_rng(0)
+    lens = [5, 300, 129, 64, 1, 511]
+    seqs = [np.concatenate([[1], rng.integers(3, 32000, size=n - 1)]) if n > 1 else np.array([1]) for n in lens]
+    label_ids = list(range(319, 339))
+    full = model.prefill_verbalize(seqs, label_ids)
+    assert torch.isfinite(full).all()
+    perm = [3, 0, 5, 1, 4, 2]
+    shuffled = model.prefill_verbalize([seqs[i] for i in perm], label_ids)
+    assert torch.equal(shuffled, full[perm])
+    for i in (0, 2, 4):
+        alone = model.prefill_verbalize([seqs[i]], label_ids)
+        assert torch.equal(alone[0], full[i])
+    # generic kernels agree with the MFMA kernels at bf16 resolution on the same weights
+    gen = model.set_variants(1, 1).prefill_verbalize(seqs[:3], label_ids)
+    assert (gen - full[:3]).abs().max() < 5e-2 * max(1.0, float(full.abs().max()))
