@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- users/sec through the two-stage retrieve+rerank scoring path on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): ML-100k shape --
+LRURec (V=3650, L=200, D=64, 2 blocks) retrieve top-50 with history masking, then ONE Llama-2-7b
+(32 layers, bf16, random weights) prefill over the templated prompts of the same users and the
+verbalizer gather over the 20 candidate letters. Synthetic data per BASELINE.md section 3.
+A step = one pass of the hot path over one batch of 32 users (the reference's ranker eval batch,
+config.py:98). Inputs (history ids, labels, prompt token ids) are resident in HBM before the
+timed region. One process per GPU; users are sharded, weights replicated; the only collective is
+the final all-reduce of the int64 rank histograms (inside the timed region).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (256x256x64 bf16 MFMA GEMM): algorithmic FLOPs per launch over
+                  its measured duration (HIP events recorded by the library on the launch stream)
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm) timed on the host cores on a
+                  bounded sample of the same workload (N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ml-100k")
+    ap.add_argument("--layers", type=int, default=32, help="Llama layers (32 = Llama-2-7b; other values are for profiling only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, hist_ids, T_sample, lru_sd):
+    """Oracle ("port") timed on the host: stage 1 over the shard's users; stage 2 on 4 users x 2 of
+    the 32 Llama-2-7b layers, extrapolated x16 (a full 7B prefill is ~5 TFLOP per user)."""
+    from oracle import llama_oracle as LO
+    from oracle import lru_oracle as O
+
+    cores = len(os.sched_getaffinity(0))
+    orc = O.LruOracle(lru_sd)
+    t0 = time.perf_counter()
+    orc.retrieve_topk(hist_ids, 50, True)
+    t1 = time.perf_counter() - t0
+    s1_per_user = t1 / len(hist_ids)
+
+    cfg = dict(vocab_size=2048, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+               num_attention_heads=32, num_key_value_heads=32, rms_norm_eps=1e-5, rope_theta=10000.0)
+    rng = np.random.default_rng(0)
+    from llamarec_amd.synth import llama_param_shapes
+
+    sd = {}
+    for name, shape in llama_param_shapes(cfg):
+        sd[name] = np.ones(shape, np.float32) if len(shape) == 1 else \
+            rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
+    seqs = [np.concatenate([[1], rng.integers(3, 2048, size=int(t) - 1)]) for t in T_sample]
+    t0 = time.perf_counter()
+    LO.prefill_verbalize(sd, cfg, seqs, list(range(100, 120)), mode="bf16")
+    t2 = time.perf_counter() - t0
+    s2_per_user = t2 / len(seqs) * (32 / 2)
+    return {
+        "value": 1.0 / (s1_per_user + s2_per_user), "unit": "users/s", "cores": cores, "kind": "port",
+        "sample": (f"stage 1: C oracle (OpenMP) over {len(hist_ids)} {workload} users = {t1:.2f} s; stage 2: numpy "
+                   f"oracle, {len(seqs)} users (T={[int(t) for t in T_sample]}) x 2 of 32 Llama-2-7b layers "
+                   f"= {t2:.2f} s, extrapolated x16"),
+        "stage1_users_per_s": 1.0 / s1_per_user, "stage2_users_per_s_extrapolated": 1.0 / s2_per_user,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    from llamarec_amd import dist as D
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    from llamarec_amd import _lib
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.pipeline import TwoStagePipeline
+    from llamarec_amd.synth import WORKLOADS, synth_prompt_tokens, synth_users
+
+    w = WORKLOADS[args.workload]
+    bsz = w["rerank_batch"]
+    n_shard = min(w["U"], max(bsz, args.steps * bsz))  # users this rank needs resident
+    hist, labels, n_hist, T = synth_users(args.workload, n_shard, first_user=rank * w["U"])
+    nb = max(1, len(hist) // bsz)
+    batches = []
+    for b in range(nb):
+        sl = slice(b * bsz, (b + 1) * bsz)
+        pids, cu = synth_prompt_tokens(T[sl], seed=1000 * (rank + 1) + b)
+        batches.append((torch.from_numpy(hist[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev),
+                        torch.from_numpy(pids).to(dev), torch.from_numpy(cu).to(dev), cu))
+
+    lru_sd = init_lru_state_dict(w["V"], seed=42)
+    retriever = LRURec.from_state_dict(lru_sd, device=dev)
+    cfg = dict(LLAMA2_7B, num_hidden_layers=args.layers)
+    ranker = LlamaRanker.random_init(cfg, seed=42, device=dev)
+    label_ids = list(range(319, 339))  # stand-in ids of "A".."T" (taken from the tokenizer at run time in real use)
+    pipe = TwoStagePipeline(retriever, ranker, label_ids, device=dev)
+
+    for i in range(args.warmup):
+        pipe.step(*batches[i % nb])
+    pipe.reset()
+    torch.cuda.synchronize()
+
+    lib = _lib.lib()
+    if not args.no_profile:
+        _lib.check(lib.lr_profile_start(args.steps * (args.layers * 6 + 16)), "lr_profile_start")
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pipe.step(*batches[i % nb])
+    retr, rer, total_users = pipe.finish()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.lr_profile_stop()
+    elapsed = D.all_reduce_max_float(elapsed, device=dev)
+
+    users = args.steps * bsz * world
+    tok_per_step = float(np.mean([b[4][-1] for b in batches]))
+
+    def collect(kind):
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        lib.lr_profile_collect(kind, C.byref(ms), C.byref(work), C.byref(n))
+        return ms.value, work.value, n.value
+
+    roofline = None
+    extra = {}
+    if not args.no_profile:
+        g_ms, g_fl, g_n = collect(0)
+        a_ms, a_fl, a_n = collect(2)
+        e_ms, _, e_n = collect(4)
+        k_ms, k_fl, k_n = collect(5)
+        if g_n:
+            ach = g_fl / (g_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm256_kernel (bf16 256x256x64 MFMA tile; QKV/O/gate-up/down)",
+                        "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                        "traffic": None, "launches": g_n, "avg_launch_ms": g_ms / g_n,
+                        "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed}
+        extra = {"attention_tflops": (a_fl / (a_ms * 1e-3) / 1e12) if a_n else None,
+                 "attention_share_of_step_time": a_ms * 1e-3 / elapsed if a_n else None,
+                 "stage1_ms_per_step": (e_ms + k_ms) / max(1, args.steps),
+                 "item_topk_tflops_f32": (k_fl / (k_ms * 1e-3) / 1e12) if k_n else None}
+
+    # stage-1-only throughput over the whole resident shard (one call; reported, not the metric)
+    all_hist = torch.from_numpy(hist).to(dev)
+    retriever.retrieve_topk(all_hist, 50, True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    retriever.retrieve_topk(all_hist, 50, True)
+    torch.cuda.synchronize()
+    stage1_users_per_s = len(hist) / (time.perf_counter() - t1)
+
+    if rank == 0:
+        out = {
+            "metric": "users/sec through retrieve+rerank", "value": users / elapsed, "unit": "users/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": (f"{args.workload} two-stage: LRURec(V={w['V']}, L={w['L']}, D=64, 2 blocks) top-50 with "
+                                    f"history mask -> Llama-2-7b ({args.layers} layers, bf16, random init) single prefill "
+                                    f"-> verbalizer over 20 candidates"),
+                       "users_per_step": bsz, "mean_prompt_tokens_per_step": tok_per_step,
+                       "llama_layers": args.layers, "parallelism": f"dp{world}"},
+            "roofline": roofline, "stage1_only_users_per_s": stage1_users_per_s,
+            "metrics": {"retrieve_NDCG@10": retr["NDCG@10"], "rerank_overall_NDCG@10": rer["NDCG@10"],
+                        "users_counted": total_users},
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, hist, T[:4], lru_sd)
+        print(json.dumps(out))
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,8 +134,11 @@ int lr_rank_histogram(const int32_t* ranked, int32_t Kmax, const int64_t* labels
 
 /* Full descending ranking of C <= 64 class scores per row (ties -> lower class id first).
  * Replaces `(-scores).argsort(dim=1)` (trainer/utils.py:55) for the reranker's [N][20]
- * verbalizer scores (trainer/llm.py:63-72). scores: DEVICE fp32 [B][C]; out: DEVICE int32 [B][C]. */
-int lr_rank_classes(const float* scores, int32_t B, int32_t C, int32_t* out_ranked, void* hip_stream);
+ * verbalizer scores (trainer/llm.py:63-72). scores: DEVICE fp32 [B][C]; out: DEVICE int32 [B][C].
+ * items (DEVICE int32 [B][C], may be NULL): when given, out[b][rank] = items[b][class] -- the
+ * candidate item ids in reranked order -- instead of the class id. */
+int lr_rank_classes(const float* scores, int32_t B, int32_t C, const int32_t* items,
+                    int32_t* out_ranked, void* hip_stream);
 
 /* Pure CPU: Recall@k / MRR@k / NDCG@k NUMERATORS (sums over users, float64) from a HOST
  * histogram: sums[3*j+0..2] for k = ks[j]. One relevant item per user, so Recall's denominator
@@ -232,6 +235,19 @@ int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M
 int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,
                         const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads,
                         int32_t num_kv_heads, int32_t head_dim, int32_t variant, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optional in-library kernel timing (HIP events on the caller's stream). Not part of the
+ * reference's surface: it exists so a benchmark can report the measured duration and the
+ * algorithmic work of each kernel family over its timed region.
+ *   kinds: 0 gemm 256x256x64 (work = flops), 1 generic gemm (flops), 2 MFMA attention (flops),
+ *          3 generic attention (flops), 4 LRU encoder (users), 5 item GEMM + top-K (flops)
+ * lr_profile_start/stop bracket the region (start allocates events: call it outside graph
+ * capture); lr_profile_collect is valid after the stream has been synchronised.
+ * ------------------------------------------------------------------------------------------ */
+int lr_profile_start(int32_t max_records);
+int lr_profile_stop(void);
+int lr_profile_collect(int32_t kind, double* total_ms, double* total_work, int64_t* launches);
 
 #ifdef __cplusplus
 }

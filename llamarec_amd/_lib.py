@@ -33,7 +33,11 @@ PROTOTYPES = {
     "lr_lru_scores_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_rank_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "lr_rank_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lr_rank_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lr_profile_start": (C.c_int, [C.c_int32]),
+    "lr_profile_stop": (C.c_int, []),
+    "lr_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int64)]),
     "lr_metrics_from_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "lr_llama_create": (C.c_int, [C.POINTER(A.LrLlamaConfig), C.POINTER(A.LrLlamaWeightsDesc),
                                   C.POINTER(C.c_void_p)]),

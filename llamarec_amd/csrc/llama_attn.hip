@@ -18,6 +18,7 @@
 //    fragment read from LDS feeds two MFMA column tiles. K tile XOR-swizzled by (row&15) for
 //    ds_read_b128; V tile by the dual-use swizzle (row reads + transposed reads).
 #include "llama_kernels.h"
+#include "lr_profile.h"
 
 typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -291,6 +292,12 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
   if (n_tok <= 0 || B <= 0) return LR_OK;
   if (nh % nkv != 0) LR_FAIL(LR_EINVAL, "attention: num_heads %d not a multiple of num_kv_heads %d", nh, nkv);
   if (variant == 0) variant = (hd == 128) ? 2 : 1;
+  double work = 0;  // causal QK^T + PV flops
+  for (int b = 0; b < B; ++b) {
+    double T = cu_host[b + 1] - cu_host[b];
+    work += 4.0 * nh * hd * (T * (T + 1) / 2);
+  }
+  LrProfScope prof(variant == 2 ? LR_PROF_ATTN_MFMA : LR_PROF_ATTN_GENERIC, work, st);
   if (variant == 2) {
     if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 2 needs head_dim 128 (got %d)", hd);
     int maxT = 0;

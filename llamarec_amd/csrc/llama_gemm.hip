@@ -21,6 +21,7 @@
 //     * workgroup -> tile map: bijective XCD remap (each XCD's L2 sees a compact set of tiles)
 //       followed by a grouped (8 M-tiles) raster so neighbours share A and B panels.
 #include "llama_kernels.h"
+#include "lr_profile.h"
 
 typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
 template <int EPI>
 static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
                       hipStream_t st) {
+  LrProfScope prof(variant == 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
   if (variant == 2) {
     static bool attr_set = false;
     if (!attr_set) {

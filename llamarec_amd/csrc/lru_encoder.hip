@@ -16,6 +16,7 @@
 //    k-ascending fmaf chains, butterfly LayerNorm sums over the 64 lanes of a wave.
 //  * the last block's out_proj/FFN run only for the tile that holds the last token.
 #include "lr_common.h"
+#include "lr_profile.h"
 
 #define TT 16  // tokens per tile
 
@@ -214,6 +215,7 @@ int lr_launch_lru_encode(const lr_lru* h, const int64_t* ids, int B, int L, floa
   p.B = B;
   p.L = L;
   p.out_q = out_q;
+  LrProfScope prof(LR_PROF_LRU_ENCODE, (double)B, st);
   hipLaunchKernelGGL(lru_encode_kernel, dim3(B), dim3(256), 0, st, p);
   LR_CHECK_LAUNCH("lru_encode_kernel");
   return LR_OK;

@@ -20,6 +20,7 @@
 //    back to its best K (which also tightens the threshold).
 //  * per-chunk sorted partial lists are merged by a second tiny kernel (one wave per user).
 #include "lr_common.h"
+#include "lr_profile.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -330,6 +331,7 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     attr_set = true;
   }
   dim3 grid(p.n_chunks, (B + TK_USERS - 1) / TK_USERS);
+  LrProfScope prof(LR_PROF_ITEM_TOPK, 2.0 * 64 * (double)p.n_rows * B, st);
   hipLaunchKernelGGL(item_topk_kernel, grid, dim3(256), lds, st, p);
   LR_CHECK_LAUNCH("item_topk_kernel");
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void rank_hist_kernel(const int32_t* ranked, i
 
 // one wave per row; lane c holds class c's key; rank = number of larger keys
 __global__ __launch_bounds__(256) void rank_classes_kernel(const float* scores, int B, int C,
-                                                           int32_t* out) {
+                                                           const int32_t* items, int32_t* out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void rank_classes_kernel(const float* scores, 
     unsigned long long km = __shfl(key, m, 64);
     rank += km > key ? 1 : 0;
   }
-  if (lane < C) out[(size_t)row * C + rank] = lane;
+  if (lane < C) out[(size_t)row * C + rank] = items ? items[(size_t)row * C + lane] : lane;
 }
 
 extern "C" int lr_rank_histogram(const int32_t* ranked, int32_t Kmax, const int64_t* labels, int32_t B,
@@ -50,13 +50,13 @@ extern "C" int lr_rank_histogram(const int32_t* ranked, int32_t Kmax, const int6
   return LR_OK;
 }
 
-extern "C" int lr_rank_classes(const float* scores, int32_t B, int32_t C, int32_t* out_ranked,
-                               void* hip_stream) {
+extern "C" int lr_rank_classes(const float* scores, int32_t B, int32_t C, const int32_t* items,
+                               int32_t* out_ranked, void* hip_stream) {
   if (!scores || !out_ranked || C < 1 || C > 64 || B < 0)
     LR_FAIL(LR_EINVAL, "lr_rank_classes: bad arguments (B=%d C=%d, C must be 1..64)", B, C);
   if (B == 0) return LR_OK;
   hipLaunchKernelGGL(rank_classes_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream,
-                     scores, B, C, out_ranked);
+                     scores, B, C, items, out_ranked);
   LR_CHECK_LAUNCH("rank_classes_kernel");
   return LR_OK;
 }

@@ -1,0 +1,56 @@
+"""Data-parallel sharding of users over the GPUs of one node (one process per GPU).
+
+Users are independent in both stages; weights are replicated; the only exchange
+is one all-reduce (sum) of the int64 rank histograms at the end -- RCCL over xGMI on GPUs
+(torch.distributed backend "nccl"), gloo in the CPU tests. The reference instead all-gathers
+[B, 32000] fp32 logits every eval step through HF Trainer / accelerate (trainer/llm.py:122,127).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (no-op for a single process)."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_users: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of rank `rank`: keeps the reference's positional user ids
+    (user_id = running index + 1, trainer/lru.py:85,127)."""
+    return (rank * n_users) // world, ((rank + 1) * n_users) // world
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_max_float(x: float, device=None) -> float:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return x

@@ -33,14 +33,21 @@ def rank_histogram(ranked: torch.Tensor, labels: torch.Tensor, hist: torch.Tenso
     return hist
 
 
-def rank_classes(scores: torch.Tensor) -> torch.Tensor:
+def rank_classes(scores: torch.Tensor, items: torch.Tensor | None = None, out=None) -> torch.Tensor:
     """`(-scores).argsort(dim=1)` for C <= 64 classes with the tie rule lower id first
-    (trainer/utils.py:55 on the reranker's [N,20] verbalizer scores)."""
+    (trainer/utils.py:55 on the reranker's [N,20] verbalizer scores). With `items` [B,C] (int32
+    candidate ids in class order) the result holds the candidates' item ids in reranked order."""
     scores = scores.to(torch.float32).contiguous()
     B, Cn = scores.shape
-    out = torch.empty((B, Cn), dtype=torch.int32, device=scores.device)
+    if out is None:
+        out = torch.empty((B, Cn), dtype=torch.int32, device=scores.device)
+    ip = None
+    if items is not None:
+        if items.dtype != torch.int32 or not items.is_contiguous() or tuple(items.shape) != (B, Cn):
+            raise ValueError("items must be a contiguous int32 [B, C] tensor")
+        ip = items.data_ptr()
     with torch.cuda.device(scores.device):
-        check(lib().lr_rank_classes(scores.data_ptr(), B, Cn, out.data_ptr(), stream_ptr()), "lr_rank_classes")
+        check(lib().lr_rank_classes(scores.data_ptr(), B, Cn, ip, out.data_ptr(), stream_ptr()), "lr_rank_classes")
     return out
 
 

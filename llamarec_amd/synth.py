@@ -84,3 +84,72 @@ def synth_llama_state(cfg: dict, seed: int, std: float = 0.02, norm_jitter: floa
             w = hash_uniform(seed * 1000 + i, shape, std)
         sd[name] = bf16_round(w)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic workloads of BASELINE.json's configs (BASELINE.md section 3 / SURVEY.md 8(d)).
+# V items, U users, L = bert_max_len, title-length range of the prompt model, rerank batch
+# (config.py:98), cfg_idx = position in BASELINE.json "configs" (seeds 42 + cfg_idx).
+# ---------------------------------------------------------------------------------------------
+WORKLOADS = {
+    "ml-100k": dict(V=3650, U=610, L=200, title=(3, 10), rerank_batch=32, cfg_idx=1),
+    "beauty": dict(V=12086, U=22332, L=50, title=(10, 32), rerank_batch=16, cfg_idx=2),
+    "games": dict(V=7676, U=15264, L=50, title=(6, 24), rerank_batch=16, cfg_idx=3),
+    "synth-1m": dict(V=1_000_000, U=1_000_000, L=200, title=(10, 32), rerank_batch=16, cfg_idx=4),
+}
+LLM_MAX_TEXT_LEN = 1536   # config.py:236
+LLM_MAX_HISTORY = 20      # config.py:237
+NUM_CANDIDATES = 20       # llm_negative_sample_size + 1 (config.py:238-241)
+
+
+def history_lengths(name: str, n_users: int, rng) -> np.ndarray:
+    w = WORKLOADS[name]
+    L = w["L"]
+    if name == "ml-100k":
+        n = np.clip(np.rint(rng.lognormal(4.4, 1.0, size=n_users)), 3, 200)
+    elif name == "beauty":
+        n = np.minimum(L, 3 + rng.geometric(0.2, size=n_users))
+    elif name == "games":
+        n = np.minimum(L, 3 + rng.geometric(0.17, size=n_users))
+    else:
+        n = rng.integers(20, 201, size=n_users)
+    return np.minimum(n, L).astype(np.int64)
+
+
+def synth_users(name: str, n_users: int | None = None, first_user: int = 0, seed_offset: int = 0):
+    """Left-padded int64 histories [U, L], labels [U] (not in the history), history lengths, and
+    prompt lengths T_u. Users are generated independently from (seed, user index) blocks so that a
+    data-parallel rank can build exactly its own contiguous shard."""
+    w = WORKLOADS[name]
+    V, L = w["V"], w["L"]
+    U = w["U"] if n_users is None else n_users
+    rng = np.random.default_rng([42 + w["cfg_idx"] + seed_offset, first_user])
+    n = history_lengths(name, U, rng)
+    ids = np.zeros((U, L), np.int64)
+    labels = np.zeros(U, np.int64)
+    for u in range(U):
+        # n_u + 1 distinct items: history + label
+        pick = rng.choice(V, size=int(n[u]) + 1, replace=False) + 1 if V < 50_000 else \
+            np.unique(rng.integers(1, V + 1, size=int(n[u]) + 8))[: int(n[u]) + 1]
+        if len(pick) < n[u] + 1:  # pragma: no cover (astronomically unlikely for V >= 50k)
+            pick = rng.choice(V, size=int(n[u]) + 1, replace=False) + 1
+        pick = rng.permutation(pick)
+        ids[u, L - n[u]:] = pick[: n[u]]
+        labels[u] = pick[n[u]]
+    lo, hi = w["title"]
+    hist = np.minimum(n, LLM_MAX_HISTORY)
+    T = np.empty(U, np.int64)
+    for u in range(U):
+        t = rng.integers(lo, hi + 1, size=int(hist[u]) + NUM_CANDIDATES)
+        T[u] = min(LLM_MAX_TEXT_LEN, 48 + int((4 + t).sum()))
+    return ids, labels, n, T
+
+
+def synth_prompt_tokens(T: np.ndarray, seed: int, vocab: int = 32000):
+    """Packed int32 prompt ids for prompt lengths T: BOS (=1) then uniform ids in [3, vocab)."""
+    rng = np.random.default_rng(seed)
+    cu = np.zeros(len(T) + 1, np.int32)
+    cu[1:] = np.cumsum(T)
+    ids = rng.integers(3, vocab, size=int(cu[-1]), dtype=np.int32)
+    ids[cu[:-1]] = 1
+    return ids, cu
