@@ -162,7 +162,7 @@ def main():
         k_ms, k_fl, k_n = collect(5)
         if g_n:
             ach = g_fl / (g_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm256_kernel (bf16 256x256x64 MFMA tile; QKV/O/gate-up/down)",
+            roofline = {"bound": "mfma", "kernel": "gemm256pp_kernel (bf16 256x256x64 MFMA tile, ping-pong pipeline; QKV/O/gate-up/down)",
                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                         "traffic": None, "launches": g_n, "avg_launch_ms": g_ms / g_n,
                         "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed}

@@ -265,11 +265,214 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
 }
 
 // =============================================================================================
+// 256 x 256 x 64 kernel, ping-pong pipeline (variant 3)
+// =============================================================================================
+// Same tile, LDS image and MFMA mapping as gemm256_kernel, different schedule. The K tile is
+// processed in 4 phases (one 64x32 quadrant of the wave's 128x64 output per phase, 16 MFMAs each):
+//     LOAD_p : ds_read the quadrant's new fragments + issue 2 global->LDS DMAs of the NEXT K tile
+//              + s_waitcnt vmcnt(4)            | s_barrier |
+//     MFMA_p : 16 x v_mfma_f32_16x16x32_bf16   | s_barrier |
+// The two wave groups (wm = 0 / 1; one wave of each per SIMD) run ONE BARRIER APART, so on every
+// SIMD one wave's MFMA segment overlaps the other wave's LOAD segment and the matrix pipe never
+// waits for LDS or DMA issue. DMAs are issued in the order their data is consumed next tile
+// (S0: phase-0 rows, 4 pieces; S1: phase-1 rows, 2; S2: phase-2 rows, 2), two per phase, and a
+// reader only needs "all but my newest 4" complete -- the DMA queue is never drained in the loop.
+// RAW: every wave's wait precedes a barrier that the reading wave passes before its LOAD_p;
+// WAR: a buffer region is overwritten a full K tile after its last read.
+#define PP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PP_BARRIER()                        \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ A,
+                                                        const u16* __restrict__ B, u16* C,
+                                                        const u16* R, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
+  const int nwg = tilesM * tilesN;
+  int id;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int per_group = G2_GROUP_M * tilesN;
+    const int g = id / per_group, rem = id % per_group;
+    const int first_m = g * G2_GROUP_M;
+    const int gsz = min(G2_GROUP_M, tilesM - first_m);
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
+  }
+  const int m0 = tm << 8, n0 = tn << 8;
+
+  // ---- DMA pieces of this wave (8 rows x 128 B each), in issue order
+  //  j = 0,1: q = 2*wave + j in 0..15
+  //  S0A rows (q>>3)*128 + (q&7)*8         S0B rows (q>>2)*64 + (q&3)*8        (phase 0)
+  //  S1B rows (q>>2)*64 + 32 + (q&3)*8                                         (phase 1)
+  //  S2A rows (q>>3)*128 + 64 + (q&7)*8                                        (phase 2)
+  const int srow = lane >> 3, spos = lane & 7;
+  const char* src[8];
+  int ldsoff[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = 2 * wave + j;
+    const int r_s0a = (q >> 3) * 128 + (q & 7) * 8;
+    const int r_s0b = (q >> 2) * 64 + (q & 3) * 8;
+    const int rows[4] = {r_s0a, r_s0b, r_s0b + 32, r_s0a + 64};
+    const bool isA[4] = {true, false, false, true};
+    // issue order: phase0: S0A#0,S0B#0  phase1: S0A#1,S0B#1  phase2: S1B#0,S1B#1  phase3: S2A#0,S2A#1
+    const int slot[4] = {j * 2 + 0, j * 2 + 1, 4 + j, 6 + j};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = rows[t] + srow;
+      const int chunk = spos ^ ((row >> 1) & 7);
+      if (isA[t]) {
+        const int arow = min(m0 + row, M - 1);
+        src[slot[t]] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
+        ldsoff[slot[t]] = rows[t] * 128;
+      } else {
+        src[slot[t]] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
+        ldsoff[slot[t]] = 32768 + rows[t] * 128;
+      }
+    }
+  }
+
+  const int frow = lane & 15;
+  const int fsw = frow >> 1;
+  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
+  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
+  const int a_base = wm * 128 * 128;
+  const int b_base = 32768 + wn * 64 * 128;
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K >> 6;
+  // prologue: whole tile 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) glds16(src[i], smem + ldsoff[i]);
+  PP_WAIT_VM(0);
+  PP_BARRIER();
+  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
+
+  bf16x8 afr[8], b0[4], b1[4];
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = smem + (kt & 1) * G2_STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * G2_STAGE_BYTES;
+    const bool more = kt + 1 < nkt;
+    const size_t koff = (size_t)(kt + 1) * 128;
+
+#define PP_LOAD_A(mh)                                                                                 \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                  \
+    afr[mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo0);       \
+    afr[4 + mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo1);   \
+  }
+#define PP_LOAD_B(dst, nh)                                                                            \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                  \
+    dst[nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo0);       \
+    dst[2 + nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo1);   \
+  }
+#define PP_STAGE(i0)                                          \
+  if (more) {                                                 \
+    glds16(src[(i0)] + koff, nxt + ldsoff[(i0)]);             \
+    glds16(src[(i0) + 1] + koff, nxt + ldsoff[(i0) + 1]);     \
+    PP_WAIT_VM(4);                                            \
+  } else {                                                    \
+    PP_WAIT_VM(0);                                            \
+  }
+#define PP_MFMA(bfrag, mh, nh)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  __builtin_amdgcn_s_setprio(1);                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
+    acc[(mh)*4 + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);                \
+  __builtin_amdgcn_s_setprio(0);
+
+    // ---- phase 0: quadrant (0,0)
+    PP_LOAD_A(0)
+    PP_LOAD_B(b0, 0)
+    PP_STAGE(0)
+    PP_BARRIER();
+    PP_MFMA(b0, 0, 0)
+    PP_BARRIER();
+    // ---- phase 1: quadrant (0,1)
+    PP_LOAD_B(b1, 1)
+    PP_STAGE(2)
+    PP_BARRIER();
+    PP_MFMA(b1, 0, 1)
+    PP_BARRIER();
+    // ---- phase 2: quadrant (1,1)
+    PP_LOAD_A(1)
+    PP_STAGE(4)
+    PP_BARRIER();
+    PP_MFMA(b1, 1, 1)
+    PP_BARRIER();
+    // ---- phase 3: quadrant (1,0)
+    PP_STAGE(6)
+    PP_BARRIER();
+    PP_MFMA(b0, 1, 0)
+    PP_BARRIER();
+#undef PP_LOAD_A
+#undef PP_LOAD_B
+#undef PP_STAGE
+#undef PP_MFMA
+  }
+  if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
+
+  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
+    if (row < M) {
+      if (EPI == LR_EPI_SWIGLU) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
+          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
 template <int EPI>
 static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
                       hipStream_t st) {
-  LrProfScope prof(variant == 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
-  if (variant == 2) {
+  LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
+  if (variant == 3) {
+    static bool attr_set3 = false;
+    if (!attr_set3) {
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
+      attr_set3 = true;
+    }
+    const int nwg = ((M + 255) / 256) * (N / 256);
+    hipLaunchKernelGGL(gemm256pp_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
+    LR_CHECK_LAUNCH("gemm256pp_kernel");
+  } else if (variant == 2) {
     static bool attr_set = false;
     if (!attr_set) {
       LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
@@ -292,12 +495,12 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
-  if (variant == 0) variant = (fast_ok && M >= 128) ? 2 : 1;
-  if (variant == 2 && !fast_ok)
-    LR_FAIL(LR_EUNSUPPORTED, "gemm variant 2 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
+  if (variant == 0) variant = (fast_ok && M >= 128) ? 3 : 1;
+  if (variant >= 2 && !fast_ok)
+    LR_FAIL(LR_EUNSUPPORTED, "gemm variant 2/3 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  if (variant != 1 && variant != 2) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
+  if (variant < 1 || variant > 3) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
   switch (epi) {
     case LR_EPI_STORE: return launch_epi<LR_EPI_STORE>(A, B, C, R, M, N, K, variant, st);
     case LR_EPI_RESIDUAL: return launch_epi<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, variant, st);

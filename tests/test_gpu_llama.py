@@ -53,7 +53,7 @@ def assert_bf16_close(got, ref32, what, absum=None):
 @pytest.mark.parametrize("M,N,K,variant", [
     (5, 7, 24, 1), (64, 64, 32, 1), (70, 130, 100, 1), (33, 96, 51, 1),
     (256, 256, 64, 2), (300, 512, 256, 2), (1, 256, 128, 2), (1000, 256, 4096, 2), (515, 768, 704, 2),
-    (300, 512, 256, 0),
+    (300, 512, 256, 0), (300, 512, 256, 3), (1000, 256, 4096, 3), (515, 768, 704, 3), (1, 256, 64, 3),
 ])
 def test_gemm_vs_numpy(M, N, K, variant):
     A = bf16_round(hash_uniform(M * 7 + K, (M, K), 1.0))
@@ -68,7 +68,7 @@ def test_gemm_fast_equals_generic_on_integers():
     A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)   # asymmetric patterns
     B = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
     ref = A @ B.T
-    for v in (1, 2):
+    for v in (1, 2, 3):
         assert np.array_equal(gemm(A, B, v), bf16_round(ref)), v
 
 
