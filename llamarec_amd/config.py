@@ -1,0 +1,80 @@
+"""Flags of the scoring path, with the reference's names and defaults (config.py:151-274 and the
+per-dataset defaults of set_template, :12-148). Parsed only when an entry point asks (the
+reference parses sys.argv at import, config.py:274, and may block on input(), :13-27 -- neither
+is reproduced). Training-only flags are accepted and ignored so existing command lines keep working.
+"""
+from __future__ import annotations
+
+import argparse
+
+EXPERIMENT_ROOT = "experiments"   # config.py:5-9
+STATE_DICT_KEY = "model_state_dict"
+RAW_DATASET_ROOT_FOLDER = "data"
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="llamarec-mi355x scoring path")
+    p.add_argument("--dataset_code", type=str, default=None)
+    p.add_argument("--model_code", type=str, default=None)
+    p.add_argument("--min_rating", type=int, default=0)
+    p.add_argument("--min_uc", type=int, default=5)
+    p.add_argument("--min_sc", type=int, default=5)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--val_batch_size", type=int, default=None)
+    p.add_argument("--test_batch_size", type=int, default=None)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--metric_ks", nargs="+", type=int, default=None)
+    p.add_argument("--rerank_metric_ks", nargs="+", type=int, default=None)
+    p.add_argument("--bert_max_len", type=int, default=None)
+    p.add_argument("--bert_hidden_units", type=int, default=64)
+    p.add_argument("--bert_num_blocks", type=int, default=None)
+    p.add_argument("--llm_base_model", type=str, default="meta-llama/Llama-2-7b-hf")
+    p.add_argument("--llm_base_tokenizer", type=str, default="meta-llama/Llama-2-7b-hf")
+    p.add_argument("--llm_max_title_len", type=int, default=32)
+    p.add_argument("--llm_max_text_len", type=int, default=1536)
+    p.add_argument("--llm_max_history", type=int, default=20)
+    p.add_argument("--llm_negative_sample_size", type=int, default=19)
+    p.add_argument("--llm_system_template", type=str, default=None)
+    p.add_argument("--llm_input_template", type=str, default=None)
+    p.add_argument("--llm_retrieved_path", type=str, default=None)
+    p.add_argument("--lora_r", type=int, default=8)
+    p.add_argument("--lora_alpha", type=int, default=32)
+    # additions of this implementation (local assets only; nothing is downloaded)
+    p.add_argument("--data_root", type=str, default=RAW_DATASET_ROOT_FOLDER)
+    p.add_argument("--export_root", type=str, default=None)
+    p.add_argument("--llm_adapter_path", type=str, default=None, help="local PEFT adapter directory")
+    p.add_argument("--synthetic", action="store_true", help="fabricate dataset / weights (nothing exists offline)")
+    return p
+
+
+def set_template(args):
+    """Dataset / model dependent defaults (config.py:57-61,98,103-111,136-146)."""
+    ml = args.dataset_code == "ml-100k"
+    if args.bert_max_len is None:
+        args.bert_max_len = 200 if ml else 50
+    if args.bert_num_blocks is None:
+        args.bert_num_blocks = 2
+    if args.metric_ks is None:
+        args.metric_ks = [1, 5, 10, 20, 50]
+    if args.rerank_metric_ks is None:
+        args.rerank_metric_ks = [1, 5, 10]
+    if args.model_code == "llm":
+        if args.test_batch_size is None:
+            args.test_batch_size = 32 if ml else 16
+        if args.val_batch_size is None:
+            args.val_batch_size = args.test_batch_size
+    else:
+        if args.test_batch_size is None:
+            args.test_batch_size = 16 if ml else 64
+        if args.val_batch_size is None:
+            args.val_batch_size = args.test_batch_size
+    return args
+
+
+def parse(argv=None, model_code=None):
+    args, _unknown = build_parser().parse_known_args(argv)
+    if model_code:
+        args.model_code = model_code
+    if args.dataset_code is None:
+        raise SystemExit("--dataset_code is required (ml-100k | beauty | games | ...)")
+    return set_template(args)

@@ -1,0 +1,118 @@
+"""Prompt construction and eval collation for the ranker -- host-side mirror of the reference's
+dataloader/llm.py:19-30,64-98, dataloader/utils.py:24-40 and trainer/llm.py:15-60 (eval branch).
+
+Pure host logic (strings and integer lists); the tokenizer is any object with the calls the
+reference makes: tokenize, convert_tokens_to_string, __call__(text, truncation, max_length,
+padding, return_tensors) and encode(text, add_special_tokens=False).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+# config.py:242-249 of the reference (defaults of --llm_system_template / --llm_input_template)
+DEFAULT_SYSTEM_TEMPLATE = ("Given user history in chronological order, recommend an item from the candidate pool "
+                           "with its index letter.")
+DEFAULT_INPUT_TEMPLATE = "User history: {}; \n Candidate pool: {}"
+LLM_MAX_TITLE_LEN = 32    # config.py:235
+LLM_MAX_TEXT_LEN = 1536   # config.py:236
+LLM_MAX_HISTORY = 20      # config.py:237
+
+# Prompt layouts. "alpaca_short" must produce byte-identical prompts to the reference's default
+# template (dataloader/templates/alpaca_short.json:3-4, pinned by tests/golden/prompts.json).
+_SECTION = "### {}:\n"
+TEMPLATES = {
+    "alpaca_short": {
+        "prompt_input": _SECTION.format("Instruction") + "{instruction}\n\n" + _SECTION.format("Input")
+        + "{input}\n\n" + _SECTION.format("Response"),
+        "prompt_no_input": _SECTION.format("Instruction") + "{instruction}\n\n" + _SECTION.format("Response"),
+        "response_split": "### Response:",
+    },
+}
+
+
+class Prompter:
+    """dataloader/utils.py:8-40: template lookup + `generate_prompt(instruction, input, label)`."""
+
+    __slots__ = ("template", "_verbose")
+
+    def __init__(self, template_name: str = "", verbose: bool = False):
+        self._verbose = verbose
+        if not template_name:
+            template_name = "alpaca_short"
+        if template_name in TEMPLATES:
+            self.template = TEMPLATES[template_name]
+        elif os.path.exists(template_name):  # a user-supplied JSON file with the same three keys
+            with open(template_name) as fp:
+                self.template = json.load(fp)
+        else:
+            raise ValueError(f"Can't read {template_name}")
+
+    def generate_prompt(self, instruction, input=None, label=None) -> str:
+        if input:
+            res = self.template["prompt_input"].format(instruction=instruction, input=input)
+        else:
+            res = self.template["prompt_no_input"].format(instruction=instruction)
+        if label:
+            res = f"{res}{label}"
+        return res
+
+
+def truncate_title(title, tokenizer, max_title_len=LLM_MAX_TITLE_LEN):
+    """dataloader/llm.py:67-70."""
+    return tokenizer.convert_tokens_to_string(tokenizer.tokenize(title)[:max_title_len])
+
+
+def build_input_text(seq, candidates, text_dict, tokenizer, max_title_len=LLM_MAX_TITLE_LEN,
+                     input_template=DEFAULT_INPUT_TEMPLATE, truncate=True):
+    """History as "(1) title \\n (2) title", candidates as "(A) title \\n (B) title"
+    (dataloader/llm.py:72-83,92). truncate=False is the online demo's variant (demo/inference.py:79-109)."""
+    tt = (lambda t: truncate_title(t, tokenizer, max_title_len)) if truncate else (lambda t: t)
+    seq_t = " \n ".join("(" + str(i + 1) + ") " + tt(text_dict[item]) for i, item in enumerate(seq))
+    can_t = " \n ".join("(" + chr(ord("A") + i) + ") " + tt(text_dict[item]) for i, item in enumerate(candidates))
+    return input_template.format(seq_t, can_t)
+
+
+def seq_to_token_ids(seq, candidates, label, text_dict, tokenizer, prompter=None,
+                     max_title_len=LLM_MAX_TITLE_LEN, max_text_len=LLM_MAX_TEXT_LEN,
+                     system_template=DEFAULT_SYSTEM_TEMPLATE, input_template=DEFAULT_INPUT_TEMPLATE):
+    """Eval branch of dataloader/llm.py:64-98 + generate_and_tokenize_eval (:19-30): returns
+    {"input_ids", "attention_mask", "labels"} with labels = index of the answer's letter."""
+    prompter = prompter or Prompter()
+    candidates = list(candidates)
+    output = chr(ord("A") + candidates.index(label))
+    text = build_input_text(seq, candidates, text_dict, tokenizer, max_title_len, input_template)
+    prompt = prompter.generate_prompt(system_template, text)
+    tok = tokenizer(prompt, truncation=True, max_length=max_text_len, padding=False, return_tensors=None)
+    out = {"input_ids": list(tok["input_ids"]), "attention_mask": list(tok["attention_mask"])}
+    out["labels"] = ord(output) - ord("A")
+    return out
+
+
+def eval_collate(batch, llm_max_length=LLM_MAX_TEXT_LEN):
+    """llama_collate_fn_w_truncation(eval=True) (trainer/llm.py:15-60): left-truncate to
+    min(llm_max_length, longest), left-pad ids with 0 and the mask with 0; labels [B,1].
+    Returns int64 numpy arrays."""
+    longest = max(len(b["input_ids"]) for b in batch)
+    max_length = min(llm_max_length, longest)
+    ids = np.zeros((len(batch), max_length), np.int64)
+    mask = np.zeros((len(batch), max_length), np.int64)
+    labels = np.zeros((len(batch), 1), np.int64)
+    for i, b in enumerate(batch):
+        x, m = list(b["input_ids"]), list(b["attention_mask"])
+        if len(x) > max_length:
+            x, m = x[-max_length:], m[-max_length:]
+        ids[i, max_length - len(x):] = x
+        mask[i, max_length - len(m):] = m
+        labels[i, 0] = b["labels"]
+    return {"input_ids": ids, "attention_mask": mask, "labels": labels}
+
+
+def eval_pack(batch, llm_max_length=LLM_MAX_TEXT_LEN):
+    """The packed (unpadded) equivalent of eval_collate for the HIP prefill: per-prompt id lists
+    after the same left truncation, plus labels. Padding never reaches the GPU."""
+    seqs = [np.asarray(b["input_ids"][-llm_max_length:], dtype=np.int32) for b in batch]
+    labels = np.asarray([b["labels"] for b in batch], dtype=np.int64)
+    return seqs, labels

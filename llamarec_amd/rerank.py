@@ -1,0 +1,90 @@
+"""Ranker evaluation -- mirror of the reference's LLMTrainer.test (trainer/llm.py:165-189) and
+compute_metrics_for_ks (:63-72), without HF Trainer: prompts are packed (no padding), one HIP
+prefill per batch returns the [B,20] verbalizer scores, and only an int64 rank histogram leaves
+the GPU (the reference gathers [N,32000] fp32 logits to the host first).
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import metrics as M
+from . import prompt as P
+
+RERANK_METRIC_KS = [1, 5, 10]  # config.py:140-143
+
+
+def merge_overall_metrics(average_metrics: dict, test_retrieval: dict) -> dict:
+    """trainer/llm.py:174-184: overall = (subset * n_ret + non_retrieval * (n_all - n_ret)) / n_all for
+    the keys present in both (the rerank ks)."""
+    original_size, retrieval_size = test_retrieval["original_size"], test_retrieval["retrieval_size"]
+    overall = {}
+    for key in test_retrieval["non_retrieval_metrics"].keys():
+        if "test_" + key in average_metrics:
+            overall["test_" + key] = (
+                average_metrics["test_" + key] * retrieval_size
+                + test_retrieval["non_retrieval_metrics"][key] * (original_size - retrieval_size)
+            ) / original_size
+    return overall
+
+
+class LLMEvaluator:
+    """test_items: list of dicts {"input_ids", "attention_mask", "labels"} as produced by
+    prompt.seq_to_token_ids (== LLMTestDataset.__getitem__, dataloader/llm.py:368-387)."""
+
+    def __init__(self, args, model, test_items, verbalizer, export_root=None, batch_size=None):
+        self.args, self.model, self.items, self.verbalizer = args, model, test_items, verbalizer
+        self.export_root = export_root
+        self.ks = list(getattr(args, "rerank_metric_ks", RERANK_METRIC_KS))
+        self.batch_size = batch_size or getattr(args, "test_batch_size", 16)
+        self.max_text_len = getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN)
+
+    def predict(self):
+        t0 = time.time()
+        ncls = self.verbalizer.num_classes
+        hist = torch.zeros(ncls + 1, dtype=torch.int64, device=self.model.device)
+        for i in range(0, len(self.items), self.batch_size):
+            seqs, labels = P.eval_pack(self.items[i:i + self.batch_size], self.max_text_len)
+            scores = self.model.prefill_verbalize(seqs, self.verbalizer.label_token_ids)
+            ranked = M.rank_classes(scores)
+            M.rank_histogram(ranked, torch.from_numpy(labels).to(self.model.device), hist)
+        m = M.metrics_from_histogram(hist, self.ks) if len(self.items) else {}
+        out = {"test_" + k: v for k, v in m.items()}
+        out["test_loss"] = -1.0  # model/llm.py:128-129: eval loss is the constant -1
+        out["test_runtime"] = time.time() - t0
+        out["test_samples_per_second"] = len(self.items) / max(out["test_runtime"], 1e-9)
+        return out
+
+    def test(self, test_retrieval):
+        average_metrics = self.predict()
+        overall = merge_overall_metrics(average_metrics, test_retrieval)
+        if self.export_root:
+            os.makedirs(self.export_root, exist_ok=True)
+            with open(os.path.join(self.export_root, "subset_metrics.json"), "w") as f:
+                json.dump(average_metrics, f, indent=4)
+            with open(os.path.join(self.export_root, "overall_metrics.json"), "w") as f:
+                json.dump(overall, f, indent=4)
+        self.overall_metrics = overall
+        return average_metrics
+
+
+def build_test_items(dataset, retrieved, tokenizer, args=None, prompter=None):
+    """LLMTestDataset (dataloader/llm.py:337-387): history = (train + val)[-llm_max_history:],
+    candidates = the retriever's ordered top-20 (not shuffled), answer = test item."""
+    max_hist = getattr(args, "llm_max_history", P.LLM_MAX_HISTORY)
+    kw = dict(max_title_len=getattr(args, "llm_max_title_len", P.LLM_MAX_TITLE_LEN),
+              max_text_len=getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN),
+              system_template=getattr(args, "llm_system_template", None) or P.DEFAULT_SYSTEM_TEMPLATE,
+              input_template=getattr(args, "llm_input_template", None) or P.DEFAULT_INPUT_TEMPLATE)
+    prompter = prompter or P.Prompter()
+    items = []
+    for user, cands in zip(retrieved["test_users"], retrieved["test_candidates"]):
+        seq = (list(dataset["train"][user]) + list(dataset["val"][user]))[-max_hist:]
+        answer = dataset["test"][user][0]
+        assert answer in cands  # dataloader/llm.py:375
+        items.append(P.seq_to_token_ids(seq, cands, answer, dataset["meta"], tokenizer, prompter, **kw))
+    return items

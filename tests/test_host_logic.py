@@ -1,0 +1,74 @@
+"""CPU tests of the host-side mirrors (prompt building, eval collation, verbalizer, metric merge)
+against data captured from the reference (tests/golden/*.json|npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from llamarec_amd import prompt as P
+from llamarec_amd.verb import ManualVerbalizer
+from tests.fake_tokenizer import FakeTokenizer
+
+
+@pytest.fixture(scope="module")
+def prompts(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "prompts.json")))
+    g["titles"] = {int(k): v for k, v in g["titles"].items()}
+    return g
+
+
+def test_templates_match_reference_defaults(prompts):
+    assert P.DEFAULT_SYSTEM_TEMPLATE == prompts["system_template"]
+    assert P.DEFAULT_INPUT_TEMPLATE == prompts["input_template"]
+
+
+def test_prompt_text_and_token_ids(prompts):
+    for c in prompts["cases"]:
+        tok = FakeTokenizer()
+        out = P.seq_to_token_ids(c["seq"], c["candidates"], c["label"], prompts["titles"], tok,
+                                 max_title_len=c["llm_max_title_len"], max_text_len=c["llm_max_text_len"])
+        assert tok.seen_texts[-1] == c["prompt_eval"]
+        assert out["input_ids"] == c["eval"]["input_ids"]
+        assert out["attention_mask"] == c["eval"]["attention_mask"]
+        assert out["labels"] == c["eval"]["labels"]
+
+
+def test_answer_must_be_a_candidate(prompts):
+    with pytest.raises(ValueError):
+        P.seq_to_token_ids([1], [2, 3], 9, prompts["titles"], FakeTokenizer())
+
+
+def test_eval_collate_and_pack(prompts):
+    cases = prompts["cases"]
+    for col in prompts["collate_eval"]:
+        batch = [cases[i]["eval"] for i in col["batch_case_indices"]]
+        out = P.eval_collate(batch, col["llm_max_length"])
+        for k in ("input_ids", "attention_mask", "labels"):
+            assert out[k].tolist() == col["out"][k], k
+        seqs, labels = P.eval_pack(batch, col["llm_max_length"])
+        for row, m, s in zip(out["input_ids"], out["attention_mask"], seqs):
+            assert row[m.astype(bool)].tolist() == s.tolist()  # packed == unpadded rows
+        assert labels.tolist() == [r[0] for r in col["out"]["labels"]]
+
+
+def test_verbalizer_ids_and_gather(golden_dir):
+    z = np.load(os.path.join(golden_dir, "verbalizer.npz"))
+    v = ManualVerbalizer(tokenizer=FakeTokenizer(), prefix="", post_log_softmax=False, classes=list(range(20)),
+                         label_words={i: chr(ord("A") + i) for i in range(20)})
+    assert v.label_words_ids.shape == z["label_words_ids"].shape
+    assert np.array_equal(v.label_words_ids, z["label_words_ids"])
+    assert np.array_equal(v.process_logits(z["logits"]), z["scores"])
+    import torch
+
+    assert np.array_equal(v.process_logits(torch.from_numpy(z["logits"])).numpy(), z["scores"])
+
+
+def test_overall_metric_merge(golden_dir):
+    from llamarec_amd.rerank import merge_overall_metrics
+
+    g = json.load(open(os.path.join(golden_dir, "merge.json")))
+    overall = merge_overall_metrics(g["subset_in"], g["test_retrieval"])
+    assert list(overall.keys()) == list(g["overall_metrics_json"].keys())
+    for k, v in g["overall_metrics_json"].items():
+        assert abs(overall[k] - v) < 1e-12
