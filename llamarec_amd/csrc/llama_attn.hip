@@ -105,18 +105,28 @@ __device__ __forceinline__ int v_off(int row, int ch) {  // dual-use swizzle, 25
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-__global__ __launch_bounds__(256) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
-                                                           const int32_t* cu, int nh, int nkv,
-                                                           int max_qblocks) {
-  __shared__ __attribute__((aligned(16))) char Ks[FA_KB * 256];
-  __shared__ __attribute__((aligned(16))) char Vs[FA_KB * 256];
+__device__ __forceinline__ void attn_glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+#define FA_TILE_BYTES (FA_KB * 256)        // one K or V tile: 64 keys x 128 dims bf16
+#define FA_STAGE_BYTES (2 * FA_TILE_BYTES)  // K tile + V tile
+
+__global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
+                                                              const int32_t* cu, int nh, int nkv,
+                                                              int max_qblocks) {
+  // [2 stages][K 16 KiB | V 16 KiB]; filled by LDS-DMA (lane-linear 1 KiB pieces = 4 rows x 256 B),
+  // the XOR swizzles are applied to the SOURCE chunk: position p of row r holds chunk p ^ s(r).
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hd = 128;
   const int b = blockIdx.z, h = blockIdx.y;
   const int qb = max_qblocks - 1 - (int)blockIdx.x;  // heavy (late) query blocks first
   const int tok0 = cu[b];
   const int T = cu[b + 1] - tok0;
   if (qb * FA_QROWS >= T) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int quad = lane >> 4, li = lane & 15;
   const int kvh = h / (nh / nkv);
   const int stride = (nh + 2 * nkv) * hd;
@@ -145,121 +155,133 @@ __global__ __launch_bounds__(256) void attn_mfma128_kernel(const u16* __restrict
 
   const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);
   const int kb_last = q_last / FA_KB;
+  const int wave_q_last = qb * FA_QROWS + wave * 32 + 31;  // last query row this wave owns
   const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
 
-  // staging: 1024 16-byte chunks per tile, 4 per thread
-  u16x8 kreg[4], vreg[4];
-  auto load_block = [&](int kb) {
+  // ---- DMA staging: 16 pieces per tile (4 rows each); wave w moves pieces 4w..4w+3 of K and of V
+  const int prow = lane >> 4, ppos = lane & 15;
+  auto stage = [&](int kb, int buf) {
+    char* base = smem + buf * FA_STAGE_BYTES + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 4, ch = c & 15;
+      const int row = (wave * 4 + i) * 4 + prow;
       const int key = min(kb * FA_KB + row, T - 1);
-      kreg[i] = *reinterpret_cast<const u16x8*>(kbase + (size_t)key * stride + ch * 8);
-      vreg[i] = *reinterpret_cast<const u16x8*>(vbase + (size_t)key * stride + ch * 8);
-    }
-  };
-  auto store_block = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 4, ch = c & 15;
-      *reinterpret_cast<u16x8*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
-      *reinterpret_cast<u16x8*>(Vs + v_off(row, ch)) = vreg[i];
+      const int kchunk = ppos ^ (row & 15);
+      const int vchunk = ppos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      attn_glds16(kbase + (size_t)key * stride + kchunk * 8, base + i * 1024);
+      attn_glds16(vbase + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
     }
   };
 
-  load_block(0);
-  store_block();
+  stage(0, 0);
+  // Q must be resident before the loop: otherwise hipcc carries its pending-load state into the loop
+  // and waits for the in-loop DMA prefetch (vmcnt is in-order) in front of the first MFMAs.
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));
   __syncthreads();
 
   for (int kb = 0; kb <= kb_last; ++kb) {
-    if (kb < kb_last) load_block(kb + 1);
+    const char* Ks = smem + (kb & 1) * FA_STAGE_BYTES;
+    const char* Vs = Ks + FA_TILE_BYTES;
+    if (kb < kb_last) stage(kb + 1, (kb + 1) & 1);
 
-    // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
-    floatx4 st[2][4];
+    if (kb * FA_KB <= wave_q_last) {  // otherwise every key of the block is masked for this wave
+      // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
+      floatx4 st[2][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+        for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 kf[2][4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int row = nt * 16 + li;
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 256 + (((ks * 4 + quad) ^ (row & 15)) << 4));
+        kf[0][nt] = *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((quad ^ (row & 15)) << 4));
+      }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][nt], 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int row = nt * 16 + li;
+            kf[(ks + 1) & 1][nt] =
+                *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((((ks + 1) * 4 + quad) ^ (row & 15)) << 4));
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+            st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][nt], qf[qt][ks], st[qt][nt], 0, 0, 0);
+      }
+
+      // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
+      bf16x8 pa[2][2];
+      const bool diag = (kb * FA_KB + FA_KB - 1) > (qb * FA_QROWS + wave * 32);  // block needs masking
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = st[qt][nt][r] * sl2;
+            if (diag) {
+              const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
+              t = (key <= qabs[qt]) ? t : -__builtin_inff();
+            }
+            st[qt][nt][r] = t;
+            mx = fmaxf(mx, t);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(st[qt][nt][r] - m_new);
+            ps += p;
+            pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
+          }
+        l_run[qt] = l_run[qt] * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
+      }
+
+      // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
+      const int qp = li >> 2, p4 = li & 3;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const int row0 = ks2 * 32 + quad * 4 + qp;
+          const int ch = dt * 2 + (p4 >> 1);
+          const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0, ch) + 8 * (p4 & 1)));
+          const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0 + 16, ch) + 8 * (p4 & 1)));
+          bf16x8 vf;
+          const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            vf[r] = b0[r];
+            vf[4 + r] = b1[r];
+          }
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+            ot[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa[qt][ks2], ot[qt][dt], 0, 0, 0);
+        }
       }
     }
-
-    // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
-    bf16x8 pa[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float mx = -__builtin_inff();
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
-          float t = st[qt][nt][r] * sl2;
-          t = (key <= qabs[qt]) ? t : -__builtin_inff();
-          st[qt][nt][r] = t;
-          mx = fmaxf(mx, t);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-      m_run[qt] = m_new;
-      float ps = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(st[qt][nt][r] - m_new);
-          ps += p;
-          pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
-        }
-      l_run[qt] = l_run[qt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
-    }
-
-    // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        const int qp = li >> 2, p = li & 3;
-        const int row0 = ks2 * 32 + quad * 4 + qp;
-        const int ch = dt * 2 + (p >> 1);
-        const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0, ch) + 8 * (p & 1)));
-        const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0 + 16, ch) + 8 * (p & 1)));
-        bf16x8 vf;
-        const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          vf[r] = b0[r];
-          vf[4 + r] = b1[r];
-        }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          ot[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa[qt][ks2], ot[qt][dt], 0, 0, 0);
-      }
-    }
-
-    __syncthreads();
-    if (kb < kb_last) {
-      store_block();
-      __syncthreads();
-    }
+    __syncthreads();  // DMA of block kb+1 landed (vmcnt(0)) and every wave is done with block kb
   }
 
   // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
@@ -304,7 +326,14 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
     const int mq = (maxT + FA_QROWS - 1) / FA_QROWS;
     if (mq == 0) return LR_OK;
-    hipLaunchKernelGGL(attn_mfma128_kernel, dim3(mq, nh, B), dim3(256), 0, st, qkv, out, cu, nh, nkv, mq);
+    static bool attr_set = false;
+    if (!attr_set) {
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_mfma128_kernel, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
+                       nkv, mq);
     LR_CHECK_LAUNCH("attn_mfma128_kernel");
   } else if (variant == 1) {
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);

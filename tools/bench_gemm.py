@@ -37,3 +37,27 @@ def run(variants, M=14800, rounds=5, check_equal=True):
 if __name__ == "__main__":
     vs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 3]
     run(vs)
+
+
+def yardstick(M=14800, rounds=5):
+    """torch.matmul (hipBLASLt) on the same shapes/data -- a yardstick only, never the product."""
+    shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for name, N, K in shapes:
+        A = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+        B = (torch.randn(N, K, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+        ts = []
+        for r in range(rounds + 1):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                C = A @ B.T
+            e1.record(); torch.cuda.synchronize()
+            if r: ts.append(e0.elapsed_time(e1) / 3)
+        fl = 2.0 * M * N * K
+        print(f"yardstick torch.matmul {name:8s}: {np.median(ts):.3f} ms {fl/np.median(ts)/1e9:.0f} TF/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "yardstick":
+    yardstick()
