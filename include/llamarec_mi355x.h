@@ -196,6 +196,11 @@ void lr_llama_destroy(lr_llama_t* h);
  * (an error if a shape does not fit). */
 int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant);
 
+/* Last-layer pruning (default ON): after the final layer only each prompt's last token is consumed
+ * (model/llm.py:131), so that layer computes K/V for all tokens but attention output, o_proj and the
+ * MLP for B rows only. Results are unchanged up to bf16 summation order; disable for A/B tests. */
+int lr_llama_set_last_layer_pruning(lr_llama_t* h, int32_t enable);
+
 /* Device workspace bytes for up to max_tokens packed tokens and max_seqs sequences per call. */
 size_t lr_llama_workspace_bytes(const lr_llama_t* h, int32_t max_tokens, int32_t max_seqs);
 

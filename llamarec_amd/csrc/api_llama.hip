@@ -30,6 +30,7 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
   h->embed = w->embed;
   h->final_norm = w->final_norm;
   h->lm_head = w->lm_head;
+  h->prune_last = 1;
   h->layers = (LrLlamaLayerWeights*)malloc(sizeof(LrLlamaLayerWeights) * cfg->num_layers);
   memcpy(h->layers, w->layers, sizeof(LrLlamaLayerWeights) * cfg->num_layers);
   LR_CHECK_HIP(hipGetDevice(&h->device));
@@ -38,10 +39,16 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
 }
 
 extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
-  if (!h || gemm_variant < 0 || gemm_variant > 3 || attention_variant < 0 || attention_variant > 2)
+  if (!h || gemm_variant < 0 || gemm_variant > 5 || attention_variant < 0 || attention_variant > 2)
     LR_FAIL(LR_EINVAL, "lr_llama_set_variants: bad argument");
   h->gemm_variant = gemm_variant;
   h->attn_variant = attention_variant;
+  return LR_OK;
+}
+
+extern "C" int lr_llama_set_last_layer_pruning(lr_llama_t* h, int32_t enable) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_llama_set_last_layer_pruning: null handle");
+  h->prune_last = enable ? 1 : 0;
   return LR_OK;
 }
 
@@ -52,14 +59,17 @@ extern "C" void lr_llama_destroy(lr_llama_t* h) {
 }
 
 struct LlamaWs {
-  int32_t *tok_pos, *tok_seq;
+  int32_t *tok_pos, *tok_seq, *last_rows;
   float* rope;
   u16 *x, *xn, *qkv, *att, *hmid;
+  u16 *x_last, *xn_last, *att_last, *h_last;  // compact [B][.] buffers of the pruned last layer
+  bool compact;                               // ws.x_last (not ws.x) holds the final residual rows
   size_t total;
 };
 
-static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, char* base) {
+static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char* base) {
   LlamaWs w;
+  w.compact = false;
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -76,14 +86,21 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, char* base) {
   w.qkv = (u16*)take(n * qkv_w * 2);
   w.att = (u16*)take(n * (size_t)c.num_heads * c.head_dim * 2);
   w.hmid = (u16*)take(n * c.intermediate_size * 2);
+  const size_t nb = (size_t)(max_seqs > 0 ? max_seqs : 1);
+  w.last_rows = (int32_t*)take(nb * 4);
+  w.x_last = (u16*)take(nb * c.hidden_size * 2);
+  w.xn_last = (u16*)take(nb * c.hidden_size * 2);
+  w.att_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
+  w.h_last = (u16*)take(nb * c.intermediate_size * 2);
   w.total = o;
   return w;
 }
 
 extern "C" size_t lr_llama_workspace_bytes(const lr_llama_t* h, int32_t max_tokens, int32_t max_seqs) {
-  (void)max_seqs;
   if (!h || max_tokens < 1) return 0;
-  return carve(h->cfg, max_tokens, nullptr).total;
+  if (max_seqs < 1) max_seqs = 1;
+  if (max_seqs > max_tokens) max_seqs = max_tokens;
+  return carve(h->cfg, max_tokens, max_seqs, nullptr).total;
 }
 
 // Runs the transformer body; leaves the residual stream (before the final norm) in ws.x.
@@ -102,7 +119,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   if (maxT > c.max_positions)
     LR_FAIL(LR_EINVAL, "llama prefill: prompt of %d tokens exceeds max_positions %d", maxT, c.max_positions);
   const int n = cu_host[B];
-  LlamaWs ws = carve(c, n, (char*)workspace);
+  LlamaWs ws = carve(c, n, B, (char*)workspace);
   if (ws.total > workspace_bytes)
     LR_FAIL(LR_EWORKSPACE, "llama prefill: workspace needs %zu bytes for %d tokens, have %zu", ws.total, n,
             workspace_bytes);
@@ -115,7 +132,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     rc = (x);               \
     if (rc) return rc;      \
   } while (0)
-  RUN(lr_launch_token_meta(cu, B, ws.tok_pos, ws.tok_seq, st));
+  RUN(lr_launch_token_meta(cu, B, ws.tok_pos, ws.tok_seq, ws.last_rows, st));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
   RUN(lr_launch_embed(ids, h->embed, c.vocab_size, d, ws.x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
@@ -123,6 +140,18 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
     RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_STORE, h->gemm_variant, st));
     RUN(lr_launch_rope(ws.qkv, ws.tok_pos, ws.rope, n, nh + nkv, qkv_w, hd, st));
+    if (l == c.num_layers - 1 && h->prune_last) {
+      // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
+      // last layer needs K/V for every token but attention output, o_proj, and the MLP for B rows only.
+      RUN(lr_launch_attention_rows(ws.qkv, ws.att_last, cu, B, ws.last_rows, B, nh, nkv, hd, st));
+      RUN(lr_launch_gather_rows(ws.x, ws.last_rows, B, d, ws.x_last, st));
+      RUN(lr_launch_gemm(ws.att_last, w.wo, ws.x_last, ws.x_last, B, d, nh * hd, LR_EPI_RESIDUAL, 1, st));
+      RUN(lr_launch_rmsnorm(ws.x_last, w.post_norm, ws.xn_last, B, d, c.rms_eps, nullptr, st));
+      RUN(lr_launch_gemm(ws.xn_last, w.wgu, ws.h_last, nullptr, B, 2 * f, d, LR_EPI_SWIGLU, 1, st));
+      RUN(lr_launch_gemm(ws.h_last, w.wdown, ws.x_last, ws.x_last, B, d, f, LR_EPI_RESIDUAL, 1, st));
+      ws.compact = true;
+      break;
+    }
     RUN(lr_launch_attention(ws.qkv, ws.att, cu, cu_host, ws.tok_pos, ws.tok_seq, B, n, nh, nkv, hd,
                             h->attn_variant, nullptr, st));
     RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st));
@@ -144,8 +173,8 @@ extern "C" int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_i
   LlamaWs ws;
   int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
   if (rc) return rc;
-  return lr_launch_head(ws.x, cu_seqlens, h->final_norm, h->lm_head, label_token_ids, B, C, h->cfg.hidden_size,
-                        h->cfg.rms_eps, out_scores, st);
+  return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : cu_seqlens, h->final_norm, h->lm_head,
+                        label_token_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out_scores, st);
 }
 
 extern "C" int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
@@ -156,8 +185,8 @@ extern "C" int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, co
   LlamaWs ws;
   int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
   if (rc) return rc;
-  return lr_launch_head(ws.x, cu_seqlens, h->final_norm, h->lm_head, nullptr, B, h->cfg.vocab_size,
-                        h->cfg.hidden_size, h->cfg.rms_eps, out_logits, st);
+  return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : cu_seqlens, h->final_norm, h->lm_head,
+                        nullptr, B, h->cfg.vocab_size, h->cfg.hidden_size, h->cfg.rms_eps, out_logits, st);
 }
 
 extern "C" int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,

@@ -32,12 +32,15 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 // generic
 // =============================================================================================
 __global__ __launch_bounds__(256) void attn_generic_kernel(const u16* qkv, u16* out, const int32_t* cu, int B,
-                                                           int n_tok, int nh, int nkv, int hd) {
+                                                           int n_tok, int nh, int nkv, int hd,
+                                                           const int32_t* q_rows) {
   __shared__ float qs[4][256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave;  // (token, head)
   if (item >= n_tok * nh) return;
-  const int tok = item / nh, h = item % nh;
+  // q_rows (optional): only these query tokens are evaluated and the output is compact [n_tok][nh*hd]
+  const int orow = item / nh, h = item % nh;
+  const int tok = q_rows ? q_rows[orow] : orow;
   const int kvh = h / (nh / nkv);
   const int stride = (nh + 2 * nkv) * hd;
   int lo = 0, hi = B;  // prompt index: largest b with cu[b] <= tok
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const u16* qkv, u16* 
       }
     }
   }
-  u16* op = out + (size_t)tok * nh * hd + h * hd;
+  u16* op = out + (size_t)orow * nh * hd + h * hd;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int d = lane + 64 * i;
@@ -304,6 +307,18 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   }
 }
 
+// attention for a list of query tokens only (the last layer needs just each prompt's last token)
+int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B, const int32_t* q_rows,
+                             int n_rows, int nh, int nkv, int hd, hipStream_t st) {
+  if (n_rows <= 0) return LR_OK;
+  if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
+  const int items = n_rows * nh;
+  hipLaunchKernelGGL(attn_generic_kernel, dim3((items + 3) / 4), dim3(256), 0, st, qkv, out, cu, B, n_rows,
+                     nh, nkv, hd, q_rows);
+  LR_CHECK_LAUNCH("attn_generic_kernel(rows)");
+  return LR_OK;
+}
+
 // =============================================================================================
 int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32_t* cu_host,
                         const int32_t* tok_pos, const int32_t* tok_seq, int B, int n_tok, int nh, int nkv,
@@ -339,7 +354,7 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
     const int items = n_tok * nh;
     hipLaunchKernelGGL(attn_generic_kernel, dim3((items + 3) / 4), dim3(256), 0, st, qkv, out, cu, B,
-                       n_tok, nh, nkv, hd);
+                       n_tok, nh, nkv, hd, (const int32_t*)nullptr);
     LR_CHECK_LAUNCH("attn_generic_kernel");
   } else {
     LR_FAIL(LR_EINVAL, "attention: unknown variant %d", variant);

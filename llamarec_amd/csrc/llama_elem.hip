@@ -24,9 +24,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // ---- token positions inside their prompt, and prompt index, for packed layouts ---------------
-__global__ void token_meta_kernel(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq) {
+__global__ void token_meta_kernel(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq,
+                                  int32_t* last_rows) {
   int b = blockIdx.x;
   int s = cu[b], e = cu[b + 1];
+  if (threadIdx.x == 0 && last_rows) last_rows[b] = e - 1;
   for (int t = s + threadIdx.x; t < e; t += blockDim.x) {
     tok_pos[t] = t - s;
     tok_seq[t] = b;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* 
   u16* xn = reinterpret_cast<u16*>(smem_raw);  // [d]
   __shared__ float red[4];
   const int b = blockIdx.x;
-  const int row = cu[b + 1] - 1;
+  const int row = cu ? cu[b + 1] - 1 : b;  // cu == nullptr: x is already compact, one row per prompt
   const u16* xr = x + (size_t)row * d;
   float ss = 0.f;
   for (int i = threadIdx.x; i < d; i += 256) {
@@ -176,9 +178,24 @@ __global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* 
   }
 }
 
+// ---- gather rows: out[i][:] = x[rows[i]][:] ----------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u16* x, const int32_t* rows, int d, u16* out) {
+  const u16x8* src = reinterpret_cast<const u16x8*>(x + (size_t)rows[blockIdx.x] * d);
+  u16x8* dst = reinterpret_cast<u16x8*>(out + (size_t)blockIdx.x * d);
+  for (int i = threadIdx.x; i < d / 8; i += 256) dst[i] = src[i];
+}
+
+int lr_launch_gather_rows(const u16* x, const int32_t* rows, int n_rows, int d, u16* out, hipStream_t st) {
+  if (n_rows <= 0) return LR_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_rows), dim3(256), 0, st, x, rows, d, out);
+  LR_CHECK_LAUNCH("gather_rows_kernel");
+  return LR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
-int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, hipStream_t st) {
-  hipLaunchKernelGGL(token_meta_kernel, dim3(B), dim3(256), 0, st, cu, B, tok_pos, tok_seq);
+int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, int32_t* last_rows,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(token_meta_kernel, dim3(B), dim3(256), 0, st, cu, B, tok_pos, tok_seq, last_rows);
   LR_CHECK_LAUNCH("token_meta_kernel");
   return LR_OK;
 }

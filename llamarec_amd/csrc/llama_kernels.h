@@ -23,7 +23,12 @@ __device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
 #define LR_EPI_RESIDUAL 1  // C = bf16( bf16(acc) + R )      (R may alias C)
 #define LR_EPI_SWIGLU 2    // C[M][N/2] = swiglu over interleaved gate/up 16-column groups
 
-int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, hipStream_t st);
+int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, int32_t* last_rows,
+                         hipStream_t st);
+int lr_launch_gather_rows(const unsigned short* x, const int32_t* rows, int n_rows, int d, unsigned short* out,
+                          hipStream_t st);
+int lr_launch_attention_rows(const unsigned short* qkv, unsigned short* out, const int32_t* cu, int B,
+                             const int32_t* q_rows, int n_rows, int nh, int nkv, int hd, hipStream_t st);
 int lr_launch_embed(const int32_t* ids, const unsigned short* table, int vocab, int d, unsigned short* out,
                     int n, hipStream_t st);
 int lr_launch_rmsnorm(const unsigned short* x, const unsigned short* w, unsigned short* out, int rows, int d,

@@ -125,6 +125,7 @@ struct lr_llama {
   int device;
   int gemm_variant;  // 0 auto, 1 generic, 2 256x256x64 (falls back to generic per shape when 0)
   int attn_variant;  // 0 auto, 1 generic, 2 MFMA head_dim 128
+  int prune_last;    // last layer: attention output / o_proj / MLP only for each prompt's last token
 };
 
 #endif  // LR_COMMON_H

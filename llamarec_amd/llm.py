@@ -207,6 +207,10 @@ class LlamaRanker:
         check(lib().lr_llama_set_variants(self._h, gemm, attention), "lr_llama_set_variants")
         return self
 
+    def set_last_layer_pruning(self, enable=True):
+        check(lib().lr_llama_set_last_layer_pruning(self._h, int(bool(enable))), "lr_llama_set_last_layer_pruning")
+        return self
+
     def eval(self):
         return self
 

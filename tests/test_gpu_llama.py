@@ -54,6 +54,8 @@ def assert_bf16_close(got, ref32, what, absum=None):
     (5, 7, 24, 1), (64, 64, 32, 1), (70, 130, 100, 1), (33, 96, 51, 1),
     (256, 256, 64, 2), (300, 512, 256, 2), (1, 256, 128, 2), (1000, 256, 4096, 2), (515, 768, 704, 2),
     (300, 512, 256, 0), (300, 512, 256, 3), (1000, 256, 4096, 3), (515, 768, 704, 3), (1, 256, 64, 3),
+    (300, 512, 256, 4), (1000, 256, 4096, 4), (515, 768, 704, 4), (1, 256, 64, 4), (700, 256, 128, 4),
+    (300, 512, 256, 5), (1000, 256, 4096, 5), (515, 768, 704, 5), (1, 256, 64, 5), (700, 256, 128, 5), (260, 256, 192, 5),
 ])
 def test_gemm_vs_numpy(M, N, K, variant):
     A = bf16_round(hash_uniform(M * 7 + K, (M, K), 1.0))
@@ -68,7 +70,7 @@ def test_gemm_fast_equals_generic_on_integers():
     A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)   # asymmetric patterns
     B = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
     ref = A @ B.T
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 4, 5):
         assert np.array_equal(gemm(A, B, v), bf16_round(ref)), v
 
 
@@ -210,3 +212,19 @@ def test_full_width_batch_invariance():
     # generic kernels agree with the MFMA kernels at bf16 resolution on the same weights
     gen = model.set_variants(1, 1).prefill_verbalize(seqs[:3], label_ids)
     assert (gen - full[:3]).abs().max() < 5e-2 * max(1.0, float(full.abs().max()))
+
+
+def test_last_layer_pruning_matches_full_last_layer(golden_dir):
+    """Default path prunes the last layer to each prompt's last token; the full last layer must give
+    the same logits up to bf16 summation order, and both must match the oracle."""
+    from llamarec_amd.llm import LlamaRanker
+    from oracle import llama_oracle as LO
+
+    for name in ("tiny_hd128", "tiny_gqa"):
+        z, cfg, sd, seqs = load_golden(golden_dir, name)
+        model = LlamaRanker.from_state_dict(sd, cfg)
+        pruned = model.last_logits(seqs).cpu().numpy()
+        full = model.set_last_layer_pruning(False).last_logits(seqs).cpu().numpy()
+        orc = LO.last_logits(sd, cfg, seqs, "bf16")
+        assert np.abs(pruned - full).max() < 2e-2
+        assert np.abs(pruned - orc).max() < 3e-2 and np.abs(full - orc).max() < 3e-2
