@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=32, help="Llama layers (32 = Llama-2-7b; other values are for profiling only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to "
+                    "rehearse several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -91,7 +94,9 @@ def main():
 
     from llamarec_amd import dist as D
 
-    rank, world, local = D.init_from_env()
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = D.init_from_env(args.dist_backend)
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -153,6 +158,21 @@ def main():
         lib.lr_profile_collect(kind, C.byref(ms), C.byref(work), C.byref(n))
         return ms.value, work.value, n.value
 
+    def pmc_traffic():
+        """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+        this same command (profiles/r01_pmc_summary.json, made by tools/summarize_pmc.py: FETCH_SIZE x2
+        + WRITE_SIZE, separate passes). None if the summary is absent."""
+        path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+        if not os.path.exists(path):
+            return None
+        d = json.load(open(path))
+        num = den = 0.0
+        for k, e in d.items():
+            if k.startswith("gemm256pp_kernel") and "hbm_bytes_per_launch" in e:
+                num += e["hbm_bytes_per_launch"] * e["launches_profiled"]
+                den += e["launches_profiled"]
+        return num / den if den else None
+
     roofline = None
     extra = {}
     if not args.no_profile:
@@ -164,7 +184,7 @@ def main():
             ach = g_fl / (g_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "gemm256pp_kernel (bf16 256x256x64 MFMA tile, ping-pong pipeline; QKV/O/gate-up/down)",
                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                        "traffic": None, "launches": g_n, "avg_launch_ms": g_ms / g_n,
+                        "traffic": pmc_traffic(), "launches": g_n, "avg_launch_ms": g_ms / g_n,
                         "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed}
         extra = {"attention_tflops": (a_fl / (a_ms * 1e-3) / 1e12) if a_n else None,
                  "attention_share_of_step_time": a_ms * 1e-3 / elapsed if a_n else None,
