@@ -170,7 +170,10 @@ typedef struct LrLlamaConfig {
  * (W + (alpha/r) B A; config.py:257-260, train_ranker.py:71-79). */
 typedef struct LrLlamaLayerWeights {
   const uint16_t* input_norm;    /* [hidden]                input_layernorm.weight */
-  const uint16_t* wqkv;          /* [(nh+2*nkv)*hd][hidden] q_proj;k_proj;v_proj stacked */
+  const uint16_t* wqkv;          /* [(nh+2*nkv)*hd][hidden] q_proj;k_proj;v_proj stacked; inside every q and
+                                    k head the rows are pair-interleaved for the fused rotary epilogue:
+                                    row 2i = HF row i, row 2i+1 = HF row i + hd/2 (lr_llama_pack_qkv).
+                                    q.k dot products are unchanged by this permutation. */
   const uint16_t* wo;            /* [hidden][nh*hd]         o_proj */
   const uint16_t* post_norm;     /* [hidden]                post_attention_layernorm.weight */
   const uint16_t* wgu;           /* [2*inter][hidden]       gate_proj / up_proj, interleaved in
@@ -224,6 +227,11 @@ int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t
                          const int32_t* cu_seqlens_host, int32_t B, float* out_logits,
                          void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Host helper: stack HF q_proj/k_proj/v_proj ([nh*hd][hidden], [nkv*hd][hidden] x2, bf16) into the
+ * wqkv layout above (pair-interleaved q/k head rows). Pure CPU. */
+int lr_llama_pack_qkv(const uint16_t* q, const uint16_t* k, const uint16_t* v, int32_t num_heads,
+                      int32_t num_kv_heads, int32_t head_dim, int32_t hidden, uint16_t* out);
+
 /* Host helper: interleave gate_proj / up_proj rows ([inter][hidden] each, bf16) into the wgu
  * layout above. Pure CPU. */
 int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,
@@ -238,7 +246,8 @@ int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M
                     int32_t K, int32_t variant, void* hip_stream);
 
 /* Stand-alone varlen causal attention (exposed for parity tests):
- * qkv: DEVICE bf16 [total][(nh+2*nkv)*hd] (RoPE already applied), out: bf16 [total][nh*hd]. */
+ * qkv: DEVICE bf16 [total][(nh+2*nkv)*hd] (RoPE already applied; any consistent permutation of the
+ * dims inside q and k heads), out: bf16 [total][nh*hd]. */
 int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,
                         const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads,
                         int32_t num_kv_heads, int32_t head_dim, int32_t variant, void* hip_stream);

@@ -13,7 +13,7 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
     LR_FAIL(LR_EINVAL, "lr_llama_create: bad config");
   if (cfg->hidden_size % 8 != 0 || cfg->intermediate_size % 16 != 0)
     LR_FAIL(LR_EUNSUPPORTED, "lr_llama_create: hidden_size %% 8 and intermediate_size %% 16 must be 0");
-  if (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim < 2 || cfg->head_dim % 2 != 0 ||
+  if (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim < 4 || cfg->head_dim % 4 != 0 ||
       cfg->head_dim > 256)
     LR_FAIL(LR_EUNSUPPORTED, "lr_llama_create: heads=%d kv_heads=%d head_dim=%d", cfg->num_heads,
             cfg->num_kv_heads, cfg->head_dim);
@@ -39,7 +39,7 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
 }
 
 extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
-  if (!h || gemm_variant < 0 || gemm_variant > 5 || attention_variant < 0 || attention_variant > 2)
+  if (!h || gemm_variant < 0 || gemm_variant > 6 || attention_variant < 0 || attention_variant > 2)
     LR_FAIL(LR_EINVAL, "lr_llama_set_variants: bad argument");
   h->gemm_variant = gemm_variant;
   h->attn_variant = attention_variant;
@@ -138,8 +138,9 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->layers[l];
     RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
-    RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_STORE, h->gemm_variant, st));
-    RUN(lr_launch_rope(ws.qkv, ws.tok_pos, ws.rope, n, nh + nkv, qkv_w, hd, st));
+    // QKV projection with the rotary embedding applied in the epilogue (q/k rows pair-interleaved)
+    RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
+                       ws.rope, hd, (nh + nkv) * hd));
     if (l == c.num_layers - 1 && h->prune_last) {
       // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
       // last layer needs K/V for every token but attention output, o_proj, and the MLP for B rows only.
@@ -197,6 +198,26 @@ extern "C" int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, i
     memcpy(out + (size_t)(32 * t) * hidden, gate + (size_t)(16 * t) * hidden, (size_t)16 * hidden * 2);
     memcpy(out + (size_t)(32 * t + 16) * hidden, up + (size_t)(16 * t) * hidden, (size_t)16 * hidden * 2);
   }
+  return LR_OK;
+}
+
+extern "C" int lr_llama_pack_qkv(const uint16_t* q, const uint16_t* k, const uint16_t* v, int32_t num_heads,
+                                 int32_t num_kv_heads, int32_t head_dim, int32_t hidden, uint16_t* out) {
+  if (!q || !k || !v || !out || num_heads < 1 || num_kv_heads < 1 || head_dim < 2 || head_dim % 2 || hidden < 1)
+    LR_FAIL(LR_EINVAL, "lr_llama_pack_qkv: bad arguments");
+  const int half = head_dim / 2;
+  const size_t rb = (size_t)hidden * 2;
+  size_t o = 0;
+  for (int part = 0; part < 2; ++part) {
+    const uint16_t* src = part == 0 ? q : k;
+    const int heads = part == 0 ? num_heads : num_kv_heads;
+    for (int hh = 0; hh < heads; ++hh)
+      for (int i = 0; i < half; ++i) {
+        memcpy(out + (o++) * hidden, src + ((size_t)hh * head_dim + i) * hidden, rb);
+        memcpy(out + (o++) * hidden, src + ((size_t)hh * head_dim + half + i) * hidden, rb);
+      }
+  }
+  memcpy(out + o * hidden, v, (size_t)num_kv_heads * head_dim * rb);
   return LR_OK;
 }
 

@@ -1,5 +1,6 @@
 // llama_elem.hip -- memory-bound pieces of the Llama prefill on gfx950: token-embedding gather,
-// RMSNorm, rotary embedding, SwiGLU (stand-alone form), final norm + verbalizer GEMV.
+// RMSNorm, the rotary cos/sin table, final norm + verbalizer GEMV. (RoPE itself and SwiGLU are
+// fused into GEMM epilogues, llama_gemm.hip.)
 //
 // Replaces the ATen kernels reached from HF LlamaModel (transformers modeling_llama.py: RMSNorm
 // with fp32 statistics, rotate_half RoPE, SiLU*mul) and, for the head, `lm_head` over ALL
@@ -86,58 +87,6 @@ __global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, flo
   cs[2 * i + 1] = bf2f(f2bf(sinf(ang)));
 }
 
-// rotate-half RoPE in place on the q and k heads of a packed qkv buffer [N][(nh+2nkv)*hd]
-__global__ __launch_bounds__(256) void rope_kernel(u16* qkv, const int32_t* tok_pos, const float* cs,
-                                                   int n_rot_heads, int row_stride, int hd) {
-  const int tok = blockIdx.x;
-  const int half = hd / 2;
-  const int pos = tok_pos[tok];
-  u16* row = qkv + (size_t)tok * row_stride;
-  const int per_head = half / 8;  // 8 pairs per thread-iteration
-  for (int i = threadIdx.x; i < n_rot_heads * per_head; i += 256) {
-    int h = i / per_head, c = (i % per_head) * 8;
-    u16x8* p1 = reinterpret_cast<u16x8*>(row + h * hd + c);
-    u16x8* p2 = reinterpret_cast<u16x8*>(row + h * hd + half + c);
-    u16x8 a = *p1, b = *p2, oa, ob;
-    const float* t = cs + ((size_t)pos * half + c) * 2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float co = t[2 * j], si = t[2 * j + 1];
-      float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
-      oa[j] = f2bf(x1 * co - x2 * si);
-      ob[j] = f2bf(x2 * co + x1 * si);
-    }
-    *p1 = oa;
-    *p2 = ob;
-  }
-}
-
-// generic (hd not a multiple of 16) scalar variant
-__global__ void rope_scalar_kernel(u16* qkv, const int32_t* tok_pos, const float* cs, int n_rot_heads,
-                                   int row_stride, int hd) {
-  const int tok = blockIdx.x;
-  const int half = hd / 2;
-  const int pos = tok_pos[tok];
-  u16* row = qkv + (size_t)tok * row_stride;
-  for (int i = threadIdx.x; i < n_rot_heads * half; i += blockDim.x) {
-    int h = i / half, j = i % half;
-    float co = cs[((size_t)pos * half + j) * 2], si = cs[((size_t)pos * half + j) * 2 + 1];
-    float x1 = bf2f(row[h * hd + j]), x2 = bf2f(row[h * hd + half + j]);
-    row[h * hd + j] = f2bf(x1 * co - x2 * si);
-    row[h * hd + half + j] = f2bf(x2 * co + x1 * si);
-  }
-}
-
-// ---- stand-alone SwiGLU on the interleaved gate/up layout (generic GEMM path) ---------------
-// gu [M][2f]: columns [32t,32t+16) = gate[16t..], [32t+16,32t+32) = up[16t..];  out [M][f]
-__global__ __launch_bounds__(256) void swiglu_kernel(const u16* gu, u16* out, int M, int f) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)M * f) return;
-  int m = (int)(i / f), c = (int)(i % f);
-  const u16* row = gu + (size_t)m * 2 * f + (c / 16) * 32 + (c % 16);
-  out[i] = swiglu_bf16(bf2f(row[0]), bf2f(row[16]));
-}
-
 // ---- final RMSNorm on each prompt's last token + dot with selected lm_head rows -------------
 // grid (B, ceil(C/32)); out[b][c] = float(bf16(sum_k xn[k] * W[row_c][k])), row_c = ids ? ids[c] : c
 __global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* cu, const u16* norm_w,
@@ -217,25 +166,6 @@ int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st) 
   int n = T * (hd / 2);
   hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cs, T, hd, theta);
   LR_CHECK_LAUNCH("rope_table_kernel");
-  return LR_OK;
-}
-
-int lr_launch_rope(u16* qkv, const int32_t* tok_pos, const float* cs, int n_tok, int n_rot_heads,
-                   int row_stride, int hd, hipStream_t st) {
-  if (hd % 16 == 0) {
-    hipLaunchKernelGGL(rope_kernel, dim3(n_tok), dim3(256), 0, st, qkv, tok_pos, cs, n_rot_heads, row_stride, hd);
-  } else {
-    hipLaunchKernelGGL(rope_scalar_kernel, dim3(n_tok), dim3(256), 0, st, qkv, tok_pos, cs, n_rot_heads,
-                       row_stride, hd);
-  }
-  LR_CHECK_LAUNCH("rope_kernel");
-  return LR_OK;
-}
-
-int lr_launch_swiglu(const u16* gu, u16* out, int M, int f, hipStream_t st) {
-  size_t n = (size_t)M * f;
-  hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gu, out, M, f);
-  LR_CHECK_LAUNCH("swiglu_kernel");
   return LR_OK;
 }
 

@@ -20,20 +20,50 @@
 //       output columns -> 8-byte epilogue accesses, and gate/up of one SwiGLU output meet in a lane.
 //     * workgroup -> tile map: bijective XCD remap (each XCD's L2 sees a compact set of tiles)
 //       followed by a grouped (8 M-tiles) raster so neighbours share A and B panels.
+#include <stdlib.h>
+
 #include "llama_kernels.h"
 #include "lr_profile.h"
 
 typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 
+// Rotary embedding fused into the QKV projection's epilogue. q/k head rows of wqkv are stored
+// pair-interleaved (row 2i = dim i, row 2i+1 = dim i + head_dim/2), so a lane's 4 consecutive
+// output columns are two complete rotation pairs.
+struct RopeArgs {
+  const int32_t* tok_pos;  // [M] position of each packed token inside its prompt
+  const float* cs;         // [max_T][head_dim/2][2] (cos, sin), bf16-valued
+  int head_dim;
+  int rot_cols;            // columns [0, rot_cols) are q and k heads; the rest (v) is stored as is
+};
+
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
 template <int EPI>
-__device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off) {
+__device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off,
+                                           const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0) {
   u16x4 o;
-  if (EPI == LR_EPI_STORE) {
+  if (EPI == LR_EPI_ROPE) {
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = bf2f(f2bf(v[j]));  // q/k are bf16 tensors before the rotation
+    if (col < rope.rot_cols) {
+      const int half = rope.head_dim >> 1;
+      const int i0 = (col % rope.head_dim) >> 1;
+      const float4 t = *reinterpret_cast<const float4*>(rope.cs + ((size_t)rope.tok_pos[row] * half + i0) * 2);
+      o[0] = f2bf(x[0] * t.x - x[1] * t.y);
+      o[1] = f2bf(x[1] * t.x + x[0] * t.y);
+      o[2] = f2bf(x[2] * t.z - x[3] * t.w);
+      o[3] = f2bf(x[3] * t.z + x[2] * t.w);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(x[j]);
+    }
+  } else if (EPI == LR_EPI_STORE) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
   } else if (EPI == LR_EPI_RESIDUAL) {
@@ -58,7 +88,7 @@ __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const u16* __restrict__ A,
                                                            const u16* __restrict__ B, u16* C,
-                                                           const u16* R, int M, int N, int K) {
+                                                           const u16* R, int M, int N, int K, RopeArgs rope) {
   __shared__ __attribute__((aligned(16))) u16 As[GG_BM * GG_LD];
   __shared__ __attribute__((aligned(16))) u16 Bs[GG_BN * GG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +143,18 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const u16* __restrict
   for (int mt = 0; mt < 2; ++mt) {
     int row = m0 + wm * 32 + mt * 16 + (lane & 15);
     if (row >= M) continue;
-    if (EPI == LR_EPI_SWIGLU) {
+    if (EPI == LR_EPI_ROPE) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = n0 + wn * 32 + nt * 16 + (lane >> 4) * 4;
+        if (col + 3 < N) {
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * N + col, rope, row, col);
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (col + j < N) C[(size_t)row * N + col + j] = f2bf(acc[mt][nt][j]);  // only hit when N%4 != 0 (no rope cols there)
+        }
+      }
+    } else if (EPI == LR_EPI_SWIGLU) {
       int ocol = (n0 + wn * 32) / 2 + (lane >> 4) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -150,7 +191,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
                                                       const u16* __restrict__ B, u16* C,
-                                                      const u16* R, int M, int N, int K) {
+                                                      const u16* R, int M, int N, int K, RopeArgs rope) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col);
         }
       }
     }
@@ -290,7 +331,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ A,
                                                         const u16* __restrict__ B, u16* C,
-                                                        const u16* R, int M, int N, int K) {
+                                                        const u16* R, int M, int N, int K, int group_m,
+                                                        RopeArgs rope) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,10 +348,10 @@ __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ 
   }
   int tm, tn;
   {
-    const int per_group = G2_GROUP_M * tilesN;
+    const int per_group = group_m * tilesN;
     const int g = id / per_group, rem = id % per_group;
-    const int first_m = g * G2_GROUP_M;
-    const int gsz = min(G2_GROUP_M, tilesM - first_m);
+    const int first_m = g * group_m;
+    const int gsz = min(group_m, tilesM - first_m);
     tm = first_m + rem % gsz;
     tn = rem / gsz;
   }
@@ -450,568 +492,7 @@ __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
-        }
-      }
-    }
-  }
-}
-
-// Timing-only ablations of variant 3 (results are WRONG by construction; never dispatched by
-// variant 0): ABL bit 0 = no DMA after the first K tile, bit 1 = no fragment reads after the first.
-template <int EPI, int ABL>
-__global__ __launch_bounds__(512) void gemm256abl_kernel(const u16* __restrict__ A,
-                                                        const u16* __restrict__ B, u16* C,
-                                                        const u16* R, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
-  const int nwg = tilesM * tilesN;
-  int id;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int per_group = G2_GROUP_M * tilesN;
-    const int g = id / per_group, rem = id % per_group;
-    const int first_m = g * G2_GROUP_M;
-    const int gsz = min(G2_GROUP_M, tilesM - first_m);
-    tm = first_m + rem % gsz;
-    tn = rem / gsz;
-  }
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  // ---- DMA pieces of this wave (8 rows x 128 B each), in issue order
-  //  j = 0,1: q = 2*wave + j in 0..15
-  //  S0A rows (q>>3)*128 + (q&7)*8         S0B rows (q>>2)*64 + (q&3)*8        (phase 0)
-  //  S1B rows (q>>2)*64 + 32 + (q&3)*8                                         (phase 1)
-  //  S2A rows (q>>3)*128 + 64 + (q&7)*8                                        (phase 2)
-  const int srow = lane >> 3, spos = lane & 7;
-  const char* src[8];
-  int ldsoff[8];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = 2 * wave + j;
-    const int r_s0a = (q >> 3) * 128 + (q & 7) * 8;
-    const int r_s0b = (q >> 2) * 64 + (q & 3) * 8;
-    const int rows[4] = {r_s0a, r_s0b, r_s0b + 32, r_s0a + 64};
-    const bool isA[4] = {true, false, false, true};
-    // issue order: phase0: S0A#0,S0B#0  phase1: S0A#1,S0B#1  phase2: S1B#0,S1B#1  phase3: S2A#0,S2A#1
-    const int slot[4] = {j * 2 + 0, j * 2 + 1, 4 + j, 6 + j};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = rows[t] + srow;
-      const int chunk = spos ^ ((row >> 1) & 7);
-      if (isA[t]) {
-        const int arow = min(m0 + row, M - 1);
-        src[slot[t]] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
-        ldsoff[slot[t]] = rows[t] * 128;
-      } else {
-        src[slot[t]] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
-        ldsoff[slot[t]] = 32768 + rows[t] * 128;
-      }
-    }
-  }
-
-  const int frow = lane & 15;
-  const int fsw = frow >> 1;
-  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
-  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
-  const int a_base = wm * 128 * 128;
-  const int b_base = 32768 + wn * 64 * 128;
-
-  floatx4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K >> 6;
-  // prologue: whole tile 0
-#pragma unroll
-  for (int i = 0; i < 8; ++i) glds16(src[i], smem + ldsoff[i]);
-  PP_WAIT_VM(0);
-  PP_BARRIER();
-  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
-
-  bf16x8 afr[8], b0[4], b1[4];
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = smem + (kt & 1) * G2_STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * G2_STAGE_BYTES;
-    const bool more = kt + 1 < nkt;
-    const size_t koff = (size_t)(kt + 1) * 128;
-
-#define PP_LOAD_A(mh)                                                                                 \
-  if (!((ABL & 2) && kt > 0)) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                  \
-    afr[mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo0);       \
-    afr[4 + mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo1);   \
-  }
-#define PP_LOAD_B(dst, nh)                                                                            \
-  if (!((ABL & 2) && kt > 0)) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                  \
-    dst[nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo0);       \
-    dst[2 + nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo1);   \
-  }
-#define PP_STAGE(i0)                                          \
-  if (more && !((ABL & 1) && kt > 0)) {                       \
-    glds16(src[(i0)] + koff, nxt + ldsoff[(i0)]);             \
-    glds16(src[(i0) + 1] + koff, nxt + ldsoff[(i0) + 1]);     \
-    PP_WAIT_VM(4);                                            \
-  } else {                                                    \
-    PP_WAIT_VM(0);                                            \
-  }
-#define PP_MFMA(bfrag, mh, nh)                                                                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
-  __builtin_amdgcn_sched_barrier(0);                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                      \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
-    acc[(mh)*4 + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);                \
-  __builtin_amdgcn_s_setprio(0);
-
-    // ---- phase 0: quadrant (0,0)
-    PP_LOAD_A(0)
-    PP_LOAD_B(b0, 0)
-    PP_STAGE(0)
-    PP_BARRIER();
-    PP_MFMA(b0, 0, 0)
-    PP_BARRIER();
-    // ---- phase 1: quadrant (0,1)
-    PP_LOAD_B(b1, 1)
-    PP_STAGE(2)
-    PP_BARRIER();
-    PP_MFMA(b1, 0, 1)
-    PP_BARRIER();
-    // ---- phase 2: quadrant (1,1)
-    PP_LOAD_A(1)
-    PP_STAGE(4)
-    PP_BARRIER();
-    PP_MFMA(b1, 1, 1)
-    PP_BARRIER();
-    // ---- phase 3: quadrant (1,0)
-    PP_STAGE(6)
-    PP_BARRIER();
-    PP_MFMA(b0, 1, 0)
-    PP_BARRIER();
-#undef PP_LOAD_A
-#undef PP_LOAD_B
-#undef PP_STAGE
-#undef PP_MFMA
-  }
-  if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
-
-  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
-    if (row < M) {
-      if (EPI == LR_EPI_SWIGLU) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
-        }
-      }
-    }
-  }
-}
-
-// =============================================================================================
-// 256 x 256 x 64 kernel, ping-pong pipeline with deep DMA prefetch (variant 5)
-// =============================================================================================
-// Variant 3's schedule, but every LDS region is refilled as soon as both wave groups have read it
-// (not one tile later), so each DMA has >= 4 phases (~1.5 K tiles, > 1 us) to land before its first
-// reader waits for it: the measured LDS-DMA issue->landed latency is ~1.1 us, longer than the
-// 2-phase slack of variant 3.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256pd_kernel(const u16* __restrict__ A,
-                                                        const u16* __restrict__ B, u16* C,
-                                                        const u16* R, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
-  const int nwg = tilesM * tilesN;
-  int id;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int per_group = G2_GROUP_M * tilesN;
-    const int g = id / per_group, rem = id % per_group;
-    const int first_m = g * G2_GROUP_M;
-    const int gsz = min(G2_GROUP_M, tilesM - first_m);
-    tm = first_m + rem % gsz;
-    tn = rem / gsz;
-  }
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  // ---- DMA pieces of this wave (8 rows x 128 B each), in issue order
-  //  j = 0,1: q = 2*wave + j in 0..15
-  //  S0A rows (q>>3)*128 + (q&7)*8         S0B rows (q>>2)*64 + (q&3)*8        (phase 0)
-  //  S1B rows (q>>2)*64 + 32 + (q&3)*8                                         (phase 1)
-  //  S2A rows (q>>3)*128 + 64 + (q&7)*8                                        (phase 2)
-  const int srow = lane >> 3, spos = lane & 7;
-  const char* src[8];
-  int ldsoff[8];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = 2 * wave + j;
-    const int r_s0a = (q >> 3) * 128 + (q & 7) * 8;
-    const int r_s0b = (q >> 2) * 64 + (q & 3) * 8;
-    const int rows[4] = {r_s0a, r_s0b, r_s0b + 32, r_s0a + 64};
-    const bool isA[4] = {true, false, false, true};
-    // issue order: phase0: S0A#0,S0B#0  phase1: S0A#1,S0B#1  phase2: S1B#0,S1B#1  phase3: S2A#0,S2A#1
-    const int slot[4] = {j * 2 + 0, j * 2 + 1, 4 + j, 6 + j};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = rows[t] + srow;
-      const int chunk = spos ^ ((row >> 1) & 7);
-      if (isA[t]) {
-        const int arow = min(m0 + row, M - 1);
-        src[slot[t]] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
-        ldsoff[slot[t]] = rows[t] * 128;
-      } else {
-        src[slot[t]] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
-        ldsoff[slot[t]] = 32768 + rows[t] * 128;
-      }
-    }
-  }
-
-  const int frow = lane & 15;
-  const int fsw = frow >> 1;
-  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
-  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
-  const int a_base = wm * 128 * 128;
-  const int b_base = 32768 + wn * 64 * 128;
-
-  floatx4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K >> 6;
-  // prologue: whole tile 0, plus the phase-0 rows (R0) of tile 1
-#pragma unroll
-  for (int i = 0; i < 8; ++i) glds16(src[i], smem + ldsoff[i]);
-  if (nkt > 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(src[i] + 128, smem + G2_STAGE_BYTES + ldsoff[i]);
-    PP_WAIT_VM(4);
-  } else {
-    PP_WAIT_VM(0);
-  }
-  PP_BARRIER();
-  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
-
-  bf16x8 afr[8], b0[4], b1[4];
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = smem + (kt & 1) * G2_STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * G2_STAGE_BYTES;
-    const bool more = kt + 1 < nkt;
-    const bool more2 = kt + 2 < nkt;
-    const size_t koff = (size_t)(kt + 1) * 128;
-
-#define PP_LOAD_A(mh)                                                                                 \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                  \
-    afr[mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo0);       \
-    afr[4 + mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo1);   \
-  }
-#define PP_LOAD_B(dst, nh)                                                                            \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                  \
-    dst[nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo0);       \
-    dst[2 + nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo1);   \
-  }
-  // DMA schedule (2 per phase, always >= 4 phases ahead of the first read):
-  //   LOAD_0(kt): R1 of tile kt+1   LOAD_1(kt): R2 of tile kt+1   (buffer nxt)
-  //   LOAD_2(kt): R0a of tile kt+2  LOAD_3(kt): R0b of tile kt+2  (buffer cur: its R0 rows were
-  //   last read in LOAD_0(kt), two barriers ago for both wave groups)
-  // A reader needs "all but my newest 8" complete.
-#define PP_STAGE1(i0)                                         \
-  if (more) {                                                 \
-    glds16(src[(i0)] + koff, nxt + ldsoff[(i0)]);             \
-    glds16(src[(i0) + 1] + koff, nxt + ldsoff[(i0) + 1]);     \
-  }                                                           \
-  if (more2) { PP_WAIT_VM(8); } else { PP_WAIT_VM(0); }
-#define PP_STAGE2(i0)                                                       \
-  if (more2) {                                                              \
-    glds16(src[(i0)] + koff + 128, const_cast<char*>(cur) + ldsoff[(i0)]);          \
-    glds16(src[(i0) + 1] + koff + 128, const_cast<char*>(cur) + ldsoff[(i0) + 1]);  \
-    PP_WAIT_VM(8);                                                          \
-  } else {                                                                  \
-    PP_WAIT_VM(0);                                                          \
-  }
-#define PP_MFMA(bfrag, mh, nh)                                                                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
-  __builtin_amdgcn_sched_barrier(0);                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                      \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
-    acc[(mh)*4 + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);                \
-  __builtin_amdgcn_s_setprio(0);
-
-    // ---- phase 0: quadrant (0,0)
-    PP_LOAD_A(0)
-    PP_LOAD_B(b0, 0)
-    PP_STAGE1(4)
-    PP_BARRIER();
-    PP_MFMA(b0, 0, 0)
-    PP_BARRIER();
-    // ---- phase 1: quadrant (0,1)
-    PP_LOAD_B(b1, 1)
-    PP_STAGE1(6)
-    PP_BARRIER();
-    PP_MFMA(b1, 0, 1)
-    PP_BARRIER();
-    // ---- phase 2: quadrant (1,1)
-    PP_LOAD_A(1)
-    PP_STAGE2(0)
-    PP_BARRIER();
-    PP_MFMA(b1, 1, 1)
-    PP_BARRIER();
-    // ---- phase 3: quadrant (1,0)
-    PP_STAGE2(2)
-    PP_BARRIER();
-    PP_MFMA(b0, 1, 0)
-    PP_BARRIER();
-#undef PP_LOAD_A
-#undef PP_LOAD_B
-#undef PP_STAGE1
-#undef PP_STAGE2
-#undef PP_MFMA
-  }
-  if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
-
-  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
-    if (row < M) {
-      if (EPI == LR_EPI_SWIGLU) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
-        }
-      }
-    }
-  }
-}
-
-// =============================================================================================
-// 256 x 256 x 64 kernel, k-step-major phases with fragments prefetched one phase ahead (variant 4)
-// =============================================================================================
-// Phases of a K tile: P0=(ks0,mh0) P1=(ks0,mh1) P2=(ks1,mh0) P3=(ks1,mh1); each multiplies the
-// 64 rows `mh` of the wave by all 64 columns over one 32-deep k-step (16 MFMAs). LOAD_p reads
-// the fragments of phase p+1 (4 or 8 ds_read_b128 into the OTHER register set), so a wave's MFMA
-// segment never waits for LDS, and issues 2 DMAs. Wave groups run one barrier apart as in variant 3.
-//   DMA sets of tile t+1 (consumption order): S0 = A rows mh0 (both groups) + all B rows (6 pieces
-//   per wave; first read in LOAD_3 of tile t), S1 = A rows mh1 (2 pieces; first read in LOAD_0 of
-//   tile t+1). Issue: S0 in LOAD_3(t-1), LOAD_0(t), LOAD_1(t); S1 in LOAD_2(t). Waits: vmcnt(2)
-//   at the end of LOAD_2 (S0 landed) and of LOAD_3 (S1 landed); each is followed by a barrier
-//   that every reader passes before its first read. Fragment reads are retired (lgkmcnt(0)) at
-//   the END of the MFMA segment that follows them, i.e. before the barrier after which the
-//   other group may overwrite that LDS region by DMA.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256km_kernel(const u16* __restrict__ A,
-                                                        const u16* __restrict__ B, u16* C,
-                                                        const u16* R, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
-  const int nwg = tilesM * tilesN;
-  int id;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int per_group = G2_GROUP_M * tilesN;
-    const int g = id / per_group, rem = id % per_group;
-    const int first_m = g * G2_GROUP_M;
-    const int gsz = min(G2_GROUP_M, tilesM - first_m);
-    tm = first_m + rem % gsz;
-    tn = rem / gsz;
-  }
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  // ---- DMA pieces of this wave in issue order: [0,1] S0 A rows, [2..5] S0 B rows, [6,7] S1 A rows
-  const int srow = lane >> 3, spos = lane & 7;
-  const char* src[8];
-  int ldsoff[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int base_row;
-    bool isA;
-    if (i < 2) {
-      const int q = 2 * wave + i;
-      base_row = (q >> 3) * 128 + (q & 7) * 8;
-      isA = true;
-    } else if (i < 6) {
-      base_row = (4 * wave + (i - 2)) * 8;
-      isA = false;
-    } else {
-      const int q = 2 * wave + (i - 6);
-      base_row = (q >> 3) * 128 + 64 + (q & 7) * 8;
-      isA = true;
-    }
-    const int row = base_row + srow;
-    const int chunk = spos ^ ((row >> 1) & 7);
-    if (isA) {
-      const int arow = min(m0 + row, M - 1);
-      src[i] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
-      ldsoff[i] = base_row * 128;
-    } else {
-      src[i] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
-      ldsoff[i] = 32768 + base_row * 128;
-    }
-  }
-
-  const int frow = lane & 15;
-  const int fsw = frow >> 1;
-  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
-  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
-  const int a_base = wm * 128 * 128;
-  const int b_base = 32768 + wn * 64 * 128;
-
-  floatx4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K >> 6;
-  bf16x8 Aa[4], Ab[4], Ba[4], Bb[4];
-
-#define KM_LOAD_A(dst, buf, ks, mh)                                                              \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *reinterpret_cast<const bf16x8*>(  \
-      (buf) + a_base + ((mh)*64 + mt * 16) * 128 + ((ks) ? fo1 : fo0));
-#define KM_LOAD_B(dst, buf, ks)                                                                  \
-  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) dst[nt] = *reinterpret_cast<const bf16x8*>(  \
-      (buf) + b_base + (nt * 16) * 128 + ((ks) ? fo1 : fo0));
-#define KM_DMA2(i0, tile, buf)                                               \
-  do {                                                                       \
-    glds16(src[(i0)] + (size_t)(tile)*128, (buf) + ldsoff[(i0)]);            \
-    glds16(src[(i0) + 1] + (size_t)(tile)*128, (buf) + ldsoff[(i0) + 1]);    \
-  } while (0)
-#define KM_MFMA(Afr, Bfr, mh)                                                                      \
-  __builtin_amdgcn_sched_barrier(0);                                                               \
-  __builtin_amdgcn_s_setprio(1);                                                                   \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                 \
-  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                 \
-    acc[(mh)*4 + mt][nt] =                                                                         \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bfr[nt], Afr[mt], acc[(mh)*4 + mt][nt], 0, 0, 0);  \
-  __builtin_amdgcn_s_setprio(0);                                                                   \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  // ---- prologue: all of tile 0, then the first fragments and the first S0 pair of tile 1
-#pragma unroll
-  for (int i = 0; i < 8; ++i) glds16(src[i], smem + ldsoff[i]);
-  PP_WAIT_VM(0);
-  PP_BARRIER();
-  KM_LOAD_A(Aa, smem, 0, 0)
-  KM_LOAD_B(Ba, smem, 0)
-  if (nkt > 1) KM_DMA2(0, 1, smem + G2_STAGE_BYTES);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = smem + (kt & 1) * G2_STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * G2_STAGE_BYTES;
-    const bool more = kt + 1 < nkt;
-    const bool more2 = kt + 2 < nkt;
-
-    // ---- P0 = (ks0, mh0): uses Aa, Ba
-    KM_LOAD_A(Ab, cur, 0, 1)
-    if (more) KM_DMA2(2, kt + 1, nxt);
-    PP_BARRIER();
-    KM_MFMA(Aa, Ba, 0)
-    PP_BARRIER();
-    // ---- P1 = (ks0, mh1): uses Ab, Ba
-    KM_LOAD_A(Aa, cur, 1, 0)
-    KM_LOAD_B(Bb, cur, 1)
-    if (more) KM_DMA2(4, kt + 1, nxt);
-    PP_BARRIER();
-    KM_MFMA(Ab, Ba, 1)
-    PP_BARRIER();
-    // ---- P2 = (ks1, mh0): uses Aa, Bb
-    KM_LOAD_A(Ab, cur, 1, 1)
-    if (more) {
-      KM_DMA2(6, kt + 1, nxt);
-      PP_WAIT_VM(2);  // S0 of tile kt+1 has landed (only the S1 pair may be in flight)
-    }
-    PP_BARRIER();
-    KM_MFMA(Aa, Bb, 0)
-    PP_BARRIER();
-    // ---- P3 = (ks1, mh1): uses Ab, Bb; prefetches tile kt+1's first fragments
-    if (more) {
-      KM_LOAD_A(Aa, nxt, 0, 0)
-      KM_LOAD_B(Ba, nxt, 0)
-      if (more2) {
-        KM_DMA2(0, kt + 2, const_cast<char*>(cur));
-        PP_WAIT_VM(2);  // S1 of tile kt+1 has landed
-      } else {
-        PP_WAIT_VM(0);
-      }
-    }
-    PP_BARRIER();
-    KM_MFMA(Ab, Bb, 1)
-    PP_BARRIER();
-  }
-  if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
-#undef KM_LOAD_A
-#undef KM_LOAD_B
-#undef KM_DMA2
-#undef KM_MFMA
-
-  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
-    if (row < M) {
-      if (EPI == LR_EPI_SWIGLU) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col);
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col);
         }
       }
     }
@@ -1021,47 +502,24 @@ __global__ __launch_bounds__(512) void gemm256km_kernel(const u16* __restrict__ 
 // =============================================================================================
 template <int EPI>
 static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
-                      hipStream_t st) {
+                      RopeArgs rope, hipStream_t st) {
   LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
-  if (variant >= 11 && variant <= 13) {
-    const int nwg = ((M + 255) / 256) * (N / 256);
-    const void* fn = variant == 11 ? reinterpret_cast<const void*>(gemm256abl_kernel<EPI, 1>)
-                   : variant == 12 ? reinterpret_cast<const void*>(gemm256abl_kernel<EPI, 2>)
-                                   : reinterpret_cast<const void*>(gemm256abl_kernel<EPI, 3>);
-    LR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-    if (variant == 11) hipLaunchKernelGGL((gemm256abl_kernel<EPI, 1>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
-    if (variant == 12) hipLaunchKernelGGL((gemm256abl_kernel<EPI, 2>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
-    if (variant == 13) hipLaunchKernelGGL((gemm256abl_kernel<EPI, 3>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
-    LR_CHECK_LAUNCH("gemm256abl_kernel");
-  } else if (variant == 5) {
-    static bool attr_set5 = false;
-    if (!attr_set5) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pd_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-      attr_set5 = true;
-    }
-    const int nwg = ((M + 255) / 256) * (N / 256);
-    hipLaunchKernelGGL(gemm256pd_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
-    LR_CHECK_LAUNCH("gemm256pd_kernel");
-  } else if (variant == 4) {
-    static bool attr_set4 = false;
-    if (!attr_set4) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256km_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-      attr_set4 = true;
-    }
-    const int nwg = ((M + 255) / 256) * (N / 256);
-    hipLaunchKernelGGL(gemm256km_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
-    LR_CHECK_LAUNCH("gemm256km_kernel");
-  } else if (variant == 3) {
+  const int nwg = ((M + 255) / 256) * (N / 256);
+  if (variant == 3) {
     static bool attr_set3 = false;
     if (!attr_set3) {
       LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
       attr_set3 = true;
     }
-    const int nwg = ((M + 255) / 256) * (N / 256);
-    hipLaunchKernelGGL(gemm256pp_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
+    static int group_m = 0;
+    if (group_m == 0) {
+      const char* e = getenv("LR_GEMM_GROUP_M");  // tuning knob (tile raster), default 8
+      group_m = e ? atoi(e) : G2_GROUP_M;
+      if (group_m < 1) group_m = G2_GROUP_M;
+    }
+    hipLaunchKernelGGL(gemm256pp_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
+                       group_m, rope);
     LR_CHECK_LAUNCH("gemm256pp_kernel");
   } else if (variant == 2) {
     static bool attr_set = false;
@@ -1070,19 +528,19 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
       attr_set = true;
     }
-    const int nwg = ((M + 255) / 256) * (N / 256);
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K, rope);
     LR_CHECK_LAUNCH("gemm256_kernel");
   } else {
     dim3 grid((N + GG_BN - 1) / GG_BN, (M + GG_BM - 1) / GG_BM);
-    hipLaunchKernelGGL(gemm_generic_kernel<EPI>, grid, dim3(256), 0, st, A, B, C, R, M, N, K);
+    hipLaunchKernelGGL(gemm_generic_kernel<EPI>, grid, dim3(256), 0, st, A, B, C, R, M, N, K, rope);
     LR_CHECK_LAUNCH("gemm_generic_kernel");
   }
   return LR_OK;
 }
 
 int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
-                   int variant, hipStream_t st) {
+                   int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs, int head_dim,
+                   int rot_cols) {
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
@@ -1091,11 +549,17 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
     LR_FAIL(LR_EUNSUPPORTED, "gemm variant 2/3 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  if ((variant < 1 || variant > 5) && (variant < 11 || variant > 13)) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
+  if (variant < 1 || variant > 3) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
+  RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols};
+  if (epi == LR_EPI_ROPE) {
+    if (!tok_pos || !rope_cs || head_dim < 2 || head_dim % 4 != 0 || rot_cols % 4 != 0 || rot_cols > N)
+      LR_FAIL(LR_EINVAL, "rope epilogue: bad arguments (head_dim=%d rot_cols=%d)", head_dim, rot_cols);
+  }
   switch (epi) {
-    case LR_EPI_STORE: return launch_epi<LR_EPI_STORE>(A, B, C, R, M, N, K, variant, st);
-    case LR_EPI_RESIDUAL: return launch_epi<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, variant, st);
-    case LR_EPI_SWIGLU: return launch_epi<LR_EPI_SWIGLU>(A, B, C, R, M, N, K, variant, st);
+    case LR_EPI_STORE: return launch_epi<LR_EPI_STORE>(A, B, C, R, M, N, K, variant, rope, st);
+    case LR_EPI_RESIDUAL: return launch_epi<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, variant, rope, st);
+    case LR_EPI_SWIGLU: return launch_epi<LR_EPI_SWIGLU>(A, B, C, R, M, N, K, variant, rope, st);
+    case LR_EPI_ROPE: return launch_epi<LR_EPI_ROPE>(A, B, C, R, M, N, K, variant, rope, st);
   }
   LR_FAIL(LR_EINVAL, "gemm: unknown epilogue %d", epi);
 }

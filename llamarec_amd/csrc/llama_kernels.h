@@ -22,6 +22,7 @@ __device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
 #define LR_EPI_STORE 0     // C = bf16(acc)
 #define LR_EPI_RESIDUAL 1  // C = bf16( bf16(acc) + R )      (R may alias C)
 #define LR_EPI_SWIGLU 2    // C[M][N/2] = swiglu over interleaved gate/up 16-column groups
+#define LR_EPI_ROPE 3      // C = bf16(acc) with rotary embedding on the pair-interleaved q/k columns
 
 int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, int32_t* last_rows,
                          hipStream_t st);
@@ -34,16 +35,15 @@ int lr_launch_embed(const int32_t* ids, const unsigned short* table, int vocab, 
 int lr_launch_rmsnorm(const unsigned short* x, const unsigned short* w, unsigned short* out, int rows, int d,
                       float eps, const int32_t* row_map, hipStream_t st);
 int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st);
-int lr_launch_rope(unsigned short* qkv, const int32_t* tok_pos, const float* cs, int n_tok, int n_rot_heads,
-                   int row_stride, int hd, hipStream_t st);
-int lr_launch_swiglu(const unsigned short* gu, unsigned short* out, int M, int f, hipStream_t st);
 int lr_launch_head(const unsigned short* x, const int32_t* cu, const unsigned short* norm_w,
                    const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
                    float* out, hipStream_t st);
 
 // C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 2 256x256x64 MFMA tile.
 int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned short* C,
-                   const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st);
+                   const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st,
+                   const int32_t* tok_pos = nullptr, const float* rope_cs = nullptr, int head_dim = 0,
+                   int rot_cols = 0);
 
 // varlen causal attention over packed qkv (RoPE applied). variant: 0 auto, 1 generic, 2 MFMA hd=128.
 int lr_launch_attention(const unsigned short* qkv, unsigned short* out, const int32_t* cu,

@@ -113,7 +113,8 @@ class LlamaRanker:
         for i in range(L):
             p = f"model.layers.{i}."
             q, k, v = (merged(p + f"self_attn.{n}_proj.weight") for n in "qkv")
-            T[f"{i}.wqkv"] = torch.cat([q, k, v], 0).to(torch.bfloat16).contiguous()
+            T[f"{i}.wqkv"] = torch.cat([self._interleave_rope_rows(q), self._interleave_rope_rows(k), v],
+                                       0).to(torch.bfloat16).contiguous()
             T[f"{i}.wo"] = t(p + "self_attn.o_proj.weight").to(torch.bfloat16).contiguous()
             T[f"{i}.wgu"] = self._interleave_gate_up(t(p + "mlp.gate_proj.weight"), t(p + "mlp.up_proj.weight"))
             T[f"{i}.wdown"] = t(p + "mlp.down_proj.weight").to(torch.bfloat16).contiguous()
@@ -172,6 +173,13 @@ class LlamaRanker:
                     w[k.replace("base_model.model.", "").replace(".default", "")] = f.get_tensor(k).float().numpy()
             lora = dict(r=ac["r"], alpha=ac["lora_alpha"], weights=w)
         return cls.from_state_dict(sd, cfg, device, lora)
+
+    def _interleave_rope_rows(self, w):
+        """Rows of every head reordered to (0, hd/2, 1, hd/2+1, ...): rotation pairs become adjacent
+        output columns for the fused rotary epilogue (== lr_llama_pack_qkv)."""
+        hd = self.hd
+        heads = w.shape[0] // hd
+        return w.view(heads, 2, hd // 2, w.shape[1]).transpose(1, 2).reshape(heads * hd, w.shape[1])
 
     @staticmethod
     def _interleave_gate_up(gate, up):

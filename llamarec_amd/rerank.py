@@ -72,6 +72,24 @@ class LLMEvaluator:
         return average_metrics
 
 
+def build_val_items(dataset, retrieved, tokenizer, args=None, prompter=None):
+    """LLMValidDataset (dataloader/llm.py:286-334): history = train[-llm_max_history:], candidates = the
+    retriever's ordered top-20 for the validation answer."""
+    max_hist = getattr(args, "llm_max_history", P.LLM_MAX_HISTORY)
+    kw = dict(max_title_len=getattr(args, "llm_max_title_len", P.LLM_MAX_TITLE_LEN),
+              max_text_len=getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN),
+              system_template=getattr(args, "llm_system_template", None) or P.DEFAULT_SYSTEM_TEMPLATE,
+              input_template=getattr(args, "llm_input_template", None) or P.DEFAULT_INPUT_TEMPLATE)
+    prompter = prompter or P.Prompter()
+    items = []
+    for user, cands in zip(retrieved["val_users"], retrieved["val_candidates"]):
+        seq = list(dataset["train"][user])[-max_hist:]
+        answer = dataset["val"][user][0]
+        assert answer in cands  # dataloader/llm.py:322
+        items.append(P.seq_to_token_ids(seq, cands, answer, dataset["meta"], tokenizer, prompter, **kw))
+    return items
+
+
 def build_test_items(dataset, retrieved, tokenizer, args=None, prompter=None):
     """LLMTestDataset (dataloader/llm.py:337-387): history = (train + val)[-llm_max_history:],
     candidates = the retriever's ordered top-20 (not shuffled), answer = test item."""

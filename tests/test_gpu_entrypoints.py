@@ -70,3 +70,44 @@ def test_entry_points_synthetic(tmp_path):
     assert sub["test_loss"] == -1.0 and set(ov) == {f"test_{m}@{k}" for m in ("Recall", "MRR", "NDCG") for k in (1, 5, 10)}
     n_ret, n_all = r["test_retrieval"]["retrieval_size"], r["test_retrieval"]["original_size"]
     assert abs(ov["test_Recall@10"] - sub["test_Recall@10"] * n_ret / n_all) < 1e-12
+
+
+def test_online_single_user_path(golden_dir):
+    """demo/inference.py flow: retrieve (no mask, no padding) -> prompt -> rank, vs the oracles."""
+    from llamarec_amd import data as D
+    from llamarec_amd import inference as I
+    from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.synth import synth_llama_state
+    from llamarec_amd.verb import ManualVerbalizer
+    from oracle import llama_oracle as LO
+    from oracle import lru_oracle as O
+    from tests.fake_tokenizer import FakeTokenizer
+
+    ds = D.synthetic_dataset(num_users=5, num_items=400, seed=3)
+    sd = init_lru_state_dict(400, seed=9)
+    retr = LRURec.from_state_dict(sd)
+    query = ds["train"][1][-7:]
+    cands = I.retrieve_candidates(retr, query, top_k=20)
+    oi, _ = O.LruOracle(sd).retrieve_topk(np.asarray(query)[None, :], 20, False)
+    assert cands == oi[0].tolist()
+    prompt = I.generate_prompt(query, cands, ds["meta"])
+    assert prompt.startswith("### Instruction:\n") and prompt.endswith("### Response:\n") and "(T) " in prompt
+    tok = FakeTokenizer()
+    cfg = dict(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               num_key_value_heads=2, max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=10000.0)
+    lsd = synth_llama_state(cfg, 11)
+    ranker = LlamaRanker.from_state_dict(lsd, cfg)
+    verb = ManualVerbalizer(tokenizer=tok, classes=list(range(20)), label_words={i: chr(65 + i) for i in range(20)})
+    top = I.rank_candidates(ranker, tok, prompt, cands, verb, top_k=10)
+    assert len(top) == 10 and set(top) <= set(cands)
+    ids = tok(prompt)["input_ids"]
+    ref = LO.prefill_verbalize(lsd, cfg, [np.asarray(ids)], verb.label_token_ids, "bf16")[0]
+    got = ranker.prefill_verbalize([np.asarray(ids)], verb.label_token_ids)[0].cpu().numpy()
+    assert np.abs(got - ref).max() < 3e-2
+    # same ranking wherever the oracle's score gaps are clear of the tolerance
+    order = np.argsort(-ref, kind="stable")
+    gaps = -np.diff(ref[order])
+    for j in range(9):
+        if gaps[j] > 6e-2 and (j == 0 or gaps[j - 1] > 6e-2):
+            assert top[j] == cands[order[j]]

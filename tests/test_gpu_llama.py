@@ -54,8 +54,7 @@ def assert_bf16_close(got, ref32, what, absum=None):
     (5, 7, 24, 1), (64, 64, 32, 1), (70, 130, 100, 1), (33, 96, 51, 1),
     (256, 256, 64, 2), (300, 512, 256, 2), (1, 256, 128, 2), (1000, 256, 4096, 2), (515, 768, 704, 2),
     (300, 512, 256, 0), (300, 512, 256, 3), (1000, 256, 4096, 3), (515, 768, 704, 3), (1, 256, 64, 3),
-    (300, 512, 256, 4), (1000, 256, 4096, 4), (515, 768, 704, 4), (1, 256, 64, 4), (700, 256, 128, 4),
-    (300, 512, 256, 5), (1000, 256, 4096, 5), (515, 768, 704, 5), (1, 256, 64, 5), (700, 256, 128, 5), (260, 256, 192, 5),
+    (700, 256, 128, 3), (260, 256, 192, 3),
 ])
 def test_gemm_vs_numpy(M, N, K, variant):
     A = bf16_round(hash_uniform(M * 7 + K, (M, K), 1.0))
@@ -70,7 +69,7 @@ def test_gemm_fast_equals_generic_on_integers():
     A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)   # asymmetric patterns
     B = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
     ref = A @ B.T
-    for v in (1, 2, 3, 4, 5):
+    for v in (1, 2, 3):
         assert np.array_equal(gemm(A, B, v), bf16_round(ref)), v
 
 
@@ -181,7 +180,13 @@ def test_lora_merge_and_gate_up_packing(golden_dir):
     got = model.last_logits(seqs).cpu().numpy()
     assert np.abs(got - LO.last_logits(sd2, cfg, seqs, "bf16")).max() < 3e-2
     assert np.abs(got - z["logits_bf16"]).max() > 3e-2  # the adapter really changed the model
-    # host packer == the torch interleave used at load
+    # host packers == the torch interleaves used at load
+    nh, nkv, hd, d = cfg["num_attention_heads"], cfg["num_key_value_heads"], model.hd, cfg["hidden_size"]
+    qb, kb, vb = (f32_to_bf16_bits(sd2[f"model.layers.0.self_attn.{n}_proj.weight"]) for n in "qkv")
+    packed = np.empty(((nh + 2 * nkv) * hd, d), np.uint16)
+    check(lib().lr_llama_pack_qkv(qb.ctypes.data, kb.ctypes.data, vb.ctypes.data, nh, nkv, hd, d, packed.ctypes.data), "pack_qkv")
+    assert np.array_equal(packed.view(np.int16), model._tensors["0.wqkv"].view(torch.int16).cpu().numpy())
+    assert np.array_equal(packed[0], qb[0]) and np.array_equal(packed[1], qb[hd // 2]) and np.array_equal(packed[2], qb[1])
     g = f32_to_bf16_bits(sd["model.layers.0.mlp.gate_proj.weight"])
     u = f32_to_bf16_bits(sd["model.layers.0.mlp.up_proj.weight"])
     out = np.empty((2 * g.shape[0], g.shape[1]), np.uint16)
