@@ -168,7 +168,7 @@ def main():
         d = json.load(open(path))
         num = den = 0.0
         for k, e in d.items():
-            if k.startswith("gemm256pp_kernel") and "hbm_bytes_per_launch" in e:
+            if k.startswith("gemm256") and "hbm_bytes_per_launch" in e:
                 num += e["hbm_bytes_per_launch"] * e["launches_profiled"]
                 den += e["launches_profiled"]
         return num / den if den else None
@@ -182,7 +182,7 @@ def main():
         k_ms, k_fl, k_n = collect(5)
         if g_n:
             ach = g_fl / (g_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm256pp_kernel (bf16 256x256x64 MFMA tile, ping-pong pipeline; QKV/O/gate-up/down)",
+            roofline = {"bound": "mfma", "kernel": "gemm256rb_kernel (bf16 256x256x64 MFMA tile, ping-pong pipeline; QKV+RoPE/O/gate-up+SwiGLU/down)",
                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                         "traffic": pmc_traffic(), "launches": g_n, "avg_launch_ms": g_ms / g_n,
                         "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed}

@@ -195,7 +195,7 @@ int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_ll
 void lr_llama_destroy(lr_llama_t* h);
 
 /* Kernel selection for parity tests: 0 = auto (default), 1 = generic kernels, 2 = the MFMA
- * 256x256x64 GEMM / head_dim-128 flash attention, gemm 3 = ping-pong pipelined 256x256x64 GEMM
+ * 256x256x64 GEMM / head_dim-128 flash attention, gemm 3 / 4 = ping-pong pipelined 256x256x64 GEMMs
  * (an error if a shape does not fit). */
 int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant);
 
@@ -241,7 +241,8 @@ int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inte
  * C[M][N] = A[M][K] * B[N][K]^T, bf16 in, fp32 accumulate, bf16 out; all DEVICE pointers,
  * row-major, leading dimensions = K, K, N. variant: 0 = auto, 1 = generic (any shape),
  * 2 = 256x256x64 MFMA tile, double-buffered; 3 = the same tile with the ping-pong 4-phase
- * pipeline (default for N%256==0, K%64==0, M>=128; any M: rows are bounds-checked). */
+ * pipeline; 4 = ping-pong with balanced fragment reads and region-recycling DMA prefetch (default for
+ * N%256==0, K%64==0, M>=128; any M: rows are bounds-checked). */
 int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
                     int32_t K, int32_t variant, void* hip_stream);
 

@@ -328,7 +328,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
 
-template <int EPI>
+// Diagnostic stamps (STAMP = true, variant 9 only, never in the product path): per phase the
+// s_memtime deltas of [LOAD + DMA issue + vmcnt wait], [wait at barrier A], [MFMA issue],
+// [wait at barrier B], summed over the K loop, for waves 0 and 4 of the first 8 workgroups.
+__device__ unsigned long long g_gemm_stamps[8 * 2 * 24];
+
+#define PP_STAMP(slot)                                                                         \
+  if (STAMP) {                                                                                 \
+    unsigned long long t_;                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    stamp_acc[(slot)] += t_ - t_prev;                                                          \
+    t_prev = t_;                                                                               \
+  }
+
+template <int EPI, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ A,
                                                         const u16* __restrict__ B, u16* C,
                                                         const u16* R, int M, int N, int K, int group_m,
@@ -411,6 +426,13 @@ __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ 
   if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
 
   bf16x8 afr[8], b0[4], b1[4];
+  unsigned long long stamp_acc[24];
+  unsigned long long t_prev = 0;
+  if (STAMP) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) stamp_acc[i] = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     const char* cur = smem + (kt & 1) * G2_STAGE_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * G2_STAGE_BYTES;
@@ -428,9 +450,11 @@ __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ 
     dst[2 + nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo1);   \
   }
 #define PP_STAGE(i0)                                          \
+  PP_STAMP(((i0) / 2) * 6 + 0) /* fragment reads landed */    \
   if (more) {                                                 \
     glds16(src[(i0)] + koff, nxt + ldsoff[(i0)]);             \
     glds16(src[(i0) + 1] + koff, nxt + ldsoff[(i0) + 1]);     \
+    PP_STAMP(((i0) / 2) * 6 + 1) /* DMAs issued */            \
     PP_WAIT_VM(4);                                            \
   } else {                                                    \
     PP_WAIT_VM(0);                                            \
@@ -450,32 +474,261 @@ __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ 
     PP_LOAD_A(0)
     PP_LOAD_B(b0, 0)
     PP_STAGE(0)
+    PP_STAMP(2)
     PP_BARRIER();
+    PP_STAMP(3)
     PP_MFMA(b0, 0, 0)
+    PP_STAMP(4)
     PP_BARRIER();
+    PP_STAMP(5)
     // ---- phase 1: quadrant (0,1)
     PP_LOAD_B(b1, 1)
     PP_STAGE(2)
+    PP_STAMP(8)
     PP_BARRIER();
+    PP_STAMP(9)
     PP_MFMA(b1, 0, 1)
+    PP_STAMP(10)
     PP_BARRIER();
+    PP_STAMP(11)
     // ---- phase 2: quadrant (1,1)
     PP_LOAD_A(1)
     PP_STAGE(4)
+    PP_STAMP(14)
     PP_BARRIER();
+    PP_STAMP(15)
     PP_MFMA(b1, 1, 1)
+    PP_STAMP(16)
     PP_BARRIER();
+    PP_STAMP(17)
     // ---- phase 3: quadrant (1,0)
     PP_STAGE(6)
+    PP_STAMP(20)
     PP_BARRIER();
+    PP_STAMP(21)
     PP_MFMA(b0, 1, 0)
+    PP_STAMP(22)
     PP_BARRIER();
+    PP_STAMP(23)
 #undef PP_LOAD_A
 #undef PP_LOAD_B
 #undef PP_STAGE
 #undef PP_MFMA
   }
   if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
+  if (STAMP) {
+    if (blockIdx.x < 8 && (wave == 0 || wave == 4) && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) g_gemm_stamps[(blockIdx.x * 2 + (wave >> 2)) * 24 + i] = stamp_acc[i];
+    }
+  }
+
+  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
+    if (row < M) {
+      if (EPI == LR_EPI_SWIGLU) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
+          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// 256 x 256 x 64 kernel, ping-pong pipeline, balanced fragment reads + region-recycling DMA (variant 4)
+// =============================================================================================
+// Measured on variant 3 with s_memtime stamps (tools/gemm_stamps.py): every LOAD segment is longer
+// than the partner's 16-MFMA segment -- LOAD_0 lands 12 ds_read_b128 (~380 cycles), a pair of DMAs
+// takes ~190 cycles to issue, and the vmcnt wait of LOAD_3 stalls ~250 cycles on DMA latency
+// (issue -> landed ~ 1 us). This variant
+//  * reads (8,4,8,4) fragments per phase instead of (12,4,8,0): the next tile's B(nh0) fragments are
+//    read in LOAD_3 of the current tile into a second register set (tiles alternate b0x / b0y);
+//  * recycles each LDS region two phases after its last read, so every DMA is issued SIX phases
+//    (~1.5 K tiles) before its first reader waits for it:
+//        LOAD_0(t): R2 (A rows mh1) of tile t+1      LOAD_1(t): R0B (B rows nh0) of tile t+2
+//        LOAD_2(t): R0A (A rows mh0) of tile t+2     LOAD_3(t): R1 (B rows nh1) of tile t+2
+//    a reader needs "all but my newest 10" complete (uniform s_waitcnt vmcnt(10)).
+// Hazards: a region is overwritten only after both wave groups retired their reads of it (issue at
+// LOAD_{p+2} for reads of LOAD_p: two barriers later for either group); every wait is followed by a
+// barrier that each reader passes before its read.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ A,
+                                                        const u16* __restrict__ B, u16* C,
+                                                        const u16* R, int M, int N, int K, int group_m,
+                                                        RopeArgs rope) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
+  const int nwg = tilesM * tilesN;
+  int id;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int per_group = group_m * tilesN;
+    const int g = id / per_group, rem = id % per_group;
+    const int first_m = g * group_m;
+    const int gsz = min(group_m, tilesM - first_m);
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
+  }
+  const int m0 = tm << 8, n0 = tn << 8;
+
+  // ---- DMA pieces of this wave (8 rows x 128 B), two per region; q = 2*wave + j in 0..15
+  //  region 0 = R0A: A rows (q>>3)*128 + (q&7)*8          region 1 = R0B: B rows (q>>2)*64 + (q&3)*8
+  //  region 2 = R1 : B rows (q>>2)*64 + 32 + (q&3)*8      region 3 = R2 : A rows (q>>3)*128 + 64 + (q&7)*8
+  const int srow = lane >> 3, spos = lane & 7;
+  const char* src[4][2];
+  int ldsoff[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = 2 * wave + j;
+    const int ra = (q >> 3) * 128 + (q & 7) * 8;
+    const int rb = (q >> 2) * 64 + (q & 3) * 8;
+    const int rows[4] = {ra, rb, rb + 32, ra + 64};
+    const bool isA[4] = {true, false, false, true};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = rows[t] + srow;
+      const int chunk = spos ^ ((row >> 1) & 7);
+      if (isA[t]) {
+        const int arow = min(m0 + row, M - 1);
+        src[t][j] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
+        ldsoff[t][j] = rows[t] * 128;
+      } else {
+        src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
+        ldsoff[t][j] = 32768 + rows[t] * 128;
+      }
+    }
+  }
+  // DMA both pieces of region `reg` of K tile `tile` into stage buffer tile&1
+#define RB_DMA(reg, tile)                                                                         \
+  do {                                                                                            \
+    char* dst_ = smem + ((tile)&1) * G2_STAGE_BYTES;                                              \
+    glds16(src[(reg)][0] + (size_t)(tile)*128, dst_ + ldsoff[(reg)][0]);                          \
+    glds16(src[(reg)][1] + (size_t)(tile)*128, dst_ + ldsoff[(reg)][1]);                          \
+  } while (0)
+
+  const int frow = lane & 15;
+  const int fsw = frow >> 1;
+  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
+  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
+  const int a_base = wm * 128 * 128;
+  const int b_base = 32768 + wn * 64 * 128;
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K >> 6;
+  bf16x8 afr[8], b0x[4], b0y[4], b1[4];
+
+#define RB_LOAD_A(buf, mh)                                                                            \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                  \
+    afr[mt] = *reinterpret_cast<const bf16x8*>((buf) + a_base + ((mh)*64 + mt * 16) * 128 + fo0);     \
+    afr[4 + mt] = *reinterpret_cast<const bf16x8*>((buf) + a_base + ((mh)*64 + mt * 16) * 128 + fo1); \
+  }
+#define RB_LOAD_B(dst, buf, nh)                                                                       \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                  \
+    dst[nt] = *reinterpret_cast<const bf16x8*>((buf) + b_base + ((nh)*32 + nt * 16) * 128 + fo0);     \
+    dst[2 + nt] = *reinterpret_cast<const bf16x8*>((buf) + b_base + ((nh)*32 + nt * 16) * 128 + fo1); \
+  }
+#define RB_MFMA(bfrag, mh, nh)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  __builtin_amdgcn_s_setprio(1);                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
+    acc[(mh)*4 + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);                \
+  __builtin_amdgcn_s_setprio(0);
+#define RB_WAIT(steady)                               \
+  if (steady) { PP_WAIT_VM(10); } else { PP_WAIT_VM(0); }
+
+  // One K tile; b0cur holds this tile's B(nh0) fragments (read during the previous tile's LOAD_3 or the
+  // prologue), b0nxt receives the next tile's.
+#define RB_TILE(kt, b0cur, b0nxt)                                                                     \
+  {                                                                                                   \
+    const char* cur = smem + ((kt)&1) * G2_STAGE_BYTES;                                               \
+    const char* nxt = smem + (((kt) + 1) & 1) * G2_STAGE_BYTES;                                       \
+    const bool more = (kt) + 1 < nkt;                                                                 \
+    const bool more2 = (kt) + 2 < nkt;                                                                \
+    /* phase 0: quadrant (0,0) */                                                                     \
+    RB_LOAD_A(cur, 0)                                                                                 \
+    if (more) RB_DMA(3, (kt) + 1);                                                                    \
+    RB_WAIT(more2)                                                                                    \
+    PP_BARRIER();                                                                                     \
+    RB_MFMA(b0cur, 0, 0)                                                                              \
+    PP_BARRIER();                                                                                     \
+    /* phase 1: quadrant (0,1) */                                                                     \
+    RB_LOAD_B(b1, cur, 1)                                                                             \
+    if (more2) RB_DMA(1, (kt) + 2);                                                                   \
+    RB_WAIT(more2)                                                                                    \
+    PP_BARRIER();                                                                                     \
+    RB_MFMA(b1, 0, 1)                                                                                 \
+    PP_BARRIER();                                                                                     \
+    /* phase 2: quadrant (1,1) */                                                                     \
+    RB_LOAD_A(cur, 1)                                                                                 \
+    if (more2) RB_DMA(0, (kt) + 2);                                                                   \
+    RB_WAIT(more2)                                                                                    \
+    PP_BARRIER();                                                                                     \
+    RB_MFMA(b1, 1, 1)                                                                                 \
+    PP_BARRIER();                                                                                     \
+    /* phase 3: quadrant (1,0); reads the next tile's B(nh0) */                                       \
+    if (more) RB_LOAD_B(b0nxt, nxt, 0)                                                                \
+    if (more2) RB_DMA(2, (kt) + 2);                                                                   \
+    RB_WAIT(more2)                                                                                    \
+    PP_BARRIER();                                                                                     \
+    RB_MFMA(b0cur, 1, 0)                                                                              \
+    PP_BARRIER();                                                                                     \
+  }
+
+  // ---- prologue: all of tile 0, then R0B, R0A, R1 of tile 1 (steady-state issue order)
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) RB_DMA(reg, 0);
+  if (nkt > 1) {
+    RB_DMA(1, 1);
+    RB_DMA(0, 1);
+    RB_DMA(2, 1);
+    PP_WAIT_VM(6);
+  } else {
+    PP_WAIT_VM(0);
+  }
+  PP_BARRIER();
+  RB_LOAD_B(b0x, smem, 0)
+  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
+
+  for (int kt = 0; kt < nkt; kt += 2) {
+    RB_TILE(kt, b0x, b0y)
+    if (kt + 1 < nkt) RB_TILE(kt + 1, b0y, b0x)
+  }
+  if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
+#undef RB_DMA
+#undef RB_LOAD_A
+#undef RB_LOAD_B
+#undef RB_MFMA
+#undef RB_WAIT
+#undef RB_TILE
 
   const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
 #pragma unroll
@@ -505,7 +758,23 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
                       RopeArgs rope, hipStream_t st) {
   LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
   const int nwg = ((M + 255) / 256) * (N / 256);
-  if (variant == 3) {
+  if (variant == 4) {
+    static bool attr_set4 = false;
+    if (!attr_set4) {
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256rb_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
+      attr_set4 = true;
+    }
+    hipLaunchKernelGGL(gemm256rb_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
+                       G2_GROUP_M, rope);
+    LR_CHECK_LAUNCH("gemm256rb_kernel");
+  } else if (variant == 9) {  // diagnostic stamps (timing perturbed by the stamps themselves; read shares, not totals)
+    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
+    hipLaunchKernelGGL((gemm256pp_kernel<EPI, true>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N,
+                       K, G2_GROUP_M, rope);
+    LR_CHECK_LAUNCH("gemm256pp_kernel<stamp>");
+  } else if (variant == 3) {
     static bool attr_set3 = false;
     if (!attr_set3) {
       LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI>),
@@ -544,12 +813,12 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
-  if (variant == 0) variant = (fast_ok && M >= 128) ? 3 : 1;
+  if (variant == 0) variant = (fast_ok && M >= 128) ? 4 : 1;
   if (variant >= 2 && !fast_ok)
     LR_FAIL(LR_EUNSUPPORTED, "gemm variant 2/3 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  if (variant < 1 || variant > 3) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
+  if ((variant < 1 || variant > 4) && variant != 9) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
   RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols};
   if (epi == LR_EPI_ROPE) {
     if (!tok_pos || !rope_cs || head_dim < 2 || head_dim % 4 != 0 || rot_cols % 4 != 0 || rot_cols > N)
@@ -562,4 +831,11 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
     case LR_EPI_ROPE: return launch_epi<LR_EPI_ROPE>(A, B, C, R, M, N, K, variant, rope, st);
   }
   LR_FAIL(LR_EINVAL, "gemm: unknown epilogue %d", epi);
+}
+
+// debug: copy the stamp sums of the last variant-9 launch to the host (16 per (workgroup, group))
+extern "C" int lr_debug_gemm_stamps(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > 8 * 2 * 24) LR_FAIL(LR_EINVAL, "lr_debug_gemm_stamps: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
 }

@@ -55,6 +55,7 @@ def assert_bf16_close(got, ref32, what, absum=None):
     (256, 256, 64, 2), (300, 512, 256, 2), (1, 256, 128, 2), (1000, 256, 4096, 2), (515, 768, 704, 2),
     (300, 512, 256, 0), (300, 512, 256, 3), (1000, 256, 4096, 3), (515, 768, 704, 3), (1, 256, 64, 3),
     (700, 256, 128, 3), (260, 256, 192, 3),
+    (300, 512, 256, 4), (1000, 256, 4096, 4), (515, 768, 704, 4), (1, 256, 64, 4), (700, 256, 128, 4), (260, 256, 192, 4),
 ])
 def test_gemm_vs_numpy(M, N, K, variant):
     A = bf16_round(hash_uniform(M * 7 + K, (M, K), 1.0))
@@ -69,7 +70,7 @@ def test_gemm_fast_equals_generic_on_integers():
     A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)   # asymmetric patterns
     B = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
     ref = A @ B.T
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 4):
         assert np.array_equal(gemm(A, B, v), bf16_round(ref)), v
 
 
