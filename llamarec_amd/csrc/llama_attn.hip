@@ -225,22 +225,22 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       const bool diag = (kb * FA_KB + FA_KB - 1) > (qb * FA_QROWS + wave * 32);  // block needs masking
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
+        // raw-score row maximum (the scale is positive, so max commutes with it)
         float mx = -__builtin_inff();
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float t = st[qt][nt][r] * sl2;
             if (diag) {
               const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
-              t = (key <= qabs[qt]) ? t : -__builtin_inff();
+              st[qt][nt][r] = (key <= qabs[qt]) ? st[qt][nt][r] : -__builtin_inff();
             }
-            st[qt][nt][r] = t;
-            mx = fmaxf(mx, t);
+            mx = fmaxf(mx, st[qt][nt][r]);
           }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[qt], mx);
+        const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
+        const bool grew = m_new > m_run[qt];
         const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
         m_run[qt] = m_new;
         float ps = 0.f;
@@ -248,15 +248,18 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(st[qt][nt][r] - m_new);
+            // exp2(s*scale*log2e - m): one fma + one exp per score
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][nt][r], sl2, -m_new));
             ps += p;
             pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
           }
         l_run[qt] = l_run[qt] * alpha + ps;
+        if (__any(grew)) {  // rescale O only when some row's maximum moved (alpha == 1 otherwise)
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
+          for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
+            for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
+        }
       }
 
       // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads

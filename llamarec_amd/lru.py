@@ -180,6 +180,8 @@ class LRURec:
         ids = self._ids(x)
         B, L = ids.shape
         q = torch.empty((B, 64), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return q
         with torch.cuda.device(self.device):
             check(lib().lr_lru_encode_last(self._h, ids.data_ptr(), B, L, q.data_ptr(), None, 0,
                                            stream_ptr()), "lr_lru_encode_last")
@@ -189,6 +191,8 @@ class LRURec:
         ids = self._ids(x)
         B, L = ids.shape
         out = torch.empty((B, self.num_items + 1), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return out
         ws = self._workspace(B, 1)
         with torch.cuda.device(self.device):
             check(lib().lr_lru_scores_last(self._h, ids.data_ptr(), B, L, int(bool(exclude_history)),
@@ -206,6 +210,8 @@ class LRURec:
         B, L = ids.shape
         idx = torch.empty((B, k), dtype=torch.int32, device=self.device)
         sc = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return idx, sc
         ws = self._workspace(B, k)
         with torch.cuda.device(self.device):
             check(lib().lr_lru_retrieve_topk(self._h, ids.data_ptr(), B, L, k, int(bool(exclude_history)),
