@@ -89,8 +89,9 @@ int lr_lru_create(const void* packed_dev, size_t packed_bytes, int32_t num_items
 void lr_lru_destroy(lr_lru_t* h);
 
 /* Workspace (device) bytes needed by lr_lru_retrieve_topk / lr_lru_scores_last for up to
- * max_users histories per call. */
-size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k);
+ * max_users histories of up to max_len ids per call (q rows, per-chunk partial top-K lists,
+ * sorted history ids for the mask). */
+size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k, int32_t max_len);
 
 /* Encode B histories and return the hidden state of the LAST position, q[B][64] (fp32).
  * Replaces LRURec.forward up to (not including) the item GEMM, last position only

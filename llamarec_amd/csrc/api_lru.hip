@@ -95,11 +95,12 @@ extern "C" void lr_lru_destroy(lr_lru_t* h) { free(h); }
 
 static size_t q_bytes(int B) { return lr_align_up((size_t)B * 64 * sizeof(float), 256); }
 
-extern "C" size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k) {
+extern "C" size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k, int32_t max_len) {
   (void)h;
   if (max_users < 1) max_users = 1;
   if (max_k < 1) max_k = 1;
-  return q_bytes(max_users) + lr_topk_workspace_bytes(max_users, max_k);
+  if (max_len < 1) max_len = 1;
+  return q_bytes(max_users) + lr_topk_workspace_bytes(max_users, max_k, max_len);
 }
 
 static int check_ids(const char* fn, const lr_lru_t* h, const void* ids, int B, int L) {

@@ -50,6 +50,7 @@ __device__ __forceinline__ void proj_64_to_256(const float* __restrict__ wt, flo
                                                const float (*in)[64], int tid, float* acc) {
 #pragma unroll
   for (int t = 0; t < TT; ++t) acc[t] = bias;
+#pragma unroll 4
   for (int k = 0; k < 64; k += 4) {
     float w0 = wt[(k + 0) * 256 + tid], w1 = wt[(k + 1) * 256 + tid];
     float w2 = wt[(k + 2) * 256 + tid], w3 = wt[(k + 3) * 256 + tid];
@@ -70,6 +71,7 @@ __device__ __forceinline__ void proj_256_to_64(const float* __restrict__ wt, flo
                                                float* acc) {
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) acc[tt] = bias;
+#pragma unroll 8
   for (int k = 0; k < 256; k += 4) {
     float w0 = wt[(k + 0) * 64 + lane], w1 = wt[(k + 1) * 64 + lane];
     float w2 = wt[(k + 2) * 64 + lane], w3 = wt[(k + 3) * 64 + lane];

@@ -8,17 +8,21 @@
 // Structure
 //  * grid = (item chunks, 128-user tiles). A workgroup = 4 wave64; wave w owns 32 users whose
 //    q rows live in registers as the MFMA B operand; all 4 waves share each 32-item tile of the
-//    table, staged global -> LDS with coalesced 16-byte loads (row stride 68 floats: the
-//    ds_read_b128 fragment reads are bank-conflict free).
+//    table, staged global -> registers -> LDS with coalesced 16-byte loads, two tiles ahead (row
+//    stride 68 floats: the ds_read_b128 fragment reads are bank-conflict free).
 //  * scores of a 32x32 (item x user) tile = 32 chained v_mfma_f32_32x32x2_f32 (exact f32,
 //    k-ordered fma chain: lane-half 0 feeds k = s, lane-half 1 feeds k = 32+s, so the sum order
 //    is lr_item_score()'s and the result is bit-identical to the CPU oracle).
-//  * each lane then holds 16 item scores of ONE user; a score enters the user's LDS candidate
-//    buffer only if its 64-bit rank key beats the user's current K-th key (threshold), so after
-//    warm-up almost nothing is inserted. The history / pad-id test (-> -1e9) is evaluated only
-//    for scores that pass the threshold. When a buffer could overflow the wave rank-selects it
-//    back to its best K (which also tightens the threshold).
+//  * history / pad masking: a pre-pass sorts every user's history ids (hist_sort_kernel); while
+//    the item tiles advance in id order each user walks a pointer through its sorted history and
+//    builds a 32-bit mask of the tile's masked items -- two instructions per score, no scans.
+//  * each lane holds 16 item scores of ONE user; a score enters the user's LDS candidate buffer
+//    only if it beats the user's current K-th best (a float pre-test, then the exact 64-bit rank
+//    key), so after warm-up almost nothing is inserted. When a buffer could overflow, the wave
+//    finds that user's exact K-th key by counting quickselect (ballots, ~10 rounds) and compacts.
 //  * per-chunk sorted partial lists are merged by a second tiny kernel (one wave per user).
+#include <limits.h>
+
 #include "lr_common.h"
 #include "lr_profile.h"
 
@@ -27,8 +31,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define TK_WAVES 4
 #define TK_USERS 128      // users per workgroup
 #define TK_CAP 112        // candidate slots per user (K <= 64 kept + insertion slack)
-#define TK_ESTRIDE 68     // floats per staged table row (64 + 4 pad)
 #define TK_MAX_CHUNKS 256
+#define TK_MAX_WGS 1024   // chunks are added only while user tiles x chunks stays below this
 
 struct TopkParams {
   const float* emb;   // [rows_padded][64]
@@ -36,48 +40,98 @@ struct TopkParams {
   int n_rows;         // V + 1
   int n_tiles;        // rows_padded / 32
   const float* q;     // [B][64]
-  const int64_t* ids; // [B][L]
+  const int32_t* hist_sorted;  // [B][L] ascending (INT_MAX = ignored entry), null if !exclude
   int B, L, K, exclude;
   int tiles_per_chunk, n_chunks;
   unsigned long long* partial;  // [B][n_chunks][K] rank keys, best first, 0 = empty
 };
 
-__device__ __forceinline__ bool in_history(const int64_t* row, int L, int item) {
-  bool hit = false;
-  for (int t = 0; t < L; ++t) hit |= (row[t] == (int64_t)item);
-  return hit;
+// ---- pre-pass: ascending sort of each user's history ids (LDS bitonic sort, one WG per user) ----
+__global__ __launch_bounds__(256) void hist_sort_kernel(const int64_t* ids, int L, int Lp, int n_rows,
+                                                        int32_t* out) {
+  extern __shared__ int32_t sk[];
+  const int u = blockIdx.x;
+  for (int i = threadIdx.x; i < Lp; i += 256) {
+    long long v = i < L ? ids[(size_t)u * L + i] : -1;
+    sk[i] = (v >= 0 && v < n_rows) ? (int32_t)v : INT_MAX;
+  }
+  __syncthreads();
+  for (int k = 2; k <= Lp; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < Lp; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const int a = sk[i], b = sk[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < L; i += 256) out[(size_t)u * L + i] = sk[i];
 }
 
-// Wave-cooperative: keep the best min(c,K) keys of b[0..c) sorted best-first in b[0..), and
-// return the K-th best key (0 if c < K). All 64 lanes must call it with wave-uniform arguments.
-__device__ __forceinline__ unsigned long long compact_user(unsigned long long* b, int c, int K,
-                                                           int lane) {
-  unsigned long long k0 = lane < c ? b[lane] : 0ull;
-  unsigned long long k1 = lane + 64 < c ? b[lane + 64] : 0ull;
-  int r0 = 0, r1 = 0;
-  for (int m = 0; m < c; ++m) {
-    unsigned long long km = b[m];
-    r0 += (km > k0) ? 1 : 0;
-    r1 += (km > k1) ? 1 : 0;
+// ---- wave-cooperative helpers on one user's candidate buffer ---------------------------------
+// Exact K-th largest key of b[0..c) (c > K, keys unique) by counting quickselect, then keep the K
+// keys >= it (unsorted) in b[0..K). Returns the K-th key. Wave-uniform arguments.
+__device__ __forceinline__ unsigned long long shrink_user(unsigned long long* b, int c, int K, int lane) {
+  const unsigned long long k0 = lane < c ? b[lane] : 0ull;
+  const unsigned long long k1 = lane + 64 < c ? b[lane + 64] : 0ull;
+  unsigned long long lo = 0ull, hi = ~0ull, kth = 0ull;
+  for (int it = 0; it < 2 * TK_CAP; ++it) {
+    const unsigned long long m0 = __ballot(k0 > lo && k0 < hi);
+    const unsigned long long m1 = __ballot(k1 > lo && k1 < hi);
+    unsigned long long pivot;
+    if (m0) pivot = __shfl(k0, __ffsll((long long)m0) - 1, 64);
+    else pivot = __shfl(k1, __ffsll((long long)m1) - 1, 64);
+    const int g = __popcll(__ballot(k0 > pivot)) + __popcll(__ballot(k1 > pivot));
+    if (g == K - 1) {
+      kth = pivot;
+      break;
+    }
+    if (g > K - 1) lo = pivot;  // the K-th largest is above the pivot
+    else hi = pivot;
   }
+  const bool keep0 = k0 >= kth && k0 != 0ull, keep1 = k1 >= kth && k1 != 0ull;
+  const unsigned long long mk0 = __ballot(keep0), mk1 = __ballot(keep1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int pos0 = __popcll(mk0 & lt), pos1 = __popcll(mk0) + __popcll(mk1 & lt);
   __builtin_amdgcn_wave_barrier();
-  if (lane < c && r0 < K) b[r0] = k0;
-  if (lane + 64 < c && r1 < K) b[r1] = k1;
+  if (keep0) b[pos0] = k0;
+  if (keep1) b[pos1] = k1;
   __builtin_amdgcn_wave_barrier();
-  unsigned long long kth = 0ull;
-  if (c >= K) kth = b[K - 1];  // same-wave LDS ops are ordered: this read sees the writes above
   return kth;
 }
+
+// Sort b[0..c), c <= 64, best first (rank = number of larger keys).
+__device__ __forceinline__ void sort_small(unsigned long long* b, int c, int lane) {
+  const unsigned long long k0 = lane < c ? b[lane] : 0ull;
+  int r0 = 0;
+  for (int m = 0; m < c; ++m) r0 += (b[m] > k0) ? 1 : 0;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < c) b[r0] = k0;
+  __builtin_amdgcn_wave_barrier();
+}
+
+#define TK_ESTRIDE 68  // floats per staged table row (64 + 4 pad: conflict-free ds_read_b128 fragments)
+
+// Table tiles are staged global -> VGPR -> LDS (an LDS-DMA ring was tried, but with ds_write / LDS
+// atomics in the same loop hipcc drains vmcnt(0) in front of every fragment read).
 
 __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* etile = reinterpret_cast<float*>(smem);                      // [2][32*68]
   float* btile = etile + 2 * 32 * TK_ESTRIDE;                         // [2][32]
   unsigned long long* buf = reinterpret_cast<unsigned long long*>(btile + 64);  // [128][CAP]
-  unsigned long long* thr = buf + TK_USERS * TK_CAP;                  // [128]
-  int* cnt = reinterpret_cast<int*>(thr + TK_USERS);                  // [128]
+  unsigned long long* thr = buf + TK_USERS * TK_CAP;                           // [128]
+  int* cnt = reinterpret_cast<int*>(thr + TK_USERS);                           // [128]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
   const int chunk = blockIdx.x;
   const int u_local = wave * 32 + col;
@@ -104,34 +158,62 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
     cnt[tid] = 0;
     thr[tid] = 0ull;
   }
-  const int64_t* hist = p.ids + (size_t)(user_ok ? user : 0) * p.L;
-
-  // staging assignment: 512 float4 per tile, thread handles float4 #tid and #tid+256
-  float4 pre0, pre1;
-  float preb = 0.f;
-  auto load_tile = [&](int tile) {
-    const float4* src = reinterpret_cast<const float4*>(p.emb + (size_t)tile * 32 * 64);
-    pre0 = src[tid];
-    pre1 = src[tid + 256];
-    if (tid < 32) preb = p.bias[tile * 32 + tid];
-  };
-  auto store_tile = [&](int bufi) {
-    float* e = etile + bufi * 32 * TK_ESTRIDE;
-    int i0 = tid, i1 = tid + 256;
-    *reinterpret_cast<float4*>(e + (i0 >> 4) * TK_ESTRIDE + (i0 & 15) * 4) = pre0;
-    *reinterpret_cast<float4*>(e + (i1 >> 4) * TK_ESTRIDE + (i1 & 15) * 4) = pre1;
-    if (tid < 32) btile[bufi * 32 + tid] = preb;
-  };
-
-  if (tile_begin < tile_end) {
-    load_tile(tile_begin);
-    store_tile(0);
+  // sorted-history cursor of this lane's user (kept by the half-0 lane): first entry >= chunk start
+  const bool walker = p.exclude && half == 0 && user_ok;
+  const int32_t* hs = p.hist_sorted + (size_t)(user_ok ? user : 0) * p.L;
+  int hptr = 0;
+  if (walker) {
+    int lo = 0, hi = p.L;
+    const int first_item = tile_begin * 32;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (hs[mid] < first_item) lo = mid + 1;
+      else hi = mid;
+    }
+    hptr = lo;
   }
+  // next history id at or after the cursor, kept in a register so that a tile without history
+  // items costs one compare (no dependent global load per tile)
+  int hnext = (walker && hptr < p.L) ? hs[hptr] : INT_MAX;
+  // staging: 512 float4 per tile, thread handles float4 #tid and #tid+256. FOUR tiles are in flight in
+  // registers (32 KiB per workgroup: the table streams from HBM / Infinity Cache with ~3 us latency when
+  // every CU pulls a different chunk), one is in LDS being multiplied. Tile t lives in register set
+  // (t - tile_begin) & 3; the tile loop is unrolled by 4 so the set index is a compile-time constant.
+  float4 e0[4], e1[4];
+  float bb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    e1[i] = e0[i];
+    bb[i] = 0.f;
+  }
+#define TK_LOAD(set_, tile_)                                                                  \
+  do {                                                                                        \
+    const float4* src_ = reinterpret_cast<const float4*>(p.emb + (size_t)(tile_)*32 * 64);    \
+    e0[set_] = src_[tid];                                                                     \
+    e1[set_] = src_[tid + 256];                                                               \
+    bb[set_] = (tid < 32) ? p.bias[(tile_)*32 + tid] : 0.f;                                   \
+  } while (0)
+#define TK_STORE(set_, bufi_)                                                                       \
+  do {                                                                                              \
+    float* e_ = etile + (bufi_)*32 * TK_ESTRIDE;                                                    \
+    *reinterpret_cast<float4*>(e_ + (tid >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e0[set_];           \
+    *reinterpret_cast<float4*>(e_ + ((tid + 256) >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e1[set_];   \
+    if (tid < 32) btile[(bufi_)*32 + tid] = bb[set_];                                               \
+  } while (0)
+  if (tile_begin < tile_end) {
+    TK_LOAD(0, tile_begin);
+    TK_STORE(0, 0);
+  }
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (tile_begin + i < tile_end) TK_LOAD(i, tile_begin + i);
   __syncthreads();
 
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
+  // body of one tile; `su` = (tile - tile_begin) & 3 is a constant after unrolling
+  auto do_tile = [&](int tile, const int su) {
     const int cur = (tile - tile_begin) & 1;
-    if (tile + 1 < tile_end) load_tile(tile + 1);
+    if (tile + 4 < tile_end) TK_LOAD(su, tile + 4);  // set `su` was emptied into LDS one tile ago
 
     // A fragments: item row `col`, k = 32*half + s
     float a[32];
@@ -146,43 +228,78 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
         a[4 * j + 3] = v.w;
       }
     }
+    // threshold and bias of my 16 rows (rows 8g + 4*half + 0..3 = one aligned float4 per g), fetched
+    // before the MFMA chain so their LDS latency is hidden
+    const unsigned long long th = thr[u_local];
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bias4[g] = *reinterpret_cast<const float4*>(btile + cur * 32 + 8 * g + 4 * half);
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], acc, 0, 0, 0);
 
-    // lane now holds, for its user `col`, the scores of items row(r) = (r&3) + 8*(r>>2) + 4*half
-    const unsigned long long th = thr[u_local];
-    const float* bt = btile + cur * 32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int item = tile * 32 + row;
-      const float sc = acc[r] + bt[row];
-      unsigned long long key = lr_rank_key(sc, (uint32_t)item);
-      bool cand = user_ok && item < p.n_rows && key > th;
-      if (cand && p.exclude) {
-        if (item == 0 || in_history(hist, p.L, item)) {
-          key = lr_rank_key(LR_MASK_SCORE, (uint32_t)item);
-          cand = key > th;
+    // which of this tile's 32 items are masked for my user (history ids and the pad id 0)
+    unsigned hmask = 0u;
+    if (p.exclude) {
+      if (walker) {
+        const int t0 = tile * 32, t1 = t0 + 32;
+        while (hnext < t1) {
+          hmask |= 1u << (hnext - t0);
+          ++hptr;
+          hnext = hptr < p.L ? hs[hptr] : INT_MAX;
         }
+        if (tile == 0) hmask |= 1u;
       }
-      if (cand) {
-        int pos = atomicAdd(&cnt[u_local], 1);
-        buf[u_local * TK_CAP + pos] = key;
+      hmask = __shfl(hmask, col, 64);  // the half-0 lane of the user tells its half-1 twin
+    }
+
+    // lane holds, for its user `col`, the scores of items row(r) = (r&3) + 8*(r>>2) + 4*half.
+    // Two passes: (1) scores + mask + float pre-test for all 16 registers with no LDS traffic inside
+    // (bias fetched as 4 x b128 beforehand); (2) the rare survivors take the exact-key path.
+    float sc[16];
+    unsigned pass = 0u;
+    {
+      const float thf = th ? lr_key_score(th) : -__builtin_inff();
+      const bool tail = (tile + 1) * 32 > p.n_rows;  // only the last tile can hold rows past V
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float4 b4 = bias4[r >> 2];
+        float v = acc[r] + ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w);
+        if ((hmask >> row) & 1u) v = LR_MASK_SCORE;
+        sc[r] = v;
+        bool ok = v >= thf;
+        if (tail) ok = ok && (tile * 32 + row < p.n_rows);
+        pass |= ok ? (1u << r) : 0u;
+      }
+      if (!user_ok) pass = 0u;
+    }
+    if (__any(pass != 0u)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((pass >> r) & 1u) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const unsigned long long key = lr_rank_key(sc[r], (uint32_t)(tile * 32 + row));
+          if (key > th) {
+            const int pos = atomicAdd(&cnt[u_local], 1);
+            buf[u_local * TK_CAP + pos] = key;
+          }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
     // keep room for the next tile (at most 32 insertions per user per tile)
     {
-      int c = cnt[u_local];
+      const int c = cnt[u_local];
       if (__any(c > TK_CAP - 32)) {
         for (int uu = 0; uu < 32; ++uu) {
-          int ul = wave * 32 + uu;
-          int cu = cnt[ul];  // wave-uniform (broadcast read)
-          if (cu > K) {
-            unsigned long long kth = compact_user(buf + ul * TK_CAP, cu, K, lane);
+          const int ul = wave * 32 + uu;
+          const int cu = cnt[ul];  // wave-uniform (broadcast read)
+          if (cu > TK_CAP - 32) {
+            const unsigned long long kth = shrink_user(buf + ul * TK_CAP, cu, K, lane);
             if (lane == 0) {
               cnt[ul] = K;
               thr[ul] = kth;
@@ -192,20 +309,30 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (tile + 1 < tile_end) store_tile(cur ^ 1);
+    if (tile + 1 < tile_end) TK_STORE((su + 1) & 3, cur ^ 1);
     __syncthreads();
+  };
+  for (int base = tile_begin; base < tile_end; base += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + u < tile_end) do_tile(base + u, u);
   }
+#undef TK_LOAD
+#undef TK_STORE
 
-  // final: sort every user's buffer and emit the chunk's partial list
+  // final: best K of every user's buffer, sorted, as the chunk's partial list
   for (int uu = 0; uu < 32; ++uu) {
-    int ul = wave * 32 + uu;
-    int gu = blockIdx.y * TK_USERS + ul;
+    const int ul = wave * 32 + uu;
+    const int gu = blockIdx.y * TK_USERS + ul;
     if (gu >= p.B) break;  // wave-uniform
     int cu = cnt[ul];
-    compact_user(buf + ul * TK_CAP, cu, K, lane);
-    int keep = min(cu, K);
+    if (cu > K) {
+      shrink_user(buf + ul * TK_CAP, cu, K, lane);
+      cu = K;
+    }
+    sort_small(buf + ul * TK_CAP, cu, lane);
     unsigned long long* dst = p.partial + ((size_t)gu * p.n_chunks + chunk) * K;
-    for (int j = lane; j < K; j += 64) dst[j] = j < keep ? buf[ul * TK_CAP + j] : 0ull;
+    for (int j = lane; j < K; j += 64) dst[j] = j < cu ? buf[ul * TK_CAP + j] : 0ull;
   }
 }
 
@@ -231,6 +358,14 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeParams p) {
   const int user = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (user >= p.B) return;
   const unsigned long long* base = p.partial + (size_t)user * p.n_chunks * p.K;
+  if (p.n_chunks == 1) {  // already sorted: just unpack
+    for (int j = lane; j < p.K; j += 64) {
+      const unsigned long long m = base[j];
+      p.out_idx[(size_t)user * p.K + j] = m ? (int32_t)lr_key_item(m) : -1;
+      if (p.out_score) p.out_score[(size_t)user * p.K + j] = m ? lr_key_score(m) : -__builtin_inff();
+    }
+    return;
+  }
   int ptr[4];
   unsigned long long hk[4];
 #pragma unroll
@@ -282,24 +417,39 @@ __global__ void mask_history_kernel(float* scores, int n_rows, const int64_t* id
   if (threadIdx.x == 0) scores[(size_t)user * n_rows] = LR_MASK_SCORE;
 }
 
+// Split the item tiles into chunks so that (user tiles x chunks) fills the 256 CUs in whole rounds:
+// minimise rounds x (tiles per chunk + the per-chunk finalisation, ~8 tile-times).
 static void topk_geometry(int n_tiles, int B, int* n_chunks, int* tiles_per_chunk) {
-  int n_ut = (B + TK_USERS - 1) / TK_USERS;
-  int want = (512 + n_ut - 1) / n_ut;
-  if (want > TK_MAX_CHUNKS) want = TK_MAX_CHUNKS;
-  if (want > n_tiles) want = n_tiles;
-  if (want < 1) want = 1;
-  int tpc = (n_tiles + want - 1) / want;
-  *tiles_per_chunk = tpc;
-  *n_chunks = (n_tiles + tpc - 1) / tpc;
+  const int n_ut = (B + TK_USERS - 1) / TK_USERS;
+  int max_chunks = TK_MAX_WGS / n_ut;
+  if (max_chunks > TK_MAX_CHUNKS) max_chunks = TK_MAX_CHUNKS;
+  if (max_chunks > n_tiles) max_chunks = n_tiles;
+  if (max_chunks < 1) max_chunks = 1;
+  long best_cost = -1;
+  int best = 1;
+  for (int c = 1; c <= max_chunks; ++c) {
+    const int tpc = (n_tiles + c - 1) / c;
+    const int real = (n_tiles + tpc - 1) / tpc;
+    const long rounds = ((long)n_ut * real + 255) / 256;
+    const long cost = rounds * (tpc + 8);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  *tiles_per_chunk = (n_tiles + best - 1) / best;
+  *n_chunks = (n_tiles + *tiles_per_chunk - 1) / *tiles_per_chunk;
 }
 
-size_t lr_topk_workspace_bytes(int B, int K) {
-  // worst case over catalog sizes: n_chunks <= min(256, ceil(512 / user tiles))
-  int n_ut = (B + TK_USERS - 1) / TK_USERS;
-  if (n_ut < 1) n_ut = 1;
-  int want = (512 + n_ut - 1) / n_ut;
-  if (want > TK_MAX_CHUNKS) want = TK_MAX_CHUNKS;
-  return lr_align_up((size_t)B * want * K * sizeof(unsigned long long), 256);
+static size_t partial_bytes_max(int B, int K) {
+  // user tiles x chunks <= TK_MAX_WGS (+ one chunk minimum) => B x chunks <= max(B, 128 * TK_MAX_WGS)
+  size_t rows = (size_t)B;
+  if (rows < (size_t)TK_USERS * TK_MAX_WGS) rows = (size_t)TK_USERS * TK_MAX_WGS;
+  return lr_align_up(rows * K * sizeof(unsigned long long), 256);
+}
+
+size_t lr_topk_workspace_bytes(int B, int K, int L) {
+  return partial_bytes_max(B, K) + lr_align_up((size_t)B * (L > 0 ? L : 1) * sizeof(int32_t), 256);
 }
 
 int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int B, int L, int K,
@@ -312,16 +462,28 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
   p.n_rows = h->lay.num_items + 1;
   p.n_tiles = h->lay.rows_padded / LR_ITEM_TILE;
   p.q = q;
-  p.ids = ids;
   p.B = B;
   p.L = L;
   p.K = K;
-  p.exclude = exclude_history;
+  p.exclude = exclude_history ? 1 : 0;
   topk_geometry(p.n_tiles, B, &p.n_chunks, &p.tiles_per_chunk);
-  size_t need = (size_t)B * p.n_chunks * K * sizeof(unsigned long long);
-  if (need > ws_bytes) LR_FAIL(LR_EWORKSPACE, "top-K workspace: need %zu bytes, have %zu", need, ws_bytes);
+  const size_t need_partial = lr_align_up((size_t)B * p.n_chunks * K * sizeof(unsigned long long), 256);
+  const size_t need_hist = p.exclude ? lr_align_up((size_t)B * L * sizeof(int32_t), 256) : 0;
+  if (need_partial + need_hist > ws_bytes)
+    LR_FAIL(LR_EWORKSPACE, "top-K workspace: need %zu bytes, have %zu", need_partial + need_hist, ws_bytes);
   p.partial = reinterpret_cast<unsigned long long*>(ws);
+  int32_t* hist_sorted = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + need_partial);
+  p.hist_sorted = p.exclude ? hist_sorted : nullptr;
 
+  LrProfScope prof(LR_PROF_ITEM_TOPK, 2.0 * 64 * (double)p.n_rows * B, st);
+  if (p.exclude) {
+    int Lp = 2;
+    while (Lp < L) Lp <<= 1;
+    if (Lp > 8192) LR_FAIL(LR_EUNSUPPORTED, "history length %d > 8192 is not supported by the mask pre-pass", L);
+    hipLaunchKernelGGL(hist_sort_kernel, dim3(B), dim3(256), (size_t)Lp * sizeof(int32_t), st, ids, L, Lp, p.n_rows,
+                       hist_sorted);
+    LR_CHECK_LAUNCH("hist_sort_kernel");
+  }
   const size_t lds = (2 * 32 * TK_ESTRIDE + 64) * sizeof(float) +
                      (size_t)TK_USERS * TK_CAP * 8 + TK_USERS * 8 + TK_USERS * 4;
   static bool attr_set = false;
@@ -331,7 +493,6 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     attr_set = true;
   }
   dim3 grid(p.n_chunks, (B + TK_USERS - 1) / TK_USERS);
-  LrProfScope prof(LR_PROF_ITEM_TOPK, 2.0 * 64 * (double)p.n_rows * B, st);
   hipLaunchKernelGGL(item_topk_kernel, grid, dim3(256), lds, st, p);
   LR_CHECK_LAUNCH("item_topk_kernel");
 

@@ -162,8 +162,8 @@ class LRURec:
             pass
 
     # -- helpers -----------------------------------------------------------------------------
-    def _workspace(self, B, K):
-        need = lib().lr_lru_workspace_bytes(self._h, B, K)
+    def _workspace(self, B, K, L=1):
+        need = lib().lr_lru_workspace_bytes(self._h, B, K, L)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -212,7 +212,7 @@ class LRURec:
         sc = torch.empty((B, k), dtype=torch.float32, device=self.device)
         if B == 0:
             return idx, sc
-        ws = self._workspace(B, k)
+        ws = self._workspace(B, k, L)
         with torch.cuda.device(self.device):
             check(lib().lr_lru_retrieve_topk(self._h, ids.data_ptr(), B, L, k, int(bool(exclude_history)),
                                              idx.data_ptr(), sc.data_ptr(), ws.data_ptr(), ws.numel(),

@@ -75,6 +75,7 @@ def test_abi_error_codes(lru):
     ids = torch.ones((2, 5), dtype=torch.int64, device="cuda")
     out = torch.empty((2, 5), dtype=torch.int32, device="cuda")
     ws = torch.empty(16, dtype=torch.uint8, device="cuda")  # far too small
+    assert l.lr_lru_workspace_bytes(model._h, 2, 5, 5) > 16
     rc = l.lr_lru_retrieve_topk(model._h, ids.data_ptr(), 2, 5, 5, 1, out.data_ptr(), None, ws.data_ptr(), 16, stream_ptr())
     assert rc == -4 and b"workspace" in l.lr_last_error()
     rc = l.lr_lru_retrieve_topk(model._h, ids.data_ptr(), 2, 5, 99, 1, out.data_ptr(), None, ws.data_ptr(), 16, stream_ptr())
