@@ -59,6 +59,15 @@ def cpu_baseline(workload, hist_ids, T_sample, lru_sd):
     from oracle import lru_oracle as O
 
     cores = len(os.sched_getaffinity(0))
+    try:  # threads the numpy BLAS actually uses for the stage-2 GEMMs (the dominant part)
+        from threadpoolctl import threadpool_info
+
+        blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
+        if blas:
+            cores = min(cores, max(blas))
+    except Exception:
+        pass
+    omp_threads = O.num_threads()
     orc = O.LruOracle(lru_sd)
     t0 = time.perf_counter()
     orc.retrieve_topk(hist_ids, 50, True)
@@ -81,7 +90,7 @@ def cpu_baseline(workload, hist_ids, T_sample, lru_sd):
     s2_per_user = t2 / len(seqs) * (32 / 2)
     return {
         "value": 1.0 / (s1_per_user + s2_per_user), "unit": "users/s", "cores": cores, "kind": "port",
-        "sample": (f"stage 1: C oracle (OpenMP) over {len(hist_ids)} {workload} users = {t1:.2f} s; stage 2: numpy "
+        "sample": (f"stage 1: C oracle ({omp_threads} OpenMP threads) over {len(hist_ids)} {workload} users = {t1:.2f} s; stage 2: numpy "
                    f"oracle, {len(seqs)} users (T={[int(t) for t in T_sample]}) x 2 of 32 Llama-2-7b layers "
                    f"= {t2:.2f} s, extrapolated x16"),
         "stage1_users_per_s": 1.0 / s1_per_user, "stage2_users_per_s_extrapolated": 1.0 / s2_per_user,
