@@ -22,15 +22,18 @@
 //    finds that user's exact K-th key by counting quickselect (ballots, ~10 rounds) and compacts.
 //  * per-chunk sorted partial lists are merged by a second tiny kernel (one wave per user).
 #include <limits.h>
+#include <stdlib.h>
 
 #include "lr_common.h"
 #include "lr_profile.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define TK_WAVES 4
 #define TK_USERS 128      // users per workgroup
-#define TK_CAP 112        // candidate slots per user (K <= 64 kept + insertion slack)
+#define TK_CAP 128        // candidate slots per user (K <= 64 kept + insertion slack)
+#define TK_BSTRIDE 129    // slot stride between users (odd: lanes of different users hit different banks)
 #define TK_MAX_CHUNKS 256
 #define TK_MAX_WGS 1024   // chunks are added only while user tiles x chunks stays below this
 
@@ -76,34 +79,48 @@ __global__ __launch_bounds__(256) void hist_sort_kernel(const int64_t* ids, int 
 }
 
 // ---- wave-cooperative helpers on one user's candidate buffer ---------------------------------
-// Exact K-th largest key of b[0..c) (c > K, keys unique) by counting quickselect, then keep the K
-// keys >= it (unsorted) in b[0..K). Returns the K-th key. Wave-uniform arguments.
-__device__ __forceinline__ unsigned long long shrink_user(unsigned long long* b, int c, int K, int lane) {
-  const unsigned long long k0 = lane < c ? b[lane] : 0ull;
-  const unsigned long long k1 = lane + 64 < c ? b[lane + 64] : 0ull;
-  unsigned long long lo = 0ull, hi = ~0ull, kth = 0ull;
-  for (int it = 0; it < 2 * TK_CAP; ++it) {
-    const unsigned long long m0 = __ballot(k0 > lo && k0 < hi);
-    const unsigned long long m1 = __ballot(k1 > lo && k1 < hi);
-    unsigned long long pivot;
-    if (m0) pivot = __shfl(k0, __ffsll((long long)m0) - 1, 64);
-    else pivot = __shfl(k1, __ffsll((long long)m1) - 1, 64);
-    const int g = __popcll(__ballot(k0 > pivot)) + __popcll(__ballot(k1 > pivot));
-    if (g == K - 1) {
-      kth = pivot;
-      break;
+// A user's candidates live in two lane-private lists (one per MFMA lane half, appended without
+// atomics): b[0..c0) and b[64..64+c1), keys unique and non-zero. Keep the best min(c0+c1, K): the exact
+// K-th largest key comes from a counting quickselect over ballots. split = true deals the survivors
+// back to the two lists (the first (n+1)/2 to list 0), otherwise they are stored from b[0] on.
+// Returns the K-th key (0 while fewer than K candidates exist: no threshold yet); *n_out = survivors.
+// Wave-uniform arguments.
+__device__ __forceinline__ unsigned long long compact_user(unsigned long long* b, int c0, int c1, int K, int lane,
+                                                           bool split, int* n_out) {
+  const unsigned long long k0 = lane < c0 ? b[lane] : 0ull;
+  const unsigned long long k1 = lane < c1 ? b[64 + lane] : 0ull;
+  unsigned long long kth = 0ull;
+  if (c0 + c1 >= K) {
+    unsigned long long lo = 0ull, hi = ~0ull;
+    for (int it = 0; it < 2 * TK_CAP; ++it) {
+      const unsigned long long m0 = __ballot(k0 > lo && k0 < hi);
+      const unsigned long long m1 = __ballot(k1 > lo && k1 < hi);
+      // pivot = first live key (v_readlane with a uniform lane index; no LDS round trip)
+      const unsigned long long src = m0 ? k0 : k1;
+      const int pl = __ffsll((long long)(m0 ? m0 : m1)) - 1;
+      const unsigned long long pivot =
+          ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(src >> 32), pl) << 32) |
+          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)src, pl);
+      const int g = __popcll(__ballot(k0 > pivot)) + __popcll(__ballot(k1 > pivot));
+      if (g == K - 1) {
+        kth = pivot;
+        break;
+      }
+      if (g > K - 1) lo = pivot;  // the K-th largest is above the pivot
+      else hi = pivot;
     }
-    if (g > K - 1) lo = pivot;  // the K-th largest is above the pivot
-    else hi = pivot;
   }
   const bool keep0 = k0 >= kth && k0 != 0ull, keep1 = k1 >= kth && k1 != 0ull;
   const unsigned long long mk0 = __ballot(keep0), mk1 = __ballot(keep1);
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const int pos0 = __popcll(mk0 & lt), pos1 = __popcll(mk0) + __popcll(mk1 & lt);
+  const int n = __popcll(mk0) + __popcll(mk1);
+  const int n0 = split ? (n + 1) >> 1 : n;
+  const int g0 = __popcll(mk0 & lt), g1 = __popcll(mk0) + __popcll(mk1 & lt);
   __builtin_amdgcn_wave_barrier();
-  if (keep0) b[pos0] = k0;
-  if (keep1) b[pos1] = k1;
+  if (keep0) b[g0 < n0 ? g0 : 64 + g0 - n0] = k0;
+  if (keep1) b[g1 < n0 ? g1 : 64 + g1 - n0] = k1;
   __builtin_amdgcn_wave_barrier();
+  *n_out = n;
   return kth;
 }
 
@@ -122,13 +139,26 @@ __device__ __forceinline__ void sort_small(unsigned long long* b, int c, int lan
 // Table tiles are staged global -> VGPR -> LDS (an LDS-DMA ring was tried, but with ds_write / LDS
 // atomics in the same loop hipcc drains vmcnt(0) in front of every fragment read).
 
+// Diagnostic stamps (STAMP = true only under LR_TOPK_STAMPS=1, never in the product path): s_memtime
+// deltas of the tile loop's segments, summed over the loop, for wave 0 of the first 16 workgroups.
+__device__ unsigned long long g_topk_stamps[16 * 8];
+#define TK_STAMP(slot)                                                         \
+  if (STAMP) {                                                                 \
+    unsigned long long t_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    stamp_acc[(slot)] += t_ - t_prev;                                          \
+    t_prev = t_;                                                               \
+  }
+
+template <bool STAMP>
 __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* etile = reinterpret_cast<float*>(smem);                      // [2][32*68]
-  float* btile = etile + 2 * 32 * TK_ESTRIDE;                         // [2][32]
-  unsigned long long* buf = reinterpret_cast<unsigned long long*>(btile + 64);  // [128][CAP]
-  unsigned long long* thr = buf + TK_USERS * TK_CAP;                           // [128]
-  int* cnt = reinterpret_cast<int*>(thr + TK_USERS);                           // [128]
+  float* btile = etile + 2 * 32 * TK_ESTRIDE;                         // [4][32]
+  unsigned long long* buf = reinterpret_cast<unsigned long long*>(btile + 128);  // [128][BSTRIDE]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,10 +184,11 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
       bq[4 * j + 3] = v.w;
     }
   }
-  if (tid < TK_USERS) {
-    cnt[tid] = 0;
-    thr[tid] = 0ull;
-  }
+  // candidate list of this lane (its user's list `half`), its fill count, and the user's threshold score
+  // (the K-th best seen at the last compaction; +inf for users past B: nothing ever passes)
+  unsigned long long* mine = buf + u_local * TK_BSTRIDE + half * 64;
+  int pos = 0;
+  float thf = user_ok ? -__builtin_inff() : __builtin_inff();
   // sorted-history cursor of this lane's user (kept by the half-0 lane): first entry >= chunk start
   const bool walker = p.exclude && half == 0 && user_ok;
   const int32_t* hs = p.hist_sorted + (size_t)(user_ok ? user : 0) * p.L;
@@ -172,168 +203,234 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
     }
     hptr = lo;
   }
-  // next history id at or after the cursor, kept in a register so that a tile without history
-  // items costs one compare (no dependent global load per tile)
-  int hnext = (walker && hptr < p.L) ? hs[hptr] : INT_MAX;
-  // staging: 512 float4 per tile, thread handles float4 #tid and #tid+256. FOUR tiles are in flight in
-  // registers (32 KiB per workgroup: the table streams from HBM / Infinity Cache with ~3 us latency when
-  // every CU pulls a different chunk), one is in LDS being multiplied. Tile t lives in register set
-  // (t - tile_begin) & 3; the tile loop is unrolled by 4 so the set index is a compile-time constant.
-  float4 e0[4], e1[4];
+  // the next two history ids at or after the cursor live in registers (h0, h1): a tile without history
+  // items costs one compare, and when h0 is consumed the id after h1 is fetched a hit ahead of its use
+  int h0 = (walker && hptr < p.L) ? hs[hptr] : INT_MAX;
+  int h1 = (walker && hptr + 1 < p.L) ? hs[hptr + 1] : INT_MAX;
+  // staging: 512 float4 per tile, thread handles float4 #tid and #tid+256. Tiles t+2 .. t+5 are in flight in
+  // registers while tile t is multiplied (32 KiB per workgroup: the table streams from HBM / Infinity
+  // Cache with ~3 us latency when every CU pulls a different chunk); tile T lives in register set
+  // (T - tile_begin) & 3, LDS table buffer (T - tile_begin) & 1 and bias slot (T - tile_begin) & 3. The
+  // tile loop is unrolled by 4 so all of these are compile-time constants.
+  // The loads are inline asm with hand-counted s_waitcnt: hipcc's own counter tracking gives up on this
+  // loop (the history walker's load sits in a data-dependent inner loop) and would drain vmcnt(0) before
+  // every LDS store, i.e. expose the full memory latency once per tile. Every wave issues exactly three
+  // loads per tile (table x2, bias), tile indices are clamped instead of guarded, so "all but the newest
+  // 9" is the same for every wave and every iteration.
+  floatx4 e0[4], e1[4];
   float bb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    e0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    e1[i] = e0[i];
-    bb[i] = 0.f;
-  }
-#define TK_LOAD(set_, tile_)                                                                  \
-  do {                                                                                        \
-    const float4* src_ = reinterpret_cast<const float4*>(p.emb + (size_t)(tile_)*32 * 64);    \
-    e0[set_] = src_[tid];                                                                     \
-    e1[set_] = src_[tid + 256];                                                               \
-    bb[set_] = (tid < 32) ? p.bias[(tile_)*32 + tid] : 0.f;                                   \
+  const unsigned voff0 = (unsigned)tid * 16u, voff1 = voff0 + 4096u, voffb = (unsigned)(tid & 31) * 4u;
+#define TK_LOAD(set_, tile_)                                                                          \
+  do {                                                                                                \
+    const int t_ = min((tile_), p.n_tiles - 1);                                                       \
+    const float* se_ = p.emb + (size_t)t_ * 32 * 64;                                                  \
+    const float* sb_ = p.bias + (size_t)t_ * 32;                                                      \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(e0[set_]) : "v"(voff0), "s"(se_) : "memory"); \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(e1[set_]) : "v"(voff1), "s"(se_) : "memory"); \
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(bb[set_]) : "v"(voffb), "s"(sb_) : "memory");   \
   } while (0)
-#define TK_STORE(set_, bufi_)                                                                       \
+#define TK_WAIT_LOADS(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+#define TK_STORE(set_)                                                                              \
   do {                                                                                              \
-    float* e_ = etile + (bufi_)*32 * TK_ESTRIDE;                                                    \
-    *reinterpret_cast<float4*>(e_ + (tid >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e0[set_];           \
-    *reinterpret_cast<float4*>(e_ + ((tid + 256) >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e1[set_];   \
-    if (tid < 32) btile[(bufi_)*32 + tid] = bb[set_];                                               \
+    float* e_ = etile + ((set_)&1) * 32 * TK_ESTRIDE;                                               \
+    *reinterpret_cast<floatx4*>(e_ + (tid >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e0[set_];          \
+    *reinterpret_cast<floatx4*>(e_ + ((tid + 256) >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e1[set_];  \
+    if (tid < 32) btile[(set_)*32 + tid] = bb[set_];                                                \
   } while (0)
-  if (tile_begin < tile_end) {
-    TK_LOAD(0, tile_begin);
-    TK_STORE(0, 0);
-  }
+  // A fragments of the tile in table buffer bufi_: item row `col`, k = 32*half + s
+#define TK_FRAGS(dst_, bufi_)                                                                       \
+  do {                                                                                              \
+    const float* er_ = etile + (bufi_)*32 * TK_ESTRIDE + col * TK_ESTRIDE + 32 * half;              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+      const float4 v_ = *reinterpret_cast<const float4*>(er_ + 4 * j_);                             \
+      dst_[4 * j_ + 0] = v_.x;                                                                      \
+      dst_[4 * j_ + 1] = v_.y;                                                                      \
+      dst_[4 * j_ + 2] = v_.z;                                                                      \
+      dst_[4 * j_ + 3] = v_.w;                                                                      \
+    }                                                                                               \
+  } while (0)
 #pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (tile_begin + i < tile_end) TK_LOAD(i, tile_begin + i);
+  for (int i = 0; i < 4; ++i) TK_LOAD(i, tile_begin + i);
+  TK_WAIT_LOADS(6);
+  TK_STORE(0);
+  TK_STORE(1);
+  TK_LOAD(0, tile_begin + 4);
+  // everything hipcc tracks has landed before the loop, or it re-waits (vmcnt(0)) at the top of every tile
+#pragma unroll
+  for (int j = 0; j < 32; ++j) asm volatile("" ::"v"(bq[j]));
+  asm volatile("" ::"v"(h0), "v"(h1));
   __syncthreads();
+  float afr[2][32];
+  TK_FRAGS(afr[0], 0);
 
-  // body of one tile; `su` = (tile - tile_begin) & 3 is a constant after unrolling
-  auto do_tile = [&](int tile, const int su) {
-    const int cur = (tile - tile_begin) & 1;
-    if (tile + 4 < tile_end) TK_LOAD(su, tile + 4);  // set `su` was emptied into LDS one tile ago
-
-    // A fragments: item row `col`, k = 32*half + s
-    float a[32];
-    {
-      const float* er = etile + cur * 32 * TK_ESTRIDE + col * TK_ESTRIDE + 32 * half;
+  // Software pipeline, three tiles deep. While the 32-MFMA chain of tile t runs (each MFMA depends on
+  // the one before: 64-cycle shadows), the same wave
+  //   * filters tile t-1: one saved score per two MFMAs, interleaved by hand; a score that reaches the
+  //     user's threshold is appended to the lane's own candidate list (no atomics);
+  //   * has tile t+1's A fragments on their way from LDS into the other fragment register set;
+  //   * walks the sorted history for tile t's mask (needed one iteration later).
+  floatx16 accp;  // scores (with bias) of the previous tile
+  unsigned hmaskp = 0u;
+  int tilep = 0;
+  bool prev_ok = false;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float4 v = *reinterpret_cast<const float4*>(er + 4 * j);
-        a[4 * j + 0] = v.x;
-        a[4 * j + 1] = v.y;
-        a[4 * j + 2] = v.z;
-        a[4 * j + 3] = v.w;
-      }
+  for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+
+#define TK_ELEM(r, thv, SLOW)                                                                           \
+  {                                                                                                     \
+    const int row_ = ((r)&3) + 8 * ((r) >> 2) + 4 * half;                                               \
+    float v_ = accp[r];                                                                                 \
+    bool ok_;                                                                                           \
+    if (SLOW) {                                                                                         \
+      if ((hmaskp >> row_) & 1u) v_ = LR_MASK_SCORE;                                                    \
+      ok_ = v_ >= (thv) && (tilep * 32 + row_ < p.n_rows);                                              \
+    } else {                                                                                            \
+      ok_ = v_ >= (thv);                                                                                \
+    }                                                                                                   \
+    if (STAMP) stamp_acc[7] += __popcll(__ballot(ok_));                                                 \
+    if (ok_) {                                                                                          \
+      mine[pos] = lr_rank_key(v_, (uint32_t)(tilep * 32 + row_));                                       \
+      ++pos;                                                                                            \
+    }                                                                                                   \
+  }
+  // after a tile's inserts: compact every user whose list could overflow on the next tile (a lane
+  // appends <= 16 keys per tile and a list holds 64), which also refreshes the user's threshold
+  auto make_room = [&]() {
+    const unsigned long long need = __ballot(pos > 48);
+    if (need) {
+      unsigned m = (unsigned)need | (unsigned)(need >> 32);
+      do {
+        const int uu = __ffs(m) - 1;  // wave-uniform
+        m &= m - 1u;
+        const int c0 = __builtin_amdgcn_readlane(pos, uu), c1 = __builtin_amdgcn_readlane(pos, uu + 32);
+        int n;
+        if (STAMP) stamp_acc[6] += 1;
+        const unsigned long long kth = compact_user(buf + (wave * 32 + uu) * TK_BSTRIDE, c0, c1, K, lane, true, &n);
+        if (col == uu) {
+          pos = half ? n - ((n + 1) >> 1) : (n + 1) >> 1;
+          if (kth) thf = lr_key_score(kth);
+        }
+      } while (m);
     }
-    // threshold and bias of my 16 rows (rows 8g + 4*half + 0..3 = one aligned float4 per g), fetched
-    // before the MFMA chain so their LDS latency is hidden
-    const unsigned long long th = thr[u_local];
-    float4 bias4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      bias4[g] = *reinterpret_cast<const float4*>(btile + cur * 32 + 8 * g + 4 * half);
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], acc, 0, 0, 0);
-
-    // which of this tile's 32 items are masked for my user (history ids and the pad id 0)
+  };
+  // which of `tile`'s 32 items are masked for my user (history ids and the pad id 0). Called late in the
+  // MFMA chain, see the note on the wait below.
+  auto walk = [&](int tile) -> unsigned {
     unsigned hmask = 0u;
     if (p.exclude) {
       if (walker) {
         const int t0 = tile * 32, t1 = t0 + 32;
-        while (hnext < t1) {
-          hmask |= 1u << (hnext - t0);
+        while (h0 < t1) {
+          hmask |= 1u << (h0 - t0);
+          h0 = h1;
           ++hptr;
-          hnext = hptr < p.L ? hs[hptr] : INT_MAX;
+          h1 = hptr + 1 < p.L ? hs[hptr + 1] : INT_MAX;
         }
         if (tile == 0) hmask |= 1u;
       }
+      // pin hipcc's wait for the look-ahead load HERE (late in the tile: the table loads issued at the top of
+      // the tile have had ~2000 cycles); left alone it waits where it next copies h1 -- at the top of the next
+      // tile, right behind the freshly issued table loads
+      asm volatile("" ::"v"(h1));
       hmask = __shfl(hmask, col, 64);  // the half-0 lane of the user tells its half-1 twin
     }
-
-    // lane holds, for its user `col`, the scores of items row(r) = (r&3) + 8*(r>>2) + 4*half.
-    // Two passes: (1) scores + mask + float pre-test for all 16 registers with no LDS traffic inside
-    // (bias fetched as 4 x b128 beforehand); (2) the rare survivors take the exact-key path.
-    float sc[16];
-    unsigned pass = 0u;
-    {
-      const float thf = th ? lr_key_score(th) : -__builtin_inff();
-      const bool tail = (tile + 1) * 32 > p.n_rows;  // only the last tile can hold rows past V
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float4 b4 = bias4[r >> 2];
-        float v = acc[r] + ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w);
-        if ((hmask >> row) & 1u) v = LR_MASK_SCORE;
-        sc[r] = v;
-        bool ok = v >= thf;
-        if (tail) ok = ok && (tile * 32 + row < p.n_rows);
-        pass |= ok ? (1u << r) : 0u;
-      }
-      if (!user_ok) pass = 0u;
-    }
-    if (__any(pass != 0u)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if ((pass >> r) & 1u) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const unsigned long long key = lr_rank_key(sc[r], (uint32_t)(tile * 32 + row));
-          if (key > th) {
-            const int pos = atomicAdd(&cnt[u_local], 1);
-            buf[u_local * TK_CAP + pos] = key;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // keep room for the next tile (at most 32 insertions per user per tile)
-    {
-      const int c = cnt[u_local];
-      if (__any(c > TK_CAP - 32)) {
-        for (int uu = 0; uu < 32; ++uu) {
-          const int ul = wave * 32 + uu;
-          const int cu = cnt[ul];  // wave-uniform (broadcast read)
-          if (cu > TK_CAP - 32) {
-            const unsigned long long kth = shrink_user(buf + ul * TK_CAP, cu, K, lane);
-            if (lane == 0) {
-              cnt[ul] = K;
-              thr[ul] = kth;
-            }
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    if (tile + 1 < tile_end) TK_STORE((su + 1) & 3, cur ^ 1);
-    __syncthreads();
+    return hmask;
   };
+
+  // body of one tile; `su` = (tile - tile_begin) & 3 is a constant after unrolling
+  auto do_tile = [&](int tile, const int su) {
+    TK_LOAD((su + 1) & 3, tile + 5);  // that set went to LDS one tile ago
+    if (tile + 1 < tile_end) TK_FRAGS(afr[(su + 1) & 1], (su + 1) & 1);
+    // this tile's bias rows (rows 8g + 4*half + 0..3 = one aligned float4 per g), added when the scores are saved
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bias4[g] = *reinterpret_cast<const float4*>(btile + su * 32 + 8 * g + 4 * half);
+    TK_STAMP(0)
+
+    const float thv = prev_ok ? thf : __builtin_inff();
+    const bool slow = __any(hmaskp != 0u) || (tilep + 1) * 32 > p.n_rows;  // masks or rows past V: rare
+    unsigned hmaskn = 0u;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    if (!slow) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r], bq[2 * r], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r + 1], bq[2 * r + 1], acc, 0, 0, 0);
+        TK_ELEM(r, thv, false)
+        if (r == 15) hmaskn = walk(tile);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r], bq[2 * r], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r + 1], bq[2 * r + 1], acc, 0, 0, 0);
+        TK_ELEM(r, thv, true)
+        if (r == 15) hmaskn = walk(tile);
+      }
+    }
+    if (STAMP) asm volatile("" ::"v"(acc));
+    TK_STAMP(2)
+    make_room();
+    TK_STAMP(3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 b4 = bias4[r >> 2];
+      accp[r] = acc[r] + ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w);
+    }
+    hmaskp = hmaskn;
+    tilep = tile;
+    prev_ok = true;
+    TK_WAIT_LOADS(9);  // tile + 2 has landed; tiles + 3, + 4, + 5 may still be in flight
+    TK_STORE((su + 2) & 3);
+    TK_STAMP(4)
+    __syncthreads();
+    TK_STAMP(5)
+  };
+  if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   for (int base = tile_begin; base < tile_end; base += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (base + u < tile_end) do_tile(base + u, u);
   }
+  if (prev_ok) {  // drain the pipeline: the last tile's scores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) TK_ELEM(r, thf, true)
+  }
+#undef TK_ELEM
 #undef TK_LOAD
 #undef TK_STORE
+#undef TK_FRAGS
+#undef TK_WAIT_LOADS
 
-  // final: best K of every user's buffer, sorted, as the chunk's partial list
+  // final: best K of every user's two lists, sorted, as the chunk's partial list
+  __builtin_amdgcn_wave_barrier();
   for (int uu = 0; uu < 32; ++uu) {
     const int ul = wave * 32 + uu;
     const int gu = blockIdx.y * TK_USERS + ul;
     if (gu >= p.B) break;  // wave-uniform
-    int cu = cnt[ul];
-    if (cu > K) {
-      shrink_user(buf + ul * TK_CAP, cu, K, lane);
-      cu = K;
-    }
-    sort_small(buf + ul * TK_CAP, cu, lane);
+    const int c0 = __builtin_amdgcn_readlane(pos, uu), c1 = __builtin_amdgcn_readlane(pos, uu + 32);
+    int cu;
+    compact_user(buf + ul * TK_BSTRIDE, c0, c1, K, lane, false, &cu);
+    sort_small(buf + ul * TK_BSTRIDE, cu, lane);
     unsigned long long* dst = p.partial + ((size_t)gu * p.n_chunks + chunk) * K;
-    for (int j = lane; j < K; j += 64) dst[j] = j < cu ? buf[ul * TK_CAP + j] : 0ull;
+    for (int j = lane; j < K; j += 64) dst[j] = j < cu ? buf[ul * TK_BSTRIDE + j] : 0ull;
   }
+  if (STAMP) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 16 && tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g_topk_stamps[wg * 8 + i] = stamp_acc[i];
+    }
+  }
+}
+
+extern "C" int lr_debug_topk_stamps(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > 16 * 8) LR_FAIL(LR_EINVAL, "lr_debug_topk_stamps: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_topk_stamps), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
 }
 
 // ---- merge: one wave per user, K rounds of "largest head wins" over <= 256 sorted lists -----
@@ -484,16 +581,22 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
                        hist_sorted);
     LR_CHECK_LAUNCH("hist_sort_kernel");
   }
-  const size_t lds = (2 * 32 * TK_ESTRIDE + 64) * sizeof(float) +
-                     (size_t)TK_USERS * TK_CAP * 8 + TK_USERS * 8 + TK_USERS * 4;
+  const size_t lds = (2 * 32 * TK_ESTRIDE + 128) * sizeof(float) +
+                     (size_t)TK_USERS * TK_BSTRIDE * 8;
   static bool attr_set = false;
+  static bool stamps = false;
   if (!attr_set) {
-    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(item_topk_kernel),
+    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(item_topk_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(item_topk_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const char* e = getenv("LR_TOPK_STAMPS");
+    stamps = e && e[0] == '1';
     attr_set = true;
   }
   dim3 grid(p.n_chunks, (B + TK_USERS - 1) / TK_USERS);
-  hipLaunchKernelGGL(item_topk_kernel, grid, dim3(256), lds, st, p);
+  if (stamps) hipLaunchKernelGGL(item_topk_kernel<true>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(item_topk_kernel<false>, grid, dim3(256), lds, st, p);
   LR_CHECK_LAUNCH("item_topk_kernel");
 
   MergeParams m;
