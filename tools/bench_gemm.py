@@ -1,7 +1,7 @@
 """A/B the bf16 GEMM variants on the Llama-2-7b prefill shapes (interleaved rounds, one process)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd._lib import check, lib, stream_ptr
 
 def run(variants, M=14800, rounds=5, check_equal=True):

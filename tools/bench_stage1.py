@@ -2,7 +2,7 @@
 bit-exactness spot check against the CPU oracle on a sample."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd.lru import LRURec, init_lru_state_dict
 from llamarec_amd.synth import WORKLOADS, synth_users
 from oracle import lru_oracle as O

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from tests.test_gpu_llama import gemm
 from llamarec_amd.synth import bf16_round, hash_uniform
 for (M,N,K) in [(1000,256,4096),(1024,256,4096),(768,256,4096),(1000,512,4096),(1000,256,2048)]:

@@ -1,7 +1,7 @@
 """Diagnostic: where do the ping-pong GEMM's phases spend their cycles (s_memtime stamps, variant 9)."""
 import ctypes as C, sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd._lib import check, lib, stream_ptr
 M, N, K = 14800, 12288, 4096
 g = torch.Generator(device="cuda"); g.manual_seed(0)

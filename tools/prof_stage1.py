@@ -1,12 +1,15 @@
 import sys, ctypes as C
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd.lru import LRURec, init_lru_state_dict
 from llamarec_amd.synth import WORKLOADS, synth_users
 from llamarec_amd import _lib
 lib = _lib.lib()
 EXCL = "--no-exclude" not in sys.argv
+ONLY = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
 for name, U in (("beauty", 22332), ("synth-1m", 4096), ("ml-100k", 610)):
+    if ONLY and name not in ONLY:
+        continue
     w = WORKLOADS[name]
     hist, labels, n, T = synth_users(name, U)
     model = LRURec.from_state_dict(init_lru_state_dict(w["V"], seed=42))

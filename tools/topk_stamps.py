@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 os.environ["LR_TOPK_STAMPS"] = "1"
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd.lru import LRURec, init_lru_state_dict
 from llamarec_amd.synth import WORKLOADS, synth_users
 from llamarec_amd._lib import check, lib
