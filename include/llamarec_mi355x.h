@@ -195,9 +195,13 @@ typedef struct lr_llama lr_llama_t;
 int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_llama_t** out);
 void lr_llama_destroy(lr_llama_t* h);
 
-/* Kernel selection for parity tests: 0 = auto (default), 1 = generic kernels, 2 = the MFMA
- * 256x256x64 GEMM / head_dim-128 flash attention, gemm 3 / 4 = ping-pong pipelined 256x256x64 GEMMs
- * (an error if a shape does not fit). */
+/* Kernel selection: 0 = auto (default), 1 = generic kernels, 2 = the MFMA 256x256x64 GEMM /
+ * head_dim-128 flash attention, gemm 3 / 4 = ping-pong pipelined 256x256x64 GEMMs (an error if a
+ * shape does not fit). gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
+ * variant 4 plus split-K wherever the output tiles alone would leave most CUs idle (a 460-token prompt
+ * gives o_proj / down_proj 32 tiles for 256 CUs); shapes that do not fit fall back as in auto. The
+ * split-K summation order depends on the token count, so unlike the default a prompt's scores are
+ * then reproducible only for the same packed batch size (bf16-level differences otherwise). */
 int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant);
 
 /* Last-layer pruning (default ON): after the final layer only each prompt's last token is consumed
@@ -246,6 +250,10 @@ int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inte
  * N%256==0, K%64==0, M>=128; any M: rows are bounds-checked). */
 int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
                     int32_t K, int32_t variant, void* hip_stream);
+/* The same with a device workspace for variant 5 (split-K, see lr_llama_set_variants): fp32 partial
+ * planes, at most 64 MiB (8 splits x M x N x 4 bytes, splits x tiles <= 256). */
+int lr_gemm_bf16_nt_ws(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
+                       int32_t K, int32_t variant, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Stand-alone varlen causal attention (exposed for parity tests):
  * qkv: DEVICE bf16 [total][(nh+2*nkv)*hd] (RoPE already applied; any consistent permutation of the

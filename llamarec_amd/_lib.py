@@ -55,6 +55,8 @@ PROTOTYPES = {
                                     C.c_void_p]),
     "lr_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "lr_gemm_bf16_nt_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_attention_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }

@@ -39,7 +39,7 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
 }
 
 extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
-  if (!h || gemm_variant < 0 || gemm_variant > 4 || attention_variant < 0 || attention_variant > 2)
+  if (!h || gemm_variant < 0 || gemm_variant > 5 || attention_variant < 0 || attention_variant > 2)
     LR_FAIL(LR_EINVAL, "lr_llama_set_variants: bad argument");
   h->gemm_variant = gemm_variant;
   h->attn_variant = attention_variant;
@@ -63,6 +63,7 @@ struct LlamaWs {
   float* rope;
   u16 *x, *xn, *qkv, *att, *hmid;
   u16 *x_last, *xn_last, *att_last, *h_last;  // compact [B][.] buffers of the pruned last layer
+  float* splitk;                              // fp32 partial planes of the split-K GEMMs (gemm variant 5)
   bool compact;                               // ws.x_last (not ws.x) holds the final residual rows
   size_t total;
 };
@@ -92,6 +93,7 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.xn_last = (u16*)take(nb * c.hidden_size * 2);
   w.att_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
   w.h_last = (u16*)take(nb * c.intermediate_size * 2);
+  w.splitk = (float*)take(LR_SPLITK_WS_BYTES);
   w.total = o;
   return w;
 }
@@ -140,7 +142,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
     // QKV projection with the rotary embedding applied in the epilogue (q/k rows pair-interleaved)
     RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
-                       ws.rope, hd, (nh + nkv) * hd));
+                       ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES));
     if (l == c.num_layers - 1 && h->prune_last) {
       // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
       // last layer needs K/V for every token but attention output, o_proj, and the MLP for B rows only.
@@ -155,10 +157,13 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     }
     RUN(lr_launch_attention(ws.qkv, ws.att, cu, cu_host, ws.tok_pos, ws.tok_seq, B, n, nh, nkv, hd,
                             h->attn_variant, nullptr, st));
-    RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st));
+    RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0,
+                       0, ws.splitk, LR_SPLITK_WS_BYTES));
     RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
-    RUN(lr_launch_gemm(ws.xn, w.wgu, ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st));
-    RUN(lr_launch_gemm(ws.hmid, w.wdown, ws.x, ws.x, n, d, f, LR_EPI_RESIDUAL, h->gemm_variant, st));
+    RUN(lr_launch_gemm(ws.xn, w.wgu, ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr, nullptr,
+                       0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
+    RUN(lr_launch_gemm(ws.hmid, w.wdown, ws.x, ws.x, n, d, f, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0, 0,
+                       ws.splitk, LR_SPLITK_WS_BYTES));
   }
 #undef RUN
   *out_ws = ws;
@@ -225,6 +230,14 @@ extern "C" int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C
                                int32_t K, int32_t variant, void* hip_stream) {
   if (!A || !B || !C) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt: null pointer");
   return lr_launch_gemm(A, B, C, nullptr, M, N, K, LR_EPI_STORE, variant, (hipStream_t)hip_stream);
+}
+
+extern "C" int lr_gemm_bf16_nt_ws(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
+                                  int32_t K, int32_t variant, void* workspace, size_t workspace_bytes,
+                                  void* hip_stream) {
+  if (!A || !B || !C) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_ws: null pointer");
+  return lr_launch_gemm(A, B, C, nullptr, M, N, K, LR_EPI_STORE, variant, (hipStream_t)hip_stream, nullptr, nullptr, 0,
+                        0, (float*)workspace, workspace_bytes);
 }
 
 extern "C" int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,

@@ -47,6 +47,10 @@ template <int EPI>
 __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off,
                                            const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0) {
   u16x4 o;
+  if (EPI == LR_EPI_PARTIAL) {  // C is the fp32 partial plane of this split
+    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(C) + off) = v;
+    return;
+  }
   if (EPI == LR_EPI_ROPE) {
     float x[4];
 #pragma unroll
@@ -562,6 +566,9 @@ __global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ 
 // Hazards: a region is overwritten only after both wave groups retired their reads of it (issue at
 // LOAD_{p+2} for reads of LOAD_p: two barriers later for either group); every wait is followed by a
 // barrier that each reader passes before its read.
+// Split-K (EPI == LR_EPI_PARTIAL): blockIdx.y = split s works on K tiles [s*T/S, (s+1)*T/S) and stores its
+// fp32 partial plane at ((float*)C)[s][M][N]; splitk_reduce_kernel sums the planes in order and applies the
+// real epilogue.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ A,
                                                         const u16* __restrict__ B, u16* C,
@@ -571,6 +578,13 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  int kt_first = 0, nkt = K >> 6;
+  if (EPI == LR_EPI_PARTIAL) {
+    const int s = blockIdx.y, S = gridDim.y, T = K >> 6;
+    kt_first = (int)((long long)s * T / S);
+    nkt = (int)((long long)(s + 1) * T / S) - kt_first;
+    C = reinterpret_cast<u16*>(reinterpret_cast<float*>(C) + (size_t)s * M * N);
+  }
 
   const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
   const int nwg = tilesM * tilesN;
@@ -610,10 +624,10 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
       const int chunk = spos ^ ((row >> 1) & 7);
       if (isA[t]) {
         const int arow = min(m0 + row, M - 1);
-        src[t][j] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
+        src[t][j] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16 + (size_t)kt_first * 128;
         ldsoff[t][j] = rows[t] * 128;
       } else {
-        src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
+        src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16 + (size_t)kt_first * 128;
         ldsoff[t][j] = 32768 + rows[t] * 128;
       }
     }
@@ -639,7 +653,6 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = K >> 6;
   bf16x8 afr[8], b0x[4], b0y[4], b1[4];
 
 #define RB_LOAD_A(buf, mh)                                                                            \
@@ -753,6 +766,69 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 }
 
 // =============================================================================================
+// split-K reduce: sum the S fp32 partial planes in split order, then the real epilogue
+// =============================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, u16* C,
+                                                            const u16* R, int M, int N, RopeArgs rope) {
+  const size_t plane = (size_t)M * N;
+  if (EPI == LR_EPI_SWIGLU) {
+    // output column c of N/2: gate column (c/16)*32 + c%16, up column 16 further (16-row interleave of wgu)
+    const int n_out = N >> 1;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (size_t)M * n_out) return;
+    const int row = (int)(i / n_out), c = (int)(i % n_out);
+    const size_t g_off = (size_t)row * N + (c >> 4) * 32 + (c & 15);
+    floatx4 g = *reinterpret_cast<const floatx4*>(part + g_off);
+    floatx4 u = *reinterpret_cast<const floatx4*>(part + g_off + 16);
+    for (int s = 1; s < S; ++s) {
+      g += *reinterpret_cast<const floatx4*>(part + s * plane + g_off);
+      u += *reinterpret_cast<const floatx4*>(part + s * plane + g_off + 16);
+    }
+    epi_store4<EPI>(g, u, C, R, (size_t)row * n_out + c);
+  } else {
+    const size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (off >= plane) return;
+    floatx4 v = *reinterpret_cast<const floatx4*>(part + off);
+    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const floatx4*>(part + s * plane + off);
+    epi_store4<EPI>(v, v, C, R, off, rope, (int)(off / N), (int)(off % N));
+  }
+}
+
+// number of K splits for an M x N x K product on 256 x 256 tiles (1 = do not split): split only when the
+// tiles alone leave at least half of the 256 CUs idle, keep >= 16 K tiles per split, <= 8 splits
+static int splitk_factor(int M, int N, int K) {
+  const int tiles = ((M + 255) / 256) * (N / 256);
+  if (tiles > 128) return 1;
+  int S = 256 / tiles;
+  if (S > 8) S = 8;
+  const int by_k = (K >> 6) / 16;
+  if (S > by_k) S = by_k;
+  return S < 2 ? 1 : S;
+}
+
+template <int EPI>
+static int launch_splitk(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int S, RopeArgs rope,
+                         float* ws, hipStream_t st) {
+  LrProfScope prof(LR_PROF_GEMM256, 2.0 * M * (double)N * K, st);
+  static bool attr_set = false;
+  if (!attr_set) {
+    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256rb_kernel<LR_EPI_PARTIAL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
+    attr_set = true;
+  }
+  const int nwg = ((M + 255) / 256) * (N / 256);
+  hipLaunchKernelGGL(gemm256rb_kernel<LR_EPI_PARTIAL>, dim3(nwg, S), dim3(512), 2 * G2_STAGE_BYTES, st, A, B,
+                     reinterpret_cast<u16*>(ws), nullptr, M, N, K, G2_GROUP_M, rope);
+  LR_CHECK_LAUNCH("gemm256rb_kernel<partial>");
+  const size_t quads = (EPI == LR_EPI_SWIGLU ? (size_t)M * (N >> 1) : (size_t)M * N) / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, ws, S, C, R, M,
+                     N, rope);
+  LR_CHECK_LAUNCH("splitk_reduce_kernel");
+  return LR_OK;
+}
+
+// =============================================================================================
 template <int EPI>
 static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
                       RopeArgs rope, hipStream_t st) {
@@ -809,20 +885,37 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
 
 int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
                    int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs, int head_dim,
-                   int rot_cols) {
+                   int rot_cols, float* splitk_ws, size_t splitk_ws_bytes) {
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
   if (variant == 0) variant = (fast_ok && M >= 128) ? 4 : 1;
+  if (variant == 5 && !(fast_ok && M >= 128)) variant = 1;  // latency mode falls back like auto does
   if (variant >= 2 && !fast_ok)
-    LR_FAIL(LR_EUNSUPPORTED, "gemm variant 2/3 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
+    LR_FAIL(LR_EUNSUPPORTED, "gemm variants 2..5 need N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  if ((variant < 1 || variant > 4) && variant != 9) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
+  if ((variant < 1 || variant > 5) && variant != 9) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
   RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols};
   if (epi == LR_EPI_ROPE) {
     if (!tok_pos || !rope_cs || head_dim < 2 || head_dim % 4 != 0 || rot_cols % 4 != 0 || rot_cols > N)
       LR_FAIL(LR_EINVAL, "rope epilogue: bad arguments (head_dim=%d rot_cols=%d)", head_dim, rot_cols);
+  }
+  if (variant == 5) {
+    const int S = splitk_factor(M, N, K);
+    if (S >= 2) {
+      if (!splitk_ws || (size_t)S * M * N * sizeof(float) > splitk_ws_bytes)
+        LR_FAIL(LR_EWORKSPACE, "gemm variant 5: split-K x%d of %dx%d needs %zu workspace bytes, have %zu", S, M, N,
+                (size_t)S * M * N * sizeof(float), splitk_ws ? splitk_ws_bytes : (size_t)0);
+      switch (epi) {
+        case LR_EPI_STORE: return launch_splitk<LR_EPI_STORE>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
+        case LR_EPI_RESIDUAL: return launch_splitk<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
+        case LR_EPI_SWIGLU: return launch_splitk<LR_EPI_SWIGLU>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
+        case LR_EPI_ROPE: return launch_splitk<LR_EPI_ROPE>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
+      }
+      LR_FAIL(LR_EINVAL, "gemm: unknown epilogue %d", epi);
+    }
+    variant = 4;
   }
   switch (epi) {
     case LR_EPI_STORE: return launch_epi<LR_EPI_STORE>(A, B, C, R, M, N, K, variant, rope, st);

@@ -23,6 +23,8 @@ __device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
 #define LR_EPI_RESIDUAL 1  // C = bf16( bf16(acc) + R )      (R may alias C)
 #define LR_EPI_SWIGLU 2    // C[M][N/2] = swiglu over interleaved gate/up 16-column groups
 #define LR_EPI_ROPE 3      // C = bf16(acc) with rotary embedding on the pair-interleaved q/k columns
+#define LR_EPI_PARTIAL 4   // internal (split-K): fp32 partial sums to the workspace, real epilogue in the reduce pass
+#define LR_SPLITK_WS_BYTES ((size_t)64 << 20)  // splits x tiles <= 256 tiles of 256 x 256 fp32
 
 int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, int32_t* last_rows,
                          hipStream_t st);
@@ -39,11 +41,12 @@ int lr_launch_head(const unsigned short* x, const int32_t* cu, const unsigned sh
                    const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
                    float* out, hipStream_t st);
 
-// C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 2 256x256x64 MFMA tile.
+// C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 2..4 256x256x64 MFMA tile,
+// 5 = variant 4 with split-K when the tiles alone would leave most CUs idle (needs splitk_ws).
 int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned short* C,
                    const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st,
                    const int32_t* tok_pos = nullptr, const float* rope_cs = nullptr, int head_dim = 0,
-                   int rot_cols = 0);
+                   int rot_cols = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
 
 // varlen causal attention over packed qkv (RoPE applied). variant: 0 auto, 1 generic, 2 MFMA hd=128.
 int lr_launch_attention(const unsigned short* qkv, unsigned short* out, const int32_t* cu,

@@ -212,6 +212,8 @@ class LlamaRanker:
         self._h, self._layers_arr = h, arr
 
     def set_variants(self, gemm=0, attention=0):
+        """Kernel selection (include/llamarec_mi355x.h): 0 = auto; gemm=5 = latency mode for the online
+        single-user path (split-K where a short prompt would leave most CUs idle)."""
         check(lib().lr_llama_set_variants(self._h, gemm, attention), "lr_llama_set_variants")
         return self
 

@@ -39,6 +39,21 @@ def gemm(A, B, variant):
     return host_f32(c)
 
 
+def gemm_ws(A, B, variant, ws_bytes=64 << 20):
+    """lr_gemm_bf16_nt_ws: the same product with a device workspace (split-K, variant 5)."""
+    from llamarec_amd._lib import check, lib, stream_ptr
+
+    M, K = A.shape
+    N = B.shape[0]
+    a, b = dev_bf16(A), dev_bf16(B)
+    c = torch.full((M, N), 0x7FC0, dtype=torch.int16, device="cuda")  # NaN poison
+    ws = torch.full((max(ws_bytes, 4) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib().lr_gemm_bf16_nt_ws(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, variant,
+                                  ws.data_ptr() if ws_bytes else None, ws_bytes, stream_ptr())
+    torch.cuda.synchronize()
+    return rc, host_f32(c)
+
+
 def assert_bf16_close(got, ref32, what, absum=None):
     """<= 1 bf16 ulp of the result, plus fp32 accumulation noise where the sum cancels
     (absum = sum_k |a||b| bounds the partial sums)."""
@@ -62,6 +77,34 @@ def test_gemm_vs_numpy(M, N, K, variant):
     B = bf16_round(hash_uniform(N * 13 + K, (N, K), 1.0))
     got = gemm(A, B, variant)
     assert_bf16_close(got, A @ B.T, f"gemm {M}x{N}x{K} v{variant}", np.abs(A) @ np.abs(B).T)
+
+
+@pytest.mark.parametrize("M,N,K", [(460, 512, 4096), (129, 256, 2048), (512, 1024, 11008), (300, 256, 8192),
+                                   (1000, 256, 1024), (460, 512, 1024 + 64)])
+def test_gemm_splitk_latency_mode(M, N, K):
+    """Variant 5 (split-K over fp32 partial planes + reduce pass): same product at bf16 resolution for
+    every split count the policy picks (8, 8, 8, 8, 8->by K, odd K-tile counts), NaN-poisoned workspace."""
+    A = bf16_round(hash_uniform(M * 7 + K, (M, K), 1.0))
+    B = bf16_round(hash_uniform(N * 13 + K, (N, K), 1.0))
+    rc, got = gemm_ws(A, B, 5)
+    assert rc == 0
+    assert_bf16_close(got, A @ B.T, f"split-K gemm {M}x{N}x{K}", np.abs(A) @ np.abs(B).T)
+    # exact on integer data (partial sums are exact in fp32, so any indexing slip shows)
+    Ai = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)
+    Bi = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
+    rc, gi = gemm_ws(Ai, Bi, 5)
+    assert rc == 0 and np.array_equal(gi, bf16_round(Ai @ Bi.T))
+
+
+def test_gemm_splitk_needs_workspace():
+    from llamarec_amd._lib import lib
+
+    A = bf16_round(hash_uniform(1, (300, 4096), 1.0))
+    B = bf16_round(hash_uniform(2, (256, 4096), 1.0))
+    rc, _ = gemm_ws(A, B, 5, ws_bytes=0)
+    assert rc != 0 and b"workspace" in lib().lr_last_error()
+    rc, got = gemm_ws(A[:, :512], B[:, :512], 5, ws_bytes=0)   # 8 K tiles: too short to split -> variant 4
+    assert rc == 0 and np.isfinite(got).all()
 
 
 def test_gemm_fast_equals_generic_on_integers():
@@ -218,6 +261,11 @@ def test_full_width_batch_invariance():
     # generic kernels agree with the MFMA kernels at bf16 resolution on the same weights
     gen = model.set_variants(1, 1).prefill_verbalize(seqs[:3], label_ids)
     assert (gen - full[:3]).abs().max() < 5e-2 * max(1.0, float(full.abs().max()))
+    # latency mode (split-K GEMMs with every fused epilogue: RoPE, residual, SwiGLU) likewise
+    for idxs in ([1], [0, 1, 2, 3], list(range(6))):
+        lat = model.set_variants(5, 0).prefill_verbalize([seqs[i] for i in idxs], label_ids)
+        assert (lat - full[idxs]).abs().max() < 5e-2 * max(1.0, float(full.abs().max()))
+    model.set_variants(0, 0)
 
 
 def test_last_layer_pruning_matches_full_last_layer(golden_dir):
