@@ -275,6 +275,52 @@ int lr_profile_start(int32_t max_records);
 int lr_profile_stop(void);
 int lr_profile_collect(int32_t kind, double* total_ms, double* total_work, int64_t* launches);
 
+/* ===========================================================================================
+ * Retriever training step
+ *   replaces  LRUTrainer.calculate_loss                      trainer/lru.py:20-28
+ *             loss.backward() through model/lru.py:38-175     (torch autograd)
+ *             clip_gradients + AdamW.step                     trainer/base.py:106-112,201-246
+ * One flat fp32 buffer holds every parameter in the reference's state_dict layouts (complex tensors as
+ * interleaved (re, im) pairs = torch.view_as_real); gradients, and Adam's two moments have the same
+ * layout, so a data-parallel job all-reduces ONE buffer between lr_lru_train_loss_grad and
+ * lr_lru_train_apply. The caller owns the state buffer and the workspace (device memory).
+ * =========================================================================================== */
+typedef struct {
+  float weight_decay;   /* 1e-2  config.py:123-124 (applied to names without "bias"/"layer_norm", trainer/base.py:222) */
+  float beta1, beta2;   /* 0.9, 0.999 (torch.optim.AdamW defaults) */
+  float eps;            /* 1e-9  config.py:181 */
+  float max_grad_norm;  /* 5.0   config.py:184 */
+  float dropout;        /* bert_dropout      0.2 config.py:216 (embedding, FFN activation, FFN output) */
+  float attn_dropout;   /* bert_attn_dropout 0.2 config.py:217 (LRU layer output) */
+  uint64_t seed;        /* dropout stream (own counter-based generator: torch's masks cannot be reproduced) */
+} LrLruTrainConfig;
+
+typedef struct lr_lru_train lr_lru_train_t;
+
+/* Bytes of DEVICE memory for parameters + gradients + Adam moments (+ a decay mask and scalars). */
+size_t lr_lru_train_state_bytes(int32_t num_items, int32_t num_blocks);
+/* init: HOST fp32 arrays in the reference's layouts (the same descriptor lr_lru_pack takes). */
+int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrainConfig* cfg, void* state_dev,
+                        size_t state_bytes, lr_lru_train_t** out);
+void lr_lru_train_destroy(lr_lru_train_t* h);
+size_t lr_lru_train_workspace_bytes(const lr_lru_train_t* h, int32_t B, int32_t L);
+/* Forward + backward of one batch: tokens/labels DEVICE int64 [B][L], left-padded with 0, label 0 =
+ * ignored (dataloader/lru.py:119-131). Fills the gradient buffer (zeroed first) and
+ * out_loss[0] = mean CE over labelled positions, out_loss[1] = their count (DEVICE float[2]). */
+int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64_t* labels, int32_t B,
+                           int32_t L, float* out_loss, void* workspace, size_t workspace_bytes,
+                           void* hip_stream);
+/* clip_grad_norm_(max_grad_norm) + one AdamW step at learning rate lr (schedulers live with the caller;
+ * max_grad_norm <= 0 = the configured limit); out_grad_norm (DEVICE float, may be null) receives the
+ * pre-clipping global norm. */
+int lr_lru_train_apply(lr_lru_train_t* h, float lr, float max_grad_norm, float* out_grad_norm,
+                       void* hip_stream);
+/* Device pointers of the flat parameter / gradient buffers and their length in floats. */
+int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_t* count);
+/* Offset and length (floats) of a parameter inside those buffers, by its reference state_dict name,
+ * e.g. "model.lru_blocks.1.lru_layer.in_proj.weight" (complex: 2 floats per element). */
+int lr_lru_train_param_range(const lr_lru_train_t* h, const char* name, size_t* offset, size_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,13 @@ def _as_f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class LrLruTrainConfig(C.Structure):
+    """include/llamarec_mi355x.h: LrLruTrainConfig."""
+    _fields_ = [("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("max_grad_norm", C.c_float), ("dropout", C.c_float), ("attn_dropout", C.c_float),
+                ("seed", C.c_uint64)]
+
+
 def lru_desc_from_state_dict(sd) -> tuple[LrLruWeightsDesc, list]:
     """Build the C weight descriptor from an LRURec state_dict (torch tensors or numpy arrays).
 

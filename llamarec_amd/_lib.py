@@ -39,6 +39,16 @@ PROTOTYPES = {
     "lr_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64)]),
     "lr_metrics_from_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "lr_lru_train_state_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "lr_lru_train_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "lr_lru_train_destroy": (None, [C.c_void_p]),
+    "lr_lru_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "lr_lru_train_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_lru_train_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "lr_lru_train_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t)]),
+    "lr_lru_train_param_range": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lr_llama_create": (C.c_int, [C.POINTER(A.LrLlamaConfig), C.POINTER(A.LrLlamaWeightsDesc),
                                   C.POINTER(C.c_void_p)]),
     "lr_llama_destroy": (None, [C.c_void_p]),

@@ -1,0 +1,904 @@
+// lru_train.hip -- LRURec retriever TRAINING step on gfx950.
+//
+// Replaces (reference): LRUTrainer.calculate_loss trainer/lru.py:20-28 (teacher-forced cross-entropy over
+// all positions, ignore_index = 0) with torch autograd through model/lru.py:38-175, and
+// BaseTrainer's clip_gradients + AdamW step (trainer/base.py:106-112,201-246).
+//
+// Shape of the computation (R = B*L token rows, row-major fp32 everywhere):
+//   forward   embed+LN -> per block { in_proj (gamma folded into the weights) -> diagonal complex scan over time
+//             -> Re(out_proj)+residual+LN -> W1+GELU -> W2+residual+LN } -> item GEMM -> softmax CE
+//   backward  the same chain reversed; all dense products (including the three V-sized ones of the tied
+//             item table: logits, d hidden, d table) run on one strided f32 MFMA GEMM
+//             (v_mfma_f32_32x32x2_f32); the recurrence is a reverse-time scan per (sequence, channel):
+//                 G_t = g_t + m_t conj(lambda) G_{t+1},   d lambda = sum_t m_{t-1} conj(h_{t-1}) G_t
+//   update    global-norm clipping + AdamW over ONE flat parameter buffer (decoupled decay only on the
+//             reference's "decay" group: names without "bias" / "layer_norm").
+// Complex parameters are stored interleaved (re, im) like torch.view_as_real and carry the gradient
+// dL/dRe + i dL/dIm -- exactly what torch autograd leaves in .grad and what AdamW consumes.
+// The recursive-doubling scan of the reference equals the sequential recurrence on left-padded batches
+// (dataloader/lru.py:119-131), pads included: h_t = u_t + m_{t-1} lambda h_{t-1}.
+//
+// This first version is correctness-first: one generic GEMM, simple row kernels, fp32 atomics for the few
+// cross-row reductions (parameter-gradient sums), logits materialised per row chunk (<= 1 GiB).
+#include <math.h>
+#include <string.h>
+
+#include "lr_common.h"
+#include "lr_profile.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// =============================================================================================
+// flat parameter layout (floats)
+// =============================================================================================
+struct TrBlockOff {
+  size_t plog, in_w, in_b, out_w, out_b, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b;
+};
+struct TrLayout {
+  int V, nb;
+  size_t emb, eln_w, eln_b, bias;
+  TrBlockOff blk[LR_MAX_LRU_BLOCKS];
+  size_t total;
+};
+struct TrSeg {
+  const char* suffix;  // name inside a block, or full name when blk < 0
+  size_t off, count;
+  int decay;
+};
+
+static TrLayout tr_layout(int V, int nb) {
+  TrLayout L;
+  L.V = V;
+  L.nb = nb;
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t at = o;
+    o += lr_align_up(n, 64);
+    return at;
+  };
+  L.emb = take((size_t)(V + 1) * 64);
+  L.eln_w = take(64);
+  L.eln_b = take(64);
+  L.bias = take((size_t)V + 1);
+  for (int b = 0; b < LR_MAX_LRU_BLOCKS; ++b) {
+    TrBlockOff& B = L.blk[b];
+    if (b >= nb) {
+      B = TrBlockOff{};
+      continue;
+    }
+    B.plog = take(3 * 128);
+    B.in_w = take(128 * 64 * 2);
+    B.in_b = take(128 * 2);
+    B.out_w = take(64 * 128 * 2);
+    B.out_b = take(64 * 2);
+    B.ln1_w = take(64);
+    B.ln1_b = take(64);
+    B.w1 = take(256 * 64);
+    B.b1 = take(256);
+    B.w2 = take(64 * 256);
+    B.b2 = take(64);
+    B.ln2_w = take(64);
+    B.ln2_b = take(64);
+  }
+  L.total = o;
+  return L;
+}
+
+// segments with the reference's state_dict names (trainer/base.py:222: decay unless "bias"/"layer_norm" in name)
+static int tr_segments(const TrLayout& L, int blk, TrSeg* out) {
+  int n = 0;
+  if (blk < 0) {
+    out[n++] = {"embedding.token.weight", L.emb, (size_t)(L.V + 1) * 64, 1};
+    out[n++] = {"embedding.layer_norm.weight", L.eln_w, 64, 0};
+    out[n++] = {"embedding.layer_norm.bias", L.eln_b, 64, 0};
+    out[n++] = {"model.bias", L.bias, (size_t)L.V + 1, 0};
+    return n;
+  }
+  const TrBlockOff& B = L.blk[blk];
+  out[n++] = {"lru_layer.params_log", B.plog, 3 * 128, 1};
+  out[n++] = {"lru_layer.in_proj.weight", B.in_w, 128 * 64 * 2, 1};
+  out[n++] = {"lru_layer.in_proj.bias", B.in_b, 128 * 2, 0};
+  out[n++] = {"lru_layer.out_proj.weight", B.out_w, 64 * 128 * 2, 1};
+  out[n++] = {"lru_layer.out_proj.bias", B.out_b, 64 * 2, 0};
+  out[n++] = {"lru_layer.layer_norm.weight", B.ln1_w, 64, 0};
+  out[n++] = {"lru_layer.layer_norm.bias", B.ln1_b, 64, 0};
+  out[n++] = {"feed_forward.w_1.weight", B.w1, 256 * 64, 1};
+  out[n++] = {"feed_forward.w_1.bias", B.b1, 256, 0};
+  out[n++] = {"feed_forward.w_2.weight", B.w2, 64 * 256, 1};
+  out[n++] = {"feed_forward.w_2.bias", B.b2, 64, 0};
+  out[n++] = {"feed_forward.layer_norm.weight", B.ln2_w, 64, 0};
+  out[n++] = {"feed_forward.layer_norm.bias", B.ln2_b, 64, 0};
+  return n;
+}
+
+struct lr_lru_train {
+  TrLayout lay;
+  LrLruTrainConfig cfg;
+  float *p, *g, *m, *v;  // flat buffers [total]
+  unsigned char* decay;  // [total] 1 = decoupled weight decay applies
+  float* scal;           // [8] device scalars: 0 loss sum, 1 n_valid, 2 grad norm^2
+  long long step;        // optimizer steps taken
+  long long fwd_calls;   // forward passes (dropout stream position)
+  int device;
+};
+
+// =============================================================================================
+// generic strided f32 GEMM on v_mfma_f32_32x32x2_f32
+//   C[m][n] (ldc) = sum_k A(m,k) * B(k,n) (+ bias[n]) (+ C[m][n] if accumulate)
+//   A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+// 64 x 64 tile, BK = 16, 4 waves (2 x 2) of one 32 x 32 MFMA block each.
+// =============================================================================================
+#define TG_BM 64
+#define TG_BN 64
+#define TG_BK 16
+#define TG_LD 68
+
+__global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, long long sam, long long sak,
+                                                         const float* __restrict__ B, long long sbk, long long sbn,
+                                                         float* C, long long ldc, const float* bias, int M, int N,
+                                                         int K, int accumulate) {
+  __shared__ float As[TG_BK][TG_LD];
+  __shared__ float Bs[TG_BK][TG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
+  for (int k0 = 0; k0 < K; k0 += TG_BK) {
+    float va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      {
+        const int kk = a_kfast ? (e & 15) : (e >> 6), mm = a_kfast ? (e >> 4) : (e & 63);
+        const int gm = m0 + mm, gk = k0 + kk;
+        va[i] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
+      }
+      {
+        const int kk = b_kfast ? (e & 15) : (e >> 6), nn = b_kfast ? (e >> 4) : (e & 63);
+        const int gn = n0 + nn, gk = k0 + kk;
+        vb[i] = (gn < N && gk < K) ? B[gk * sbk + gn * sbn] : 0.f;
+      }
+    }
+    __syncthreads();  // previous tile consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      As[a_kfast ? (e & 15) : (e >> 6)][a_kfast ? (e >> 4) : (e & 63)] = va[i];
+      Bs[b_kfast ? (e & 15) : (e >> 6)][b_kfast ? (e >> 4) : (e & 63)] = vb[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TG_BK / 2; ++s) {
+      const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col < N) {
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < M) {
+        float v = acc[r] + bv;
+        float* c = C + row * ldc + col;
+        *c = accumulate ? (*c + v) : v;
+      }
+    }
+  }
+}
+
+static int tr_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+                   long long ldc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st) {
+  if (M <= 0 || N <= 0) return LR_OK;
+  dim3 grid((N + TG_BN - 1) / TG_BN, (M + TG_BM - 1) / TG_BM);
+  hipLaunchKernelGGL(train_gemm_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K,
+                     accumulate);
+  LR_CHECK_LAUNCH("train_gemm_kernel");
+  return LR_OK;
+}
+// Y[R][N] = X[R][K] W[N][K]^T + b
+static int tr_linear_fwd(const float* X, const float* W, const float* b, float* Y, int R, int N, int K, hipStream_t st) {
+  return tr_gemm(X, K, 1, W, 1, K, Y, N, b, R, N, K, 0, st);
+}
+// dX[R][K] = dY[R][N] W[N][K]      (accumulate optional)
+static int tr_linear_bwd_data(const float* dY, const float* W, float* dX, int R, int N, int K, int acc, hipStream_t st) {
+  return tr_gemm(dY, N, 1, W, K, 1, dX, K, nullptr, R, K, N, acc, st);
+}
+// dW[N][K] = dY[R][N]^T X[R][K]
+static int tr_linear_bwd_weight(const float* dY, const float* X, float* dW, int R, int N, int K, int acc, hipStream_t st) {
+  return tr_gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, R, acc, st);
+}
+
+// =============================================================================================
+// dropout: counter-based hash -> keep mask, identical in forward and backward
+// =============================================================================================
+__device__ __forceinline__ float tr_drop_scale(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
+  if (p <= 0.f) return 1.f;
+  unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * (site + 1)) ^ (idx * 0xD6E8FEB86659FD93ull);
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.0f / (1.0f - p);
+}
+
+// =============================================================================================
+// row kernels (one wave per 64-feature row)
+// =============================================================================================
+__device__ __forceinline__ float tr_wave_sum(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+
+// x = LN(dropout(E[id])): saves xhat and rstd
+__global__ __launch_bounds__(256) void tr_embed_ln_fwd(const long long* ids, const float* E, int V, const float* w,
+                                                       const float* b, float* x, float* xhat, float* rstd, int R,
+                                                       unsigned long long seed, float p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  long long id = ids[row];
+  if (id < 0 || id > V) id = 0;
+  float e = E[id * 64 + lane] * tr_drop_scale(seed, 0, (unsigned long long)row * 64 + lane, p);
+  const float mu = tr_wave_sum(e) * (1.0f / 64);
+  const float d = e - mu;
+  const float rs = 1.0f / sqrtf(tr_wave_sum(d * d) * (1.0f / 64) + LR_LN_EPS);
+  const float xh = d * rs;
+  xhat[row * 64 + lane] = xh;
+  x[row * 64 + lane] = xh * w[lane] + b[lane];
+  if (lane == 0) rstd[row] = rs;
+}
+
+// y = LN(dropout(o) + res)
+__global__ __launch_bounds__(256) void tr_res_ln_fwd(const float* o, const float* res, const float* w, const float* b,
+                                                     float* y, float* xhat, float* rstd, int R,
+                                                     unsigned long long seed, unsigned site, float p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const size_t i = (size_t)row * 64 + lane;
+  const float e = o[i] * tr_drop_scale(seed, site, i, p) + res[i];
+  const float mu = tr_wave_sum(e) * (1.0f / 64);
+  const float d = e - mu;
+  const float rs = 1.0f / sqrtf(tr_wave_sum(d * d) * (1.0f / 64) + LR_LN_EPS);
+  const float xh = d * rs;
+  xhat[i] = xh;
+  y[i] = xh * w[lane] + b[lane];
+  if (lane == 0) rstd[row] = rs;
+}
+
+// LN backward for y = LN(e): dx (pre-LN gradient); dw/db accumulated with atomics (one add per workgroup)
+__global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* w,
+                                                 float* de, float* dw, float* db, int R) {
+  __shared__ float sw[4][64], sb[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  float gw = 0.f, gb = 0.f;
+  if (row < R) {
+    const size_t i = (size_t)row * 64 + lane;
+    const float g = dy[i], xh = xhat[i];
+    gw = g * xh;
+    gb = g;
+    const float dxh = g * w[lane];
+    const float m1 = tr_wave_sum(dxh) * (1.0f / 64);
+    const float m2 = tr_wave_sum(dxh * xh) * (1.0f / 64);
+    de[i] = rstd[row] * (dxh - m1 - xh * m2);
+  }
+  sw[wave][lane] = gw;
+  sb[wave][lane] = gb;
+  __syncthreads();
+  if (wave == 0) {
+    atomicAdd(dw + lane, sw[0][lane] + sw[1][lane] + sw[2][lane] + sw[3][lane]);
+    atomicAdd(db + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+  }
+}
+
+// g = dropout(gelu(a)) elementwise; backward: da = dg * mask * gelu'(a)
+__global__ void tr_gelu_fwd(const float* a, float* g, size_t n, unsigned long long seed, unsigned site, float p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i];
+  g[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)) * tr_drop_scale(seed, site, i, p);
+}
+__global__ void tr_gelu_bwd(const float* a, float* dg_to_da, size_t n, unsigned long long seed, unsigned site, float p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i];
+  const float d = 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+  dg_to_da[i] = dg_to_da[i] * tr_drop_scale(seed, site, i, p) * d;
+}
+// x *= dropout mask (backward of a dropout whose forward was fused elsewhere)
+__global__ void tr_drop_bwd(float* x, size_t n, unsigned long long seed, unsigned site, float p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= tr_drop_scale(seed, site, i, p);
+}
+__global__ void tr_add_inplace(float* x, const float* y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += y[i];
+}
+// out[n] += sum over rows of x[r][n]   (column sums; rows split over blockIdx.y, atomics between splits)
+__global__ __launch_bounds__(256) void tr_colsum(const float* x, long long ld, int R, int N, float* out, int rows_per) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[r * ld + n];
+  atomicAdd(out + n, s);
+}
+
+// =============================================================================================
+// derived per-step weights of a block and their gradients
+// =============================================================================================
+struct TrDerived {  // offsets (floats) inside the workspace's derived region, per block
+  size_t wi, bi, wo, bo, lam;  // [256][64], [256], [64][256], [64], [256] (re | im)
+  size_t dwi, dbi, dwo, dbo, dlam;
+};
+
+__global__ void tr_prep_kernel(const float* plog, const float* in_w, const float* in_b, const float* out_w,
+                               const float* out_b, float* wi, float* bi, float* wo, float* bo, float* lam) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 16383
+  if (i < 128) {
+    const float nu = expf(plog[i]), th = expf(plog[128 + i]);
+    const float mag = expf(-nu);
+    lam[i] = mag * cosf(th);
+    lam[128 + i] = mag * sinf(th);
+    const float ga = expf(plog[256 + i]);
+    bi[i] = ga * in_b[2 * i];
+    bi[128 + i] = ga * in_b[2 * i + 1];
+  }
+  if (i < 64) bo[i] = out_b[2 * i];
+  if (i < 128 * 64) {  // in_w[c][k] complex
+    const int c = i >> 6, k = i & 63;
+    const float ga = expf(plog[256 + c]);
+    wi[c * 64 + k] = ga * in_w[2 * i];
+    wi[(128 + c) * 64 + k] = ga * in_w[2 * i + 1];
+  }
+  if (i < 64 * 128) {  // out_w[o][c] complex
+    const int o = i >> 7, c = i & 127;
+    wo[o * 256 + c] = out_w[2 * i];
+    wo[o * 256 + 128 + c] = -out_w[2 * i + 1];
+  }
+}
+
+// gradients of the stored parameters from those of the derived ones (one workgroup of 128 threads per block)
+__global__ __launch_bounds__(128) void tr_unprep_kernel(const float* plog, const float* in_w, const float* in_b,
+                                                        const float* lam, const float* dwi, const float* dbi,
+                                                        const float* dwo, const float* dbo, const float* dlam,
+                                                        float* g_plog, float* g_in_w, float* g_in_b, float* g_out_w,
+                                                        float* g_out_b) {
+  const int c = threadIdx.x;  // complex channel
+  const float nu = expf(plog[c]), th = expf(plog[128 + c]), ga = expf(plog[256 + c]);
+  float dga = in_b[2 * c] * dbi[c] + in_b[2 * c + 1] * dbi[128 + c];
+  for (int k = 0; k < 64; ++k) {
+    const float dre = dwi[c * 64 + k], dim = dwi[(128 + c) * 64 + k];
+    dga += in_w[2 * (c * 64 + k)] * dre + in_w[2 * (c * 64 + k) + 1] * dim;
+    g_in_w[2 * (c * 64 + k)] = ga * dre;
+    g_in_w[2 * (c * 64 + k) + 1] = ga * dim;
+  }
+  g_in_b[2 * c] = ga * dbi[c];
+  g_in_b[2 * c + 1] = ga * dbi[128 + c];
+  const float lr_ = lam[c], li = lam[128 + c], dr = dlam[c], di = dlam[128 + c];
+  // d/d nu = -Re(dlam conj(lam)); d/d theta = Re(dlam conj(i lam)) = dr*(-li) + di*lr
+  g_plog[c] = -(dr * lr_ + di * li) * nu;
+  g_plog[128 + c] = (-dr * li + di * lr_) * th;
+  g_plog[256 + c] = dga * ga;
+  for (int o = 0; o < 64; ++o) {
+    g_out_w[2 * (o * 128 + c)] = dwo[o * 256 + c];
+    g_out_w[2 * (o * 128 + c) + 1] = -dwo[o * 256 + 128 + c];
+  }
+  if (c < 64) {
+    g_out_b[2 * c] = dbo[c];
+    g_out_b[2 * c + 1] = 0.f;
+  }
+}
+
+// =============================================================================================
+// the recurrence: forward in place (u -> h), backward in place (g -> du) + d lambda
+// =============================================================================================
+// grid: B blocks of 128 threads (thread = complex channel); rows b*L .. b*L+L-1, columns c (re) and 128+c (im)
+__global__ __launch_bounds__(128) void tr_scan_fwd(float* uh, const long long* ids, const float* lam, int L) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float lr_ = lam[c], li = lam[128 + c];
+  float hr = 0.f, hi = 0.f;
+  float* base = uh + (size_t)b * L * 256;
+  for (int t = 0; t < L; ++t) {
+    const float ur = base[t * 256 + c], ui = base[t * 256 + 128 + c];
+    const bool carry = t > 0 && ids[(size_t)b * L + t - 1] > 0;
+    const float nr = carry ? ur + (lr_ * hr - li * hi) : ur;
+    const float ni = carry ? ui + (lr_ * hi + li * hr) : ui;
+    hr = nr;
+    hi = ni;
+    base[t * 256 + c] = hr;
+    base[t * 256 + 128 + c] = hi;
+  }
+}
+__global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, const long long* ids, const float* lam,
+                                                   float* dlam, int L) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float lr_ = lam[c], li = lam[128 + c];
+  float Gr = 0.f, Gi = 0.f, dr = 0.f, di = 0.f;
+  float* gb = g + (size_t)b * L * 256;
+  const float* hb = h + (size_t)b * L * 256;
+  for (int t = L - 1; t >= 0; --t) {
+    float gr = gb[t * 256 + c], gi = gb[t * 256 + 128 + c];
+    if (t < L - 1 && ids[(size_t)b * L + t] > 0) {  // h_{t+1} = u_{t+1} + lambda h_t : G_t += conj(lambda) G_{t+1}
+      gr += lr_ * Gr + li * Gi;
+      gi += lr_ * Gi - li * Gr;
+    }
+    Gr = gr;
+    Gi = gi;
+    gb[t * 256 + c] = Gr;
+    gb[t * 256 + 128 + c] = Gi;
+    if (t > 0 && ids[(size_t)b * L + t - 1] > 0) {  // d lambda += conj(h_{t-1}) G_t
+      const float pr = hb[(t - 1) * 256 + c], pi = hb[(t - 1) * 256 + 128 + c];
+      dr += pr * Gr + pi * Gi;
+      di += pr * Gi - pi * Gr;
+    }
+  }
+  atomicAdd(dlam + c, dr);
+  atomicAdd(dlam + 128 + c, di);
+}
+
+// =============================================================================================
+// softmax cross-entropy over a chunk of logit rows, in place: logits -> d logits; loss sum accumulated
+// =============================================================================================
+__global__ void tr_count_valid(const long long* labels, int R, float* scal) {
+  __shared__ int s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) c += labels[i] != 0;
+  atomicAdd(&s, c);
+  __syncthreads();
+  if (threadIdx.x == 0 && s) atomicAdd(scal + 1, (float)s);
+}
+__device__ __forceinline__ float tr_block_reduce(float v, bool is_max, float* sh) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const float o = __shfl_xor(v, s, 64);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+  return r;
+}
+__global__ __launch_bounds__(256) void tr_ce_kernel(float* logits, long long ld, int C, const long long* labels,
+                                                    float* scal) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  float* x = logits + row * ld;
+  const long long lab = labels[row];
+  if (lab == 0) {  // ignore_index: no loss, no gradient
+    for (int j = threadIdx.x; j < C; j += 256) x[j] = 0.f;
+    return;
+  }
+  float mx = -__builtin_inff();
+  for (int j = threadIdx.x; j < C; j += 256) mx = fmaxf(mx, x[j]);
+  mx = tr_block_reduce(mx, true, sh);
+  float se = 0.f;
+  for (int j = threadIdx.x; j < C; j += 256) se += expf(x[j] - mx);
+  se = tr_block_reduce(se, false, sh);
+  const float inv_n = 1.0f / scal[1], inv_se = 1.0f / se;
+  const float picked = x[lab];
+  __syncthreads();
+  for (int j = threadIdx.x; j < C; j += 256) {
+    const float p = expf(x[j] - mx) * inv_se;
+    x[j] = (p - (j == lab ? 1.0f : 0.0f)) * inv_n;
+  }
+  if (threadIdx.x == 0) atomicAdd(scal, logf(se) + mx - picked);
+}
+__global__ void tr_finish_loss(float* scal, float* out) {
+  out[0] = scal[0] / fmaxf(scal[1], 1.0f);
+  out[1] = scal[1];
+}
+
+// embedding backward: dE[id] += de[row]
+__global__ __launch_bounds__(256) void tr_embed_bwd(const float* de, const long long* ids, int V, float* dE, int R,
+                                                    unsigned long long seed, float p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  long long id = ids[row];
+  if (id < 0 || id > V) id = 0;
+  atomicAdd(dE + id * 64 + lane, de[(size_t)row * 64 + lane] * tr_drop_scale(seed, 0, (unsigned long long)row * 64 + lane, p));
+}
+
+// =============================================================================================
+// optimizer
+// =============================================================================================
+__global__ __launch_bounds__(256) void tr_sumsq_kernel(const float* g, size_t n, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+  s = tr_block_reduce(s, false, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+__global__ void tr_adamw_kernel(float* p, const float* g, float* m, float* v, const unsigned char* decay, size_t n,
+                                const float* scal, float max_norm, float lr, float wd, float b1, float b2, float eps,
+                                float bc1, float bc2_sqrt, float* out_norm) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float norm = sqrtf(scal[2]);
+  if (i == 0 && out_norm) *out_norm = norm;
+  if (i >= n) return;
+  const float coef = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
+  const float gi = g[i] * coef;
+  float pi = p[i];
+  if (decay[i]) pi *= 1.0f - lr * wd;
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+
+// =============================================================================================
+// workspace
+// =============================================================================================
+struct TrBlockWs {
+  TrDerived d;
+  float *h, *xhat1, *rstd1, *y, *a, *g, *xhat2, *rstd2, *xout;  // saved activations
+};
+struct TrWs {
+  float* derived;  // derived weights + their gradients, all blocks
+  float *x0, *xhat0, *rstd0;
+  TrBlockWs blk[LR_MAX_LRU_BLOCKS];
+  float *d64a, *d64b, *d256;  // gradient scratch [R][64] x2, [R][256]
+  float* logits;              // [rows_chunk][V+1]
+  int rows_chunk;
+  size_t total;
+};
+#define TR_LOGIT_BYTES ((size_t)1 << 30)
+
+static TrWs tr_carve(const TrLayout& lay, int R, char* base) {
+  TrWs w;
+  size_t o = 0;
+  auto take = [&](size_t floats) {
+    size_t at = o;
+    o += lr_align_up(floats * sizeof(float), 256);
+    return (float*)(base + at);
+  };
+  size_t doff = 0;
+  auto dtake = [&](size_t n) {
+    size_t at = doff;
+    doff += lr_align_up(n, 64);
+    return at;
+  };
+  for (int b = 0; b < lay.nb; ++b) {
+    TrDerived& d = w.blk[b].d;
+    d.wi = dtake(256 * 64);
+    d.bi = dtake(256);
+    d.wo = dtake(64 * 256);
+    d.bo = dtake(64);
+    d.lam = dtake(256);
+    d.dwi = dtake(256 * 64);
+    d.dbi = dtake(256);
+    d.dwo = dtake(64 * 256);
+    d.dbo = dtake(64);
+    d.dlam = dtake(256);
+  }
+  w.derived = take(doff);
+  const size_t r = (size_t)R;
+  w.x0 = take(r * 64);
+  w.xhat0 = take(r * 64);
+  w.rstd0 = take(r);
+  for (int b = 0; b < lay.nb; ++b) {
+    TrBlockWs& B = w.blk[b];
+    B.h = take(r * 256);
+    B.xhat1 = take(r * 64);
+    B.rstd1 = take(r);
+    B.y = take(r * 64);
+    B.a = take(r * 256);
+    B.g = take(r * 256);
+    B.xhat2 = take(r * 64);
+    B.rstd2 = take(r);
+    B.xout = take(r * 64);
+  }
+  w.d64a = take(r * 64);
+  w.d64b = take(r * 64);
+  w.d256 = take(r * 256);
+  const size_t C = (size_t)lay.V + 1;
+  size_t rc = TR_LOGIT_BYTES / (C * sizeof(float));
+  if (rc < 64) rc = 64;
+  if (rc > r) rc = r;
+  w.rows_chunk = (int)rc;
+  w.logits = take(rc * C);
+  w.total = o;
+  return w;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" size_t lr_lru_train_state_bytes(int32_t num_items, int32_t num_blocks) {
+  if (num_items < 1 || num_blocks < 1 || num_blocks > LR_MAX_LRU_BLOCKS) return 0;
+  const size_t n = tr_layout(num_items, num_blocks).total;
+  return 4 * n * sizeof(float) + lr_align_up(n, 256) + 256;
+}
+
+static int tr_find(const TrLayout& L, const char* name, TrSeg* out) {
+  TrSeg segs[16];
+  int n = tr_segments(L, -1, segs);
+  for (int i = 0; i < n; ++i)
+    if (!strcmp(name, segs[i].suffix)) {
+      *out = segs[i];
+      return 1;
+    }
+  const char* pre = "model.lru_blocks.";
+  if (strncmp(name, pre, strlen(pre))) return 0;
+  const char* q = name + strlen(pre);
+  int b = 0;
+  while (*q >= '0' && *q <= '9') b = b * 10 + (*q++ - '0');
+  if (*q++ != '.' || b >= L.nb) return 0;
+  n = tr_segments(L, b, segs);
+  for (int i = 0; i < n; ++i)
+    if (!strcmp(q, segs[i].suffix)) {
+      *out = segs[i];
+      return 1;
+    }
+  return 0;
+}
+
+extern "C" int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrainConfig* cfg, void* state_dev,
+                                   size_t state_bytes, lr_lru_train_t** out) {
+  if (!init || !cfg || !state_dev || !out) LR_FAIL(LR_EINVAL, "lr_lru_train_create: null argument");
+  if (init->hidden != 64) LR_FAIL(LR_EUNSUPPORTED, "lr_lru_train_create: hidden=%d, only 64 is implemented", init->hidden);
+  const size_t need = lr_lru_train_state_bytes(init->num_items, init->num_blocks);
+  if (!need || state_bytes < need) LR_FAIL(LR_EINVAL, "lr_lru_train_create: state buffer %zu < %zu bytes", state_bytes, need);
+  if (cfg->dropout < 0.f || cfg->dropout >= 1.f || cfg->attn_dropout < 0.f || cfg->attn_dropout >= 1.f)
+    LR_FAIL(LR_EINVAL, "lr_lru_train_create: dropout outside [0, 1)");
+  lr_lru_train* h = (lr_lru_train*)calloc(1, sizeof(lr_lru_train));
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_create: out of host memory");
+  h->lay = tr_layout(init->num_items, init->num_blocks);
+  h->cfg = *cfg;
+  const size_t n = h->lay.total;
+  h->p = (float*)state_dev;
+  h->g = h->p + n;
+  h->m = h->g + n;
+  h->v = h->m + n;
+  h->decay = (unsigned char*)(h->v + n);
+  h->scal = (float*)(h->decay + lr_align_up(n, 256));
+  LR_CHECK_HIP(hipGetDevice(&h->device));
+  // host image of the parameters and the decay mask, one upload each
+  float* img = (float*)calloc(n, sizeof(float));
+  unsigned char* dec = (unsigned char*)calloc(n, 1);
+  if (!img || !dec) {
+    free(img);
+    free(dec);
+    free(h);
+    LR_FAIL(LR_EINVAL, "lr_lru_train_create: out of host memory");
+  }
+  const TrLayout& L = h->lay;
+  const size_t rows = (size_t)L.V + 1;
+  memcpy(img + L.emb, init->item_emb, rows * 64 * sizeof(float));
+  memcpy(img + L.eln_w, init->emb_ln_w, 64 * sizeof(float));
+  memcpy(img + L.eln_b, init->emb_ln_b, 64 * sizeof(float));
+  memcpy(img + L.bias, init->item_bias, rows * sizeof(float));
+  for (int b = 0; b < L.nb; ++b) {
+    const LrLruBlockWeights& w = init->blocks[b];
+    const TrBlockOff& B = L.blk[b];
+    memcpy(img + B.plog, w.params_log, 3 * 128 * sizeof(float));
+    memcpy(img + B.in_w, w.in_proj_w, 128 * 64 * 2 * sizeof(float));
+    memcpy(img + B.in_b, w.in_proj_b, 128 * 2 * sizeof(float));
+    memcpy(img + B.out_w, w.out_proj_w, 64 * 128 * 2 * sizeof(float));
+    memcpy(img + B.out_b, w.out_proj_b, 64 * 2 * sizeof(float));
+    memcpy(img + B.ln1_w, w.ln1_w, 64 * sizeof(float));
+    memcpy(img + B.ln1_b, w.ln1_b, 64 * sizeof(float));
+    memcpy(img + B.w1, w.ffn_w1, 256 * 64 * sizeof(float));
+    memcpy(img + B.b1, w.ffn_b1, 256 * sizeof(float));
+    memcpy(img + B.w2, w.ffn_w2, 64 * 256 * sizeof(float));
+    memcpy(img + B.b2, w.ffn_b2, 64 * sizeof(float));
+    memcpy(img + B.ln2_w, w.ln2_w, 64 * sizeof(float));
+    memcpy(img + B.ln2_b, w.ln2_b, 64 * sizeof(float));
+  }
+  TrSeg segs[16];
+  for (int b = -1; b < L.nb; ++b) {
+    const int ns = tr_segments(L, b, segs);
+    for (int i = 0; i < ns; ++i)
+      if (segs[i].decay) memset(dec + segs[i].off, 1, segs[i].count);
+  }
+  hipError_t e1 = hipMemcpy(h->p, img, n * sizeof(float), hipMemcpyHostToDevice);
+  hipError_t e2 = hipMemcpy(h->decay, dec, n, hipMemcpyHostToDevice);
+  hipError_t e3 = hipMemset(h->g, 0, 3 * n * sizeof(float));
+  hipError_t e4 = hipMemset(h->scal, 0, 8 * sizeof(float));
+  free(img);
+  free(dec);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    free(h);
+    LR_FAIL(LR_EHIP, "lr_lru_train_create: upload failed");
+  }
+  *out = h;
+  return LR_OK;
+}
+
+extern "C" void lr_lru_train_destroy(lr_lru_train_t* h) { free(h); }
+
+extern "C" size_t lr_lru_train_workspace_bytes(const lr_lru_train_t* h, int32_t B, int32_t L) {
+  if (!h || B < 1 || L < 1) return 0;
+  return tr_carve(h->lay, B * L, nullptr).total;
+}
+
+extern "C" int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_t* count) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_buffers: null handle");
+  if (params) *params = h->p;
+  if (grads) *grads = h->g;
+  if (count) *count = h->lay.total;
+  return LR_OK;
+}
+
+extern "C" int lr_lru_train_param_range(const lr_lru_train_t* h, const char* name, size_t* offset, size_t* count) {
+  if (!h || !name || !offset || !count) LR_FAIL(LR_EINVAL, "lr_lru_train_param_range: null argument");
+  TrSeg s;
+  if (!tr_find(h->lay, name, &s)) LR_FAIL(LR_EINVAL, "lr_lru_train_param_range: unknown parameter '%s'", name);
+  *offset = s.off;
+  *count = s.count;
+  return LR_OK;
+}
+
+#define TR_RUN(x)            \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_) return rc_;     \
+  } while (0)
+#define TR_EW(kernel, n, ...)                                                                         \
+  do {                                                                                                \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, st, __VA_ARGS__);   \
+    LR_CHECK_LAUNCH(#kernel);                                                                         \
+  } while (0)
+
+extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64_t* labels, int32_t B,
+                                      int32_t L, float* out_loss, void* workspace, size_t workspace_bytes,
+                                      void* hip_stream) {
+  if (!h || !tokens || !labels || !out_loss || !workspace) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: null argument");
+  if (B < 1 || L < 1) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: B=%d L=%d", B, L);
+  const TrLayout& lay = h->lay;
+  const int R = B * L, V = lay.V, C = V + 1;
+  TrWs ws = tr_carve(lay, R, (char*)workspace);
+  if (ws.total > workspace_bytes)
+    LR_FAIL(LR_EWORKSPACE, "lr_lru_train_loss_grad: workspace needs %zu bytes, have %zu", ws.total, workspace_bytes);
+  hipStream_t st = (hipStream_t)hip_stream;
+  const long long* ids = (const long long*)tokens;
+  const long long* lab = (const long long*)labels;
+  float *P = h->p, *G = h->g;
+  const unsigned long long seed = h->cfg.seed * 0x9E3779B97F4A7C15ull + (unsigned long long)(h->fwd_calls++) * 0xA24BAED4963EE407ull;
+  const float pd = h->cfg.dropout, pa = h->cfg.attn_dropout;
+  const unsigned grid_rows = (unsigned)((R + 3) / 4);
+
+  LR_CHECK_HIP(hipMemsetAsync(G, 0, lay.total * sizeof(float), st));
+  LR_CHECK_HIP(hipMemsetAsync(h->scal, 0, 8 * sizeof(float), st));
+  {  // gradients of the derived weights start from zero as well
+    const TrDerived& d0 = ws.blk[0].d;
+    const TrDerived& dl = ws.blk[lay.nb - 1].d;
+    LR_CHECK_HIP(hipMemsetAsync(ws.derived + d0.wi, 0, (dl.dlam + 256 - d0.wi) * sizeof(float), st));
+  }
+  // ---- forward
+  for (int b = 0; b < lay.nb; ++b) {
+    const TrBlockOff& o = lay.blk[b];
+    const TrDerived& d = ws.blk[b].d;
+    TR_EW(tr_prep_kernel, 128 * 64, P + o.plog, P + o.in_w, P + o.in_b, P + o.out_w, P + o.out_b, ws.derived + d.wi,
+          ws.derived + d.bi, ws.derived + d.wo, ws.derived + d.bo, ws.derived + d.lam);
+  }
+  hipLaunchKernelGGL(tr_embed_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ids, P + lay.emb, V, P + lay.eln_w,
+                     P + lay.eln_b, ws.x0, ws.xhat0, ws.rstd0, R, seed, pd);
+  LR_CHECK_LAUNCH("tr_embed_ln_fwd");
+  const float* x = ws.x0;
+  for (int b = 0; b < lay.nb; ++b) {
+    const TrBlockOff& o = lay.blk[b];
+    TrBlockWs& W = ws.blk[b];
+    const float* D = ws.derived;
+    TR_RUN(tr_linear_fwd(x, D + W.d.wi, D + W.d.bi, W.h, R, 256, 64, st));
+    hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), 0, st, W.h, ids, D + W.d.lam, L);
+    LR_CHECK_LAUNCH("tr_scan_fwd");
+    TR_RUN(tr_linear_fwd(W.h, D + W.d.wo, D + W.d.bo, ws.d64a, R, 64, 256, st));
+    hipLaunchKernelGGL(tr_res_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ws.d64a, x, P + o.ln1_w, P + o.ln1_b, W.y,
+                       W.xhat1, W.rstd1, R, seed, 10u + 4u * b, pa);
+    LR_CHECK_LAUNCH("tr_res_ln_fwd");
+    TR_RUN(tr_linear_fwd(W.y, P + o.w1, P + o.b1, W.a, R, 256, 64, st));
+    TR_EW(tr_gelu_fwd, (size_t)R * 256, W.a, W.g, (size_t)R * 256, seed, 11u + 4u * b, pd);
+    TR_RUN(tr_linear_fwd(W.g, P + o.w2, P + o.b2, ws.d64a, R, 64, 256, st));
+    hipLaunchKernelGGL(tr_res_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ws.d64a, W.y, P + o.ln2_w, P + o.ln2_b, W.xout,
+                       W.xhat2, W.rstd2, R, seed, 12u + 4u * b, pd);
+    LR_CHECK_LAUNCH("tr_res_ln_fwd");
+    x = W.xout;
+  }
+  // ---- item GEMM + cross-entropy, row chunk by row chunk: d x_final in d64b
+  hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, h->scal);
+  LR_CHECK_LAUNCH("tr_count_valid");
+  float* dx = ws.d64b;
+  for (int r0 = 0; r0 < R; r0 += ws.rows_chunk) {
+    const int rc = (R - r0 < ws.rows_chunk) ? R - r0 : ws.rows_chunk;
+    const float* xf = x + (size_t)r0 * 64;
+    TR_RUN(tr_gemm(xf, 64, 1, P + lay.emb, 1, 64, ws.logits, C, P + lay.bias, rc, C, 64, 0, st));  // scores (model/lru.py:85)
+    hipLaunchKernelGGL(tr_ce_kernel, dim3(rc), dim3(256), 0, st, ws.logits, (long long)C, C, lab + r0, h->scal);
+    LR_CHECK_LAUNCH("tr_ce_kernel");
+    TR_RUN(tr_gemm(ws.logits, C, 1, P + lay.emb, 64, 1, dx + (size_t)r0 * 64, 64, nullptr, rc, 64, C, 0, st));  // d x
+    TR_RUN(tr_gemm(ws.logits, 1, C, xf, 64, 1, G + lay.emb, 64, nullptr, C, 64, rc, 1, st));                     // d table
+    hipLaunchKernelGGL(tr_colsum, dim3((C + 255) / 256, (rc + 255) / 256), dim3(256), 0, st, ws.logits, (long long)C, rc,
+                       C, G + lay.bias, 256);
+    LR_CHECK_LAUNCH("tr_colsum");
+  }
+  hipLaunchKernelGGL(tr_finish_loss, dim3(1), dim3(1), 0, st, h->scal, out_loss);
+  LR_CHECK_LAUNCH("tr_finish_loss");
+
+  // ---- backward through the blocks; dx = gradient of the block's output
+  for (int b = lay.nb - 1; b >= 0; --b) {
+    const TrBlockOff& o = lay.blk[b];
+    TrBlockWs& W = ws.blk[b];
+    float* D = ws.derived;
+    const float* xin = b ? ws.blk[b - 1].xout : ws.x0;
+    float* dz0 = ws.d64a;
+    // LN2: dx -> dz0 (gradient of W2 g + b2 (dropped) + y)
+    hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, W.xhat2, W.rstd2, P + o.ln2_w, dz0, G + o.ln2_w,
+                       G + o.ln2_b, R);
+    LR_CHECK_LAUNCH("tr_ln_bwd");
+    // dy (residual branch) = dz0; the W2 branch sees dropout(dz0)
+    LR_CHECK_HIP(hipMemcpyAsync(dx, dz0, (size_t)R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));  // dx now = dy partial
+    if (pd > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dz0, (size_t)R * 64, seed, 12u + 4u * b, pd);
+    TR_RUN(tr_linear_bwd_weight(dz0, W.g, G + o.w2, R, 64, 256, 0, st));
+    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, dz0, 64LL, R, 64, G + o.b2, 256);
+    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_data(dz0, P + o.w2, ws.d256, R, 64, 256, 0, st));  // d g
+    TR_EW(tr_gelu_bwd, (size_t)R * 256, W.a, ws.d256, (size_t)R * 256, seed, 11u + 4u * b, pd);  // -> d a
+    TR_RUN(tr_linear_bwd_weight(ws.d256, W.y, G + o.w1, R, 256, 64, 0, st));
+    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, ws.d256, 256LL, R, 256, G + o.b1, 256);
+    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_data(ws.d256, P + o.w1, dx, R, 256, 64, 1, st));  // dy += da W1
+    // LN1: dy -> dy0 (gradient of dropout(o) + x)
+    float* dy0 = ws.d64a;
+    hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, W.xhat1, W.rstd1, P + o.ln1_w, dy0, G + o.ln1_w,
+                       G + o.ln1_b, R);
+    LR_CHECK_LAUNCH("tr_ln_bwd");
+    LR_CHECK_HIP(hipMemcpyAsync(dx, dy0, (size_t)R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));  // residual: dx_in = dy0 + ...
+    if (pa > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dy0, (size_t)R * 64, seed, 10u + 4u * b, pa);
+    // out_proj (derived real form [64][256] over (Re h | Im h))
+    TR_RUN(tr_linear_bwd_weight(dy0, W.h, D + W.d.dwo, R, 64, 256, 0, st));
+    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, dy0, 64LL, R, 64, D + W.d.dbo, 256);
+    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_data(dy0, D + W.d.wo, ws.d256, R, 64, 256, 0, st));  // g_t = direct gradient of h_t
+    hipLaunchKernelGGL(tr_scan_bwd, dim3(B), dim3(128), 0, st, ws.d256, W.h, ids, D + W.d.lam, D + W.d.dlam, L);
+    LR_CHECK_LAUNCH("tr_scan_bwd");
+    // in_proj (derived, gamma folded): du in d256
+    TR_RUN(tr_linear_bwd_weight(ws.d256, xin, D + W.d.dwi, R, 256, 64, 0, st));
+    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, ws.d256, 256LL, R, 256, D + W.d.dbi, 256);
+    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_data(ws.d256, D + W.d.wi, dx, R, 256, 64, 1, st));  // dx_in += du Wi
+    hipLaunchKernelGGL(tr_unprep_kernel, dim3(1), dim3(128), 0, st, P + o.plog, P + o.in_w, P + o.in_b, D + W.d.lam,
+                       D + W.d.dwi, D + W.d.dbi, D + W.d.dwo, D + W.d.dbo, D + W.d.dlam, G + o.plog, G + o.in_w, G + o.in_b,
+                       G + o.out_w, G + o.out_b);
+    LR_CHECK_LAUNCH("tr_unprep_kernel");
+  }
+  // ---- embedding LayerNorm and the lookup
+  hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, ws.xhat0, ws.rstd0, P + lay.eln_w, ws.d64a,
+                     G + lay.eln_w, G + lay.eln_b, R);
+  LR_CHECK_LAUNCH("tr_ln_bwd");
+  hipLaunchKernelGGL(tr_embed_bwd, dim3(grid_rows), dim3(256), 0, st, ws.d64a, ids, V, G + lay.emb, R, seed, pd);
+  LR_CHECK_LAUNCH("tr_embed_bwd");
+  return LR_OK;
+}
+
+extern "C" int lr_lru_train_apply(lr_lru_train_t* h, float lr, float max_grad_norm, float* out_grad_norm,
+                                  void* hip_stream) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_apply: null handle");
+  if (max_grad_norm <= 0.f) max_grad_norm = h->cfg.max_grad_norm;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t n = h->lay.total;
+  LR_CHECK_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(float), st));
+  hipLaunchKernelGGL(tr_sumsq_kernel, dim3(256), dim3(256), 0, st, h->g, n, h->scal + 2);
+  LR_CHECK_LAUNCH("tr_sumsq_kernel");
+  h->step += 1;
+  const LrLruTrainConfig& c = h->cfg;
+  const float bc1 = 1.0f - powf(c.beta1, (float)h->step);
+  const float bc2s = sqrtf(1.0f - powf(c.beta2, (float)h->step));
+  hipLaunchKernelGGL(tr_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->p, h->g, h->m, h->v, h->decay,
+                     n, h->scal, max_grad_norm, lr, c.weight_decay, c.beta1, c.beta2, c.eps, bc1, bc2s, out_grad_norm);
+  LR_CHECK_LAUNCH("tr_adamw_kernel");
+  return LR_OK;
+}

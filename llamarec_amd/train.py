@@ -1,0 +1,177 @@
+"""Retriever training on MI355X -- host-side mirror of the reference's training seam, backed by the HIP
+kernels of csrc/lru_train.hip (no torch autograd, no CPU fallback).
+
+Reference interface being replaced (paths into the reference tree):
+  LRUTrainer.calculate_loss(batch)                  trainer/lru.py:20-28   CE over all positions, ignore_index=0
+  BaseTrainer.train_one_epoch: zero_grad, backward,  trainer/base.py:84-132
+      clip_gradients(max_grad_norm), optimizer.step, lr_scheduler.step
+  BaseTrainer._create_optimizer (AdamW, two groups)   trainer/base.py:219-246
+  checkpoints: {"model_state_dict": ...} in models/best_acc_model.pth     trainer/base.py:326-330, config.py:7
+Batches are what LRUTrainDataset yields (dataloader/lru.py:119-131): int64 tokens / labels [B, L], left-padded
+with 0; label 0 = ignored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from ._lib import check, lib, stream_ptr
+
+_COMPLEX = ("in_proj.weight", "in_proj.bias", "out_proj.weight", "out_proj.bias")
+
+
+class LRUTrainEngine:
+    """Parameters, gradients and AdamW state of one LRURec on one GPU.
+
+    >>> eng = LRUTrainEngine(init_lru_state_dict(num_items), lr=1e-3)
+    >>> loss = eng.train_step(tokens, labels)          # forward + backward + clip + AdamW
+    >>> torch.save({"model_state_dict": eng.state_dict()}, "best_acc_model.pth")   # reference format
+    """
+
+    def __init__(self, state_dict, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-9, max_grad_norm=5.0,
+                 dropout=0.2, attn_dropout=0.2, seed=42, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("LRUTrainEngine needs a GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device(device)
+        self.lr = float(lr)
+        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in state_dict.items()}
+        # logical shapes; complex tensors may arrive as complex64 [...] or as float pairs [..., 2]
+        self._shapes = {k: (tuple(v.shape[:-1]) if (any(k.endswith(c) for c in _COMPLEX) and not np.iscomplexobj(v))
+                            else tuple(v.shape)) for k, v in sd.items()}
+        desc, keep = A.lru_desc_from_state_dict(sd)
+        self.num_items, self.num_blocks = int(desc.num_items), int(desc.num_blocks)
+        cfg = A.LrLruTrainConfig(weight_decay=weight_decay, beta1=betas[0], beta2=betas[1], eps=eps,
+                                 max_grad_norm=max_grad_norm, dropout=dropout, attn_dropout=attn_dropout, seed=seed)
+        nbytes = lib().lr_lru_train_state_bytes(self.num_items, self.num_blocks)
+        if nbytes == 0:
+            raise ValueError("unsupported LRURec shape")
+        with torch.cuda.device(self.device):
+            self._state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize()
+            h = C.c_void_p()
+            check(lib().lr_lru_train_create(C.byref(desc), C.byref(cfg), self._state.data_ptr(), nbytes, C.byref(h)),
+                  "lr_lru_train_create")
+        del keep
+        self._h = h
+        p, g, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        check(lib().lr_lru_train_buffers(self._h, C.byref(p), C.byref(g), C.byref(n)), "lr_lru_train_buffers")
+        self._n = int(n.value)
+        base = self._state.data_ptr()
+        f32 = self._state.view(torch.float32)
+        self.params = f32[(p.value - base) // 4:(p.value - base) // 4 + self._n]   # views into the state buffer
+        self.grads = f32[(g.value - base) // 4:(g.value - base) // 4 + self._n]
+        self._ws = None
+        self._out = torch.zeros(3, dtype=torch.float32, device=self.device)  # loss, n_valid, grad norm
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().lr_lru_train_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # -- one step ----------------------------------------------------------------------------
+    def _batch(self, tokens, labels):
+        t = torch.as_tensor(np.asarray(tokens) if not isinstance(tokens, torch.Tensor) else tokens)
+        l = torch.as_tensor(np.asarray(labels) if not isinstance(labels, torch.Tensor) else labels)
+        if t.dim() != 2 or t.shape != l.shape:
+            raise ValueError(f"tokens {tuple(t.shape)} and labels {tuple(l.shape)} must both be [B, L]")
+        return (t.to(device=self.device, dtype=torch.int64).contiguous(),
+                l.to(device=self.device, dtype=torch.int64).contiguous())
+
+    def loss_and_grads(self, tokens, labels):
+        """trainer/lru.py:20-28 + loss.backward(): fills `self.grads`, returns the loss as a 0-dim device tensor."""
+        t, l = self._batch(tokens, labels)
+        B, L = t.shape
+        need = lib().lr_lru_train_workspace_bytes(self._h, B, L)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().lr_lru_train_loss_grad(self._h, t.data_ptr(), l.data_ptr(), B, L, self._out.data_ptr(),
+                                               self._ws.data_ptr(), self._ws.numel(), stream_ptr()), "lr_lru_train_loss_grad")
+        return self._out[0]
+
+    def apply(self, lr=None, max_grad_norm=None):
+        """clip_gradients(limit) + optimizer.step (trainer/base.py:109-110,201-202); returns the pre-clip gradient
+        norm (0-dim device tensor)."""
+        with torch.cuda.device(self.device):
+            check(lib().lr_lru_train_apply(self._h, float(self.lr if lr is None else lr),
+                                           float(0.0 if max_grad_norm is None else max_grad_norm),
+                                           self._out[2:].data_ptr(), stream_ptr()), "lr_lru_train_apply")
+        return self._out[2]
+
+    def train_step(self, tokens, labels, lr=None, all_reduce=None):
+        """One optimizer step. all_reduce: optional callable(tensor) that averages the flat gradient buffer across
+        data-parallel ranks (llamarec_amd.dist.average_)."""
+        loss = self.loss_and_grads(tokens, labels)
+        if all_reduce is not None:
+            all_reduce(self.grads)
+        self.apply(lr)
+        return loss
+
+    # -- parameters by their reference names -------------------------------------------------
+    def _range(self, name):
+        off, cnt = C.c_size_t(), C.c_size_t()
+        check(lib().lr_lru_train_param_range(self._h, name.encode(), C.byref(off), C.byref(cnt)), "lr_lru_train_param_range")
+        return int(off.value), int(cnt.value)
+
+    def _named(self, flat):
+        out = {}
+        for name, cshape in self._shapes.items():
+            off, cnt = self._range(name)
+            a = flat[off:off + cnt].detach().cpu().numpy().copy()
+            if any(name.endswith(c) for c in _COMPLEX):
+                out[name] = a.view(np.complex64).reshape(cshape)
+            else:
+                out[name] = a.reshape(cshape)
+        return out
+
+    def state_dict(self):
+        """Reference-format state_dict (numpy; complex64 where the reference's tensors are complex): feeds
+        LRURec.from_state_dict and `torch.save({"model_state_dict": ...})`."""
+        return self._named(self.params)
+
+    def grad_dict(self):
+        return self._named(self.grads)
+
+
+class LRUTrainer:
+    """Mirror of the reference's LRUTrainer training surface (trainer/lru.py:13-28, trainer/base.py:60-132):
+    `calculate_loss(batch)` and `train_one_epoch`-style stepping; evaluation/candidate generation stay with
+    llamarec_amd.retrieve.LRUEvaluator (they run on the exported weights)."""
+
+    def __init__(self, args, state_dict=None, device="cuda:0"):
+        from .lru import init_lru_state_dict
+
+        self.args = args
+        if state_dict is None:
+            state_dict = init_lru_state_dict(args.num_items, getattr(args, "seed", 42), getattr(args, "bert_num_blocks", 2))
+        self.engine = LRUTrainEngine(
+            state_dict, lr=getattr(args, "lr", 1e-3), weight_decay=getattr(args, "weight_decay", 1e-2),
+            eps=getattr(args, "adam_epsilon", 1e-9), max_grad_norm=getattr(args, "max_grad_norm", 5.0),
+            dropout=getattr(args, "bert_dropout", 0.2), attn_dropout=getattr(args, "bert_attn_dropout", 0.2),
+            seed=getattr(args, "seed", 42), device=device)
+        self.iterations = 0
+
+    def calculate_loss(self, batch):
+        seqs, labels = batch
+        return self.engine.loss_and_grads(seqs, labels)
+
+    def train_one_epoch(self, batches, all_reduce=None, lr_lambda=None):
+        """batches: iterable of (tokens, labels). Returns the mean loss (host float), like the reference's
+        AverageMeterSet over the epoch (trainer/base.py:86-118)."""
+        total, n = 0.0, 0
+        for tokens, labels in batches:
+            lr = self.engine.lr * (lr_lambda(self.iterations) if lr_lambda else 1.0)
+            loss = self.engine.train_step(tokens, labels, lr=lr, all_reduce=all_reduce)
+            total += float(loss)
+            n += 1
+            self.iterations += 1
+        return total / max(n, 1)
+
+    def state_dict(self):
+        return self.engine.state_dict()
