@@ -133,10 +133,13 @@ struct lr_lru_train {
 #define TG_BK 16
 #define TG_LD 68
 
+// gridDim.z > 1 splits K: every split ADDS its partial product with fp32 atomics (C must hold the value to
+// accumulate onto, e.g. zero). rowsum (optional): rowsum[m] += sum_k A(m,k), taken from the A tiles by the
+// workgroups of column block 0 -- the bias gradient that goes with a weight gradient dW = dY^T X.
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, long long sam, long long sak,
                                                          const float* __restrict__ B, long long sbk, long long sbn,
                                                          float* C, long long ldc, const float* bias, int M, int N,
-                                                         int K, int accumulate) {
+                                                         int K, int accumulate, float* rowsum) {
   __shared__ float As[TG_BK][TG_LD];
   __shared__ float Bs[TG_BK][TG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,7 +149,11 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
-  for (int k0 = 0; k0 < K; k0 += TG_BK) {
+  const int ksteps = (K + TG_BK - 1) / TG_BK;
+  const int ks0 = (int)((long long)blockIdx.z * ksteps / gridDim.z), ks1 = (int)((long long)(blockIdx.z + 1) * ksteps / gridDim.z);
+  const bool want_rowsum = rowsum != nullptr && blockIdx.x == 0;
+  float rs = 0.f;
+  for (int k0 = ks0 * TG_BK; k0 < ks1 * TG_BK; k0 += TG_BK) {
     float va[4], vb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -170,6 +177,10 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
       Bs[b_kfast ? (e & 15) : (e >> 6)][b_kfast ? (e >> 4) : (e & 63)] = vb[i];
     }
     __syncthreads();
+    if (want_rowsum && tid < TG_BM) {
+#pragma unroll
+      for (int kk = 0; kk < TG_BK; ++kk) rs += As[kk][tid];
+    }
 #pragma unroll
     for (int s = 0; s < TG_BK / 2; ++s) {
       const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -177,27 +188,38 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
   }
+  if (want_rowsum && tid < TG_BM && m0 + tid < M) atomicAdd(rowsum + m0 + tid, rs);
   const int col = n0 + wn * 32 + (lane & 31);
   if (col < N) {
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row < M) {
         float v = acc[r] + bv;
         float* c = C + row * ldc + col;
-        *c = accumulate ? (*c + v) : v;
+        if (gridDim.z > 1) atomicAdd(c, v);
+        else *c = accumulate ? (*c + v) : v;
       }
     }
   }
 }
 
+// accumulate: 0 = overwrite, 1 = add to C. split_ok: the caller guarantees that C already holds the value to add to
+// (zero for a fresh result), so K may be split over workgroups with atomic adds when the tiles alone are too few.
 static int tr_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
-                   long long ldc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st) {
+                   long long ldc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st,
+                   bool split_ok = false, float* rowsum = nullptr) {
   if (M <= 0 || N <= 0) return LR_OK;
-  dim3 grid((N + TG_BN - 1) / TG_BN, (M + TG_BM - 1) / TG_BM);
+  dim3 grid((N + TG_BN - 1) / TG_BN, (M + TG_BM - 1) / TG_BM, 1);
+  if (split_ok) {
+    const int tiles = grid.x * grid.y, ksteps = (K + TG_BK - 1) / TG_BK;
+    int S = 1024 / tiles;          // ~4 workgroups per CU
+    if (S > ksteps / 8) S = ksteps / 8;  // >= 8 K steps per split
+    if (S > 1) grid.z = S;
+  }
   hipLaunchKernelGGL(train_gemm_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K,
-                     accumulate);
+                     accumulate, rowsum);
   LR_CHECK_LAUNCH("train_gemm_kernel");
   return LR_OK;
 }
@@ -209,9 +231,10 @@ static int tr_linear_fwd(const float* X, const float* W, const float* b, float* 
 static int tr_linear_bwd_data(const float* dY, const float* W, float* dX, int R, int N, int K, int acc, hipStream_t st) {
   return tr_gemm(dY, N, 1, W, K, 1, dX, K, nullptr, R, K, N, acc, st);
 }
-// dW[N][K] = dY[R][N]^T X[R][K]
-static int tr_linear_bwd_weight(const float* dY, const float* X, float* dW, int R, int N, int K, int acc, hipStream_t st) {
-  return tr_gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, R, acc, st);
+// dW[N][K] += dY[R][N]^T X[R][K] and db[N] += column sums of dY   (both buffers pre-zeroed: K = R is split)
+static int tr_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int R, int N, int K,
+                                hipStream_t st) {
+  return tr_gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, R, 1, st, true, db);
 }
 
 // =============================================================================================
@@ -318,20 +341,6 @@ __global__ void tr_drop_bwd(float* x, size_t n, unsigned long long seed, unsigne
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= tr_drop_scale(seed, site, i, p);
 }
-__global__ void tr_add_inplace(float* x, const float* y, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] += y[i];
-}
-// out[n] += sum over rows of x[r][n]   (column sums; rows split over blockIdx.y, atomics between splits)
-__global__ __launch_bounds__(256) void tr_colsum(const float* x, long long ld, int R, int N, float* out, int rows_per) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += x[r * ld + n];
-  atomicAdd(out + n, s);
-}
-
 // =============================================================================================
 // derived per-step weights of a block and their gradients
 // =============================================================================================
@@ -366,35 +375,36 @@ __global__ void tr_prep_kernel(const float* plog, const float* in_w, const float
   }
 }
 
-// gradients of the stored parameters from those of the derived ones (one workgroup of 128 threads per block)
-__global__ __launch_bounds__(128) void tr_unprep_kernel(const float* plog, const float* in_w, const float* in_b,
-                                                        const float* lam, const float* dwi, const float* dbi,
-                                                        const float* dwo, const float* dbo, const float* dlam,
-                                                        float* g_plog, float* g_in_w, float* g_in_b, float* g_out_w,
-                                                        float* g_out_b) {
-  const int c = threadIdx.x;  // complex channel
+// gradients of the stored parameters from those of the derived ones: workgroup = complex channel c, thread = k / o
+__global__ __launch_bounds__(64) void tr_unprep_kernel(const float* plog, const float* in_w, const float* in_b,
+                                                       const float* lam, const float* dwi, const float* dbi,
+                                                       const float* dwo, const float* dbo, const float* dlam,
+                                                       float* g_plog, float* g_in_w, float* g_in_b, float* g_out_w,
+                                                       float* g_out_b) {
+  const int c = blockIdx.x, k = threadIdx.x;
   const float nu = expf(plog[c]), th = expf(plog[128 + c]), ga = expf(plog[256 + c]);
-  float dga = in_b[2 * c] * dbi[c] + in_b[2 * c + 1] * dbi[128 + c];
-  for (int k = 0; k < 64; ++k) {
-    const float dre = dwi[c * 64 + k], dim = dwi[(128 + c) * 64 + k];
-    dga += in_w[2 * (c * 64 + k)] * dre + in_w[2 * (c * 64 + k) + 1] * dim;
-    g_in_w[2 * (c * 64 + k)] = ga * dre;
-    g_in_w[2 * (c * 64 + k) + 1] = ga * dim;
-  }
-  g_in_b[2 * c] = ga * dbi[c];
-  g_in_b[2 * c + 1] = ga * dbi[128 + c];
-  const float lr_ = lam[c], li = lam[128 + c], dr = dlam[c], di = dlam[128 + c];
-  // d/d nu = -Re(dlam conj(lam)); d/d theta = Re(dlam conj(i lam)) = dr*(-li) + di*lr
-  g_plog[c] = -(dr * lr_ + di * li) * nu;
-  g_plog[128 + c] = (-dr * li + di * lr_) * th;
-  g_plog[256 + c] = dga * ga;
-  for (int o = 0; o < 64; ++o) {
-    g_out_w[2 * (o * 128 + c)] = dwo[o * 256 + c];
-    g_out_w[2 * (o * 128 + c) + 1] = -dwo[o * 256 + 128 + c];
-  }
-  if (c < 64) {
-    g_out_b[2 * c] = dbo[c];
-    g_out_b[2 * c + 1] = 0.f;
+  const float dre = dwi[c * 64 + k], dim = dwi[(128 + c) * 64 + k];
+  float dga = in_w[2 * (c * 64 + k)] * dre + in_w[2 * (c * 64 + k) + 1] * dim;
+  g_in_w[2 * (c * 64 + k)] = ga * dre;
+  g_in_w[2 * (c * 64 + k) + 1] = ga * dim;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) dga += __shfl_xor(dga, s, 64);
+  const int o = k;  // out_w[o][c]
+  g_out_w[2 * (o * 128 + c)] = dwo[o * 256 + c];
+  g_out_w[2 * (o * 128 + c) + 1] = -dwo[o * 256 + 128 + c];
+  if (k == 0) {
+    dga += in_b[2 * c] * dbi[c] + in_b[2 * c + 1] * dbi[128 + c];
+    g_in_b[2 * c] = ga * dbi[c];
+    g_in_b[2 * c + 1] = ga * dbi[128 + c];
+    const float lr_ = lam[c], li = lam[128 + c], dr = dlam[c], di = dlam[128 + c];
+    // d/d nu = -Re(dlam conj(lam)); d/d theta = Re(dlam conj(i lam)) = dr*(-li) + di*lr
+    g_plog[c] = -(dr * lr_ + di * li) * nu;
+    g_plog[128 + c] = (-dr * li + di * lr_) * th;
+    g_plog[256 + c] = dga * ga;
+    if (c < 64) {
+      g_out_b[2 * c] = dbo[c];
+      g_out_b[2 * c + 1] = 0.f;
+    }
   }
 }
 
@@ -813,17 +823,16 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
   hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, h->scal);
   LR_CHECK_LAUNCH("tr_count_valid");
   float* dx = ws.d64b;
+  LR_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)R * 64 * sizeof(float), st));  // its GEMM splits K = V+1 with atomic adds
   for (int r0 = 0; r0 < R; r0 += ws.rows_chunk) {
     const int rc = (R - r0 < ws.rows_chunk) ? R - r0 : ws.rows_chunk;
     const float* xf = x + (size_t)r0 * 64;
     TR_RUN(tr_gemm(xf, 64, 1, P + lay.emb, 1, 64, ws.logits, C, P + lay.bias, rc, C, 64, 0, st));  // scores (model/lru.py:85)
     hipLaunchKernelGGL(tr_ce_kernel, dim3(rc), dim3(256), 0, st, ws.logits, (long long)C, C, lab + r0, h->scal);
     LR_CHECK_LAUNCH("tr_ce_kernel");
-    TR_RUN(tr_gemm(ws.logits, C, 1, P + lay.emb, 64, 1, dx + (size_t)r0 * 64, 64, nullptr, rc, 64, C, 0, st));  // d x
-    TR_RUN(tr_gemm(ws.logits, 1, C, xf, 64, 1, G + lay.emb, 64, nullptr, C, 64, rc, 1, st));                     // d table
-    hipLaunchKernelGGL(tr_colsum, dim3((C + 255) / 256, (rc + 255) / 256), dim3(256), 0, st, ws.logits, (long long)C, rc,
-                       C, G + lay.bias, 256);
-    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_gemm(ws.logits, C, 1, P + lay.emb, 64, 1, dx + (size_t)r0 * 64, 64, nullptr, rc, 64, C, 1, st, true));  // d x
+    // d table += d logits^T x, and d bias += column sums of d logits (the row sums of the A operand)
+    TR_RUN(tr_gemm(ws.logits, 1, C, xf, 64, 1, G + lay.emb, 64, nullptr, C, 64, rc, 1, st, true, G + lay.bias));
   }
   hipLaunchKernelGGL(tr_finish_loss, dim3(1), dim3(1), 0, st, h->scal, out_loss);
   LR_CHECK_LAUNCH("tr_finish_loss");
@@ -842,14 +851,10 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
     // dy (residual branch) = dz0; the W2 branch sees dropout(dz0)
     LR_CHECK_HIP(hipMemcpyAsync(dx, dz0, (size_t)R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));  // dx now = dy partial
     if (pd > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dz0, (size_t)R * 64, seed, 12u + 4u * b, pd);
-    TR_RUN(tr_linear_bwd_weight(dz0, W.g, G + o.w2, R, 64, 256, 0, st));
-    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, dz0, 64LL, R, 64, G + o.b2, 256);
-    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_weight(dz0, W.g, G + o.w2, G + o.b2, R, 64, 256, st));
     TR_RUN(tr_linear_bwd_data(dz0, P + o.w2, ws.d256, R, 64, 256, 0, st));  // d g
     TR_EW(tr_gelu_bwd, (size_t)R * 256, W.a, ws.d256, (size_t)R * 256, seed, 11u + 4u * b, pd);  // -> d a
-    TR_RUN(tr_linear_bwd_weight(ws.d256, W.y, G + o.w1, R, 256, 64, 0, st));
-    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, ws.d256, 256LL, R, 256, G + o.b1, 256);
-    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_weight(ws.d256, W.y, G + o.w1, G + o.b1, R, 256, 64, st));
     TR_RUN(tr_linear_bwd_data(ws.d256, P + o.w1, dx, R, 256, 64, 1, st));  // dy += da W1
     // LN1: dy -> dy0 (gradient of dropout(o) + x)
     float* dy0 = ws.d64a;
@@ -859,18 +864,14 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
     LR_CHECK_HIP(hipMemcpyAsync(dx, dy0, (size_t)R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));  // residual: dx_in = dy0 + ...
     if (pa > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dy0, (size_t)R * 64, seed, 10u + 4u * b, pa);
     // out_proj (derived real form [64][256] over (Re h | Im h))
-    TR_RUN(tr_linear_bwd_weight(dy0, W.h, D + W.d.dwo, R, 64, 256, 0, st));
-    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, dy0, 64LL, R, 64, D + W.d.dbo, 256);
-    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_weight(dy0, W.h, D + W.d.dwo, D + W.d.dbo, R, 64, 256, st));
     TR_RUN(tr_linear_bwd_data(dy0, D + W.d.wo, ws.d256, R, 64, 256, 0, st));  // g_t = direct gradient of h_t
     hipLaunchKernelGGL(tr_scan_bwd, dim3(B), dim3(128), 0, st, ws.d256, W.h, ids, D + W.d.lam, D + W.d.dlam, L);
     LR_CHECK_LAUNCH("tr_scan_bwd");
     // in_proj (derived, gamma folded): du in d256
-    TR_RUN(tr_linear_bwd_weight(ws.d256, xin, D + W.d.dwi, R, 256, 64, 0, st));
-    hipLaunchKernelGGL(tr_colsum, dim3(1, (R + 255) / 256), dim3(256), 0, st, ws.d256, 256LL, R, 256, D + W.d.dbi, 256);
-    LR_CHECK_LAUNCH("tr_colsum");
+    TR_RUN(tr_linear_bwd_weight(ws.d256, xin, D + W.d.dwi, D + W.d.dbi, R, 256, 64, st));
     TR_RUN(tr_linear_bwd_data(ws.d256, D + W.d.wi, dx, R, 256, 64, 1, st));  // dx_in += du Wi
-    hipLaunchKernelGGL(tr_unprep_kernel, dim3(1), dim3(128), 0, st, P + o.plog, P + o.in_w, P + o.in_b, D + W.d.lam,
+    hipLaunchKernelGGL(tr_unprep_kernel, dim3(128), dim3(64), 0, st, P + o.plog, P + o.in_w, P + o.in_b, D + W.d.lam,
                        D + W.d.dwi, D + W.d.dbi, D + W.d.dwo, D + W.d.dbo, D + W.d.dlam, G + o.plog, G + o.in_w, G + o.in_b,
                        G + o.out_w, G + o.out_b);
     LR_CHECK_LAUNCH("tr_unprep_kernel");
