@@ -1,7 +1,7 @@
-"""Flags of the scoring path, with the reference's names and defaults (config.py:151-274 and the
-per-dataset defaults of set_template, :12-148). Parsed only when an entry point asks (the
-reference parses sys.argv at import, config.py:274, and may block on input(), :13-27 -- neither
-is reproduced). Training-only flags are accepted and ignored so existing command lines keep working.
+"""Flags of the scoring path and of retriever training, with the reference's names and defaults
+(config.py:151-274 and the per-dataset defaults of set_template, :12-148). Parsed only when an entry point
+asks (the reference parses sys.argv at import, config.py:274, and may block on input(), :13-27 -- neither
+is reproduced). Ranker-training flags are accepted and ignored so existing command lines keep working.
 """
 from __future__ import annotations
 
@@ -44,6 +44,27 @@ def build_parser():
     p.add_argument("--export_root", type=str, default=None)
     p.add_argument("--llm_adapter_path", type=str, default=None, help="local PEFT adapter directory")
     p.add_argument("--synthetic", action="store_true", help="fabricate dataset / weights (nothing exists offline)")
+    # retriever training (config.py:166-202,216-217; defaults filled in set_template like config.py:103-134)
+    p.add_argument("--train_batch_size", type=int, default=None)
+    p.add_argument("--sliding_window_size", type=float, default=1.0)
+    p.add_argument("--num_epochs", type=int, default=500)
+    p.add_argument("--lr", type=float, default=None)
+    p.add_argument("--weight_decay", type=float, default=None)
+    p.add_argument("--adam_epsilon", type=float, default=1e-9)
+    p.add_argument("--max_grad_norm", type=float, default=5.0)
+    p.add_argument("--enable_lr_schedule", action="store_true")
+    p.add_argument("--enable_lr_warmup", action="store_true")
+    p.add_argument("--warmup_steps", type=int, default=100)
+    p.add_argument("--decay_step", type=int, default=10000)
+    p.add_argument("--gamma", type=float, default=1.0)
+    p.add_argument("--val_strategy", type=str, default=None, choices=["epoch", "iteration"])
+    p.add_argument("--val_iterations", type=int, default=500)
+    p.add_argument("--early_stopping_patience", type=int, default=None)
+    p.add_argument("--best_metric", type=str, default=None)
+    p.add_argument("--bert_dropout", type=float, default=0.2)
+    p.add_argument("--bert_attn_dropout", type=float, default=0.2)
+    p.add_argument("--eval_only", action="store_true", help="skip training (a checkpoint must exist)")
+    p.add_argument("--max_train_iterations", type=int, default=None, help="stop after this many optimizer steps")
     return p
 
 
@@ -54,6 +75,18 @@ def set_template(args):
         args.bert_max_len = 200 if ml else 50
     if args.bert_num_blocks is None:
         args.bert_num_blocks = 2
+    if args.train_batch_size is None:                      # config.py:103-107
+        args.train_batch_size = 16 if ml else 64
+    if args.lr is None:                                    # config.py:121-124
+        args.lr = 1e-3
+    if args.weight_decay is None:
+        args.weight_decay = 1e-2
+    if args.val_strategy is None:                          # config.py:76-79
+        args.val_strategy = "iteration"
+    if args.early_stopping_patience is None:
+        args.early_stopping_patience = 20
+    if args.best_metric is None:                           # config.py:140-141
+        args.best_metric = "Recall@10"
     if args.metric_ks is None:
         args.metric_ks = [1, 5, 10, 20, 50]
     if args.rerank_metric_ks is None:

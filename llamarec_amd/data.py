@@ -55,6 +55,51 @@ def lru_eval_arrays(dataset, mode, max_len):
         np.asarray(labels, dtype=np.int64).reshape(len(users), 1)
 
 
+def lru_train_sequences(dataset, max_len, sliding_window_size=1.0):
+    """LRUTrainDataset.__init__ (dataloader/lru.py:92-112): users in sorted order; a sequence shorter than
+    max_len + step is one sample, a longer one is cut into windows of max_len taken from the END backwards
+    with step int(sliding_window_size * max_len)."""
+    step = int(sliding_window_size * max_len)
+    assert step > 0
+    out = []
+    u2seq = dataset["train"]
+    for u in sorted(u2seq.keys()):
+        seq = list(u2seq[u])
+        if len(seq) < max_len + step:
+            out.append(seq)
+        else:
+            out.extend(seq[i:i + max_len] for i in range(len(seq) - max_len, -1, -step))
+    return out
+
+
+def lru_train_batch(seqs, max_len):
+    """LRUTrainDataset.__getitem__ (dataloader/lru.py:117-131) for a list of samples: tokens = seq[:-1][-L:],
+    labels = seq[-L:], both left-padded with 0 -> int64 [B, L] x 2. A sample of <= L items therefore has one pad
+    position that carries a label (its first item)."""
+    B = len(seqs)
+    tokens = np.zeros((B, max_len), np.int64)
+    labels = np.zeros((B, max_len), np.int64)
+    for i, seq in enumerate(seqs):
+        lab = seq[-max_len:]
+        tok = seq[:-1][-max_len:]
+        if tok:
+            tokens[i, max_len - len(tok):] = tok
+        labels[i, max_len - len(lab):] = lab
+    return tokens, labels
+
+
+def train_batches(all_seqs, batch_size, max_len, rng, rank=0, world=1):
+    """One epoch of shuffled training batches (DataLoader(shuffle=True), dataloader/lru.py:52-60; the order comes
+    from `rng`, torch's sampler stream is not reproduced). With world > 1 every rank sees the same permutation and
+    takes its contiguous share of each global batch."""
+    order = rng.permutation(len(all_seqs))
+    for i in range(0, len(order), batch_size * world):
+        idx = order[i + rank * batch_size:i + (rank + 1) * batch_size]
+        if len(idx) == 0:
+            idx = order[i:i + 1]          # keep ranks in lock-step on a ragged tail
+        yield lru_train_batch([all_seqs[j] for j in idx], max_len)
+
+
 def batches(ids, labels, batch_size):
     """Unshuffled eval batches (dataloader/lru.py:74: shuffle=False keeps user ids positional)."""
     for i in range(0, len(ids), batch_size):

@@ -139,12 +139,36 @@ class LRUTrainEngine:
         return self._named(self.grads)
 
 
-class LRUTrainer:
-    """Mirror of the reference's LRUTrainer training surface (trainer/lru.py:13-28, trainer/base.py:60-132):
-    `calculate_loss(batch)` and `train_one_epoch`-style stepping; evaluation/candidate generation stay with
-    llamarec_amd.retrieve.LRUEvaluator (they run on the exported weights)."""
+def average_gradients_(flat: torch.Tensor) -> torch.Tensor:
+    """Data-parallel gradient exchange: ONE all-reduce of the flat gradient buffer (RCCL over xGMI with backend
+    "nccl", gloo in the CPU tests), then the mean -- what DDP does bucket by bucket for the reference. No-op for a
+    single process."""
+    import torch.distributed as dist
 
-    def __init__(self, args, state_dict=None, device="cuda:0"):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
+    return flat
+
+
+def lr_lambda_from_args(args, num_training_steps=None):
+    """The reference's optional schedules (trainer/base.py:45-57,248-260): linear warm-up + linear decay, or StepLR."""
+    if not getattr(args, "enable_lr_schedule", False):
+        return None
+    if getattr(args, "enable_lr_warmup", False):
+        w, n = args.warmup_steps, max(int(num_training_steps or 0), args.warmup_steps + 1)
+        return lambda it: it / max(1, w) if it < w else max(0.0, (n - it) / max(1, n - w))
+    return lambda it: args.gamma ** (it // args.decay_step)
+
+
+class LRUTrainer:
+    """Mirror of the reference's LRUTrainer training surface (trainer/lru.py:13-28, trainer/base.py:60-154,
+    trainer/loggers.py:102-125): `calculate_loss(batch)`, `train()` with validation every `val_iterations`
+    optimizer steps (or every epoch), best-`best_metric` checkpointing to models/best_acc_model.pth and early
+    stopping after `early_stopping_patience` validations without improvement. Validation itself is the scoring
+    path (llamarec_amd.retrieve.LRUEvaluator on the exported weights, history not masked: trainer/base.py:141-143)."""
+
+    def __init__(self, args, state_dict=None, device="cuda:0", export_root=None, rank=0, world=1):
         from .lru import init_lru_state_dict
 
         self.args = args
@@ -154,24 +178,79 @@ class LRUTrainer:
             state_dict, lr=getattr(args, "lr", 1e-3), weight_decay=getattr(args, "weight_decay", 1e-2),
             eps=getattr(args, "adam_epsilon", 1e-9), max_grad_norm=getattr(args, "max_grad_norm", 5.0),
             dropout=getattr(args, "bert_dropout", 0.2), attn_dropout=getattr(args, "bert_attn_dropout", 0.2),
-            seed=getattr(args, "seed", 42), device=device)
+            seed=getattr(args, "seed", 42) + 7919 * rank, device=device)
+        self.device = device
+        self.export_root = export_root
+        self.rank, self.world = rank, world
         self.iterations = 0
+        self.best_metric, self.patience_counter = 0.0, 0
+        self.history = []
 
     def calculate_loss(self, batch):
         seqs, labels = batch
         return self.engine.loss_and_grads(seqs, labels)
 
-    def train_one_epoch(self, batches, all_reduce=None, lr_lambda=None):
-        """batches: iterable of (tokens, labels). Returns the mean loss (host float), like the reference's
-        AverageMeterSet over the epoch (trainer/base.py:86-118)."""
+    def train_one_epoch(self, batches, lr_lambda=None, validate=None):
+        """batches: iterable of (tokens, labels). Returns (mean loss, stop flag) -- trainer/base.py:98-132."""
         total, n = 0.0, 0
+        reduce_ = average_gradients_ if self.world > 1 else None
+        max_it = getattr(self.args, "max_train_iterations", None)
         for tokens, labels in batches:
             lr = self.engine.lr * (lr_lambda(self.iterations) if lr_lambda else 1.0)
-            loss = self.engine.train_step(tokens, labels, lr=lr, all_reduce=all_reduce)
+            loss = self.engine.train_step(tokens, labels, lr=lr, all_reduce=reduce_)
             total += float(loss)
             n += 1
             self.iterations += 1
-        return total / max(n, 1)
+            if validate and getattr(self.args, "val_strategy", "iteration") == "iteration" and \
+                    self.iterations % self.args.val_iterations == 0 and validate():
+                return total / max(n, 1), True
+            if max_it and self.iterations >= max_it:
+                return total / max(n, 1), True
+        return total / max(n, 1), False
+
+    def _log_val(self, metrics):
+        """BestModelLogger.log + LoggerService.log_val (trainer/loggers.py:26-35,116-125): True = stop."""
+        cur = metrics.get(getattr(self.args, "best_metric", "Recall@10"), 0.0)
+        self.history.append(dict(iteration=self.iterations, **metrics))
+        if self.best_metric < cur:
+            self.best_metric, self.patience_counter = cur, 0
+            if self.export_root and self.rank == 0:
+                import os
+
+                os.makedirs(os.path.join(self.export_root, "models"), exist_ok=True)
+                sd = {k: torch.from_numpy(v) for k, v in self.engine.state_dict().items()}
+                torch.save({"model_state_dict": sd}, os.path.join(self.export_root, "models", "best_acc_model.pth"))
+        else:
+            self.patience_counter += 1
+        return self.patience_counter >= getattr(self.args, "early_stopping_patience", 20)
+
+    def validate(self, val_loader):
+        from .lru import LRURec
+        from .retrieve import LRUEvaluator
+
+        model = LRURec.from_state_dict(self.engine.state_dict(), device=self.device)
+        metrics = LRUEvaluator(self.args, model, val_loader, []).validate()
+        return self._log_val(metrics)
+
+    def train(self, all_seqs, val_loader, rng=None):
+        """trainer/base.py:60-82: validate, then epochs of shuffled batches until early stopping / num_epochs."""
+        from . import data as D
+
+        rng = rng or np.random.default_rng(getattr(self.args, "seed", 42))
+        L, bs = self.args.bert_max_len, self.args.train_batch_size
+        steps_per_epoch = (len(all_seqs) + bs * self.world - 1) // (bs * self.world)
+        lr_lambda = lr_lambda_from_args(self.args, steps_per_epoch * self.args.num_epochs)
+        val = (lambda: self.validate(val_loader)) if val_loader is not None else None
+        stop = val() if val else False
+        losses = []
+        for _epoch in range(self.args.num_epochs):
+            if stop:
+                break
+            loss, stop = self.train_one_epoch(D.train_batches(all_seqs, bs, L, rng, self.rank, self.world), lr_lambda, val)
+            losses.append(loss)
+            if not stop and val and self.args.val_strategy == "epoch":
+                stop = val()
+        return losses
 
     def state_dict(self):
         return self.engine.state_dict()

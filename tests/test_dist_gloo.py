@@ -83,3 +83,56 @@ def test_shard_ranges_cover_users_contiguously():
             assert edges[0][0] == 0 and edges[-1][1] == U
             assert all(edges[i][1] == edges[i + 1][0] for i in range(W - 1))
             assert max(h - l for l, h in edges) - min(h - l for l, h in edges) <= 1
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from llamarec_amd import data as D
+    from llamarec_amd import dist as DD
+    from llamarec_amd.train import average_gradients_
+
+    r, w, _ = DD.init_from_env(backend="gloo")
+    # every rank draws the same permutation and takes its contiguous share of each global batch
+    seqs = [[(u + i) % 50 + 1 for i in range(3 + u % 9)] for u in range(37)]
+    mine = [(t.copy(), l.copy()) for t, l in D.train_batches(seqs, 4, 8, np.random.default_rng(5), r, w)]
+    # "gradients": rank-dependent flat buffer -> mean over ranks after ONE all-reduce
+    g = torch.arange(10, dtype=torch.float32) * (r + 1)
+    average_gradients_(g)
+    DD.barrier()
+    q.put((r, mine, g.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_shards_batches_and_averages_gradients():
+    """Retriever training under data parallelism (train_retriever.py under torchrun): batch sharding and the
+    one-buffer gradient average, on CPU over gloo."""
+    sys.path.insert(0, REPO)
+    from llamarec_amd import data as D
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (m, g)) for r, m, g in (q.get(timeout=120) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(got[0][1], np.arange(10) * 1.5) and np.allclose(got[1][1], got[0][1])
+    seqs = [[(u + i) % 50 + 1 for i in range(3 + u % 9)] for u in range(37)]
+    single = list(D.train_batches(seqs, 8, 8, np.random.default_rng(5)))      # one rank, global batch 8
+    assert len(got[0][0]) == len(got[1][0]) == len(single)
+    for (t0, l0), (t1, l1), (ts, ls) in zip(got[0][0], got[1][0], single):
+        if len(ts) == 8:
+            assert np.array_equal(np.concatenate([t0, t1]), ts) and np.array_equal(np.concatenate([l0, l1]), ls)
+    # LRUTrainDataset semantics: a short sequence has ONE labelled pad position
+    t, l = D.lru_train_batch([[5, 6, 7]], 8)
+    assert t.tolist() == [[0, 0, 0, 0, 0, 0, 5, 6]] and l.tolist() == [[0, 0, 0, 0, 0, 5, 6, 7]]
+    t, l = D.lru_train_batch([list(range(1, 12))], 8)
+    assert t.tolist() == [[3, 4, 5, 6, 7, 8, 9, 10]] and l.tolist() == [[4, 5, 6, 7, 8, 9, 10, 11]]
+    # sliding windows from the end (dataloader/lru.py:103-110)
+    ds = {"train": {1: list(range(1, 30)), 2: [1, 2, 3]}}
+    assert D.lru_train_sequences(ds, 8, 1.0) == [list(range(22, 30)), list(range(14, 22)), list(range(6, 14)), [1, 2, 3]]

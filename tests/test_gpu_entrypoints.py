@@ -6,6 +6,7 @@ import pickle
 from types import SimpleNamespace
 
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +54,9 @@ def test_entry_points_synthetic(tmp_path):
     import train_retriever
 
     lru_root = str(tmp_path / "experiments" / "lru" / "synthetic")
-    out = train_retriever.main(["--dataset_code", "synthetic", "--synthetic", "--export_root", lru_root])
+    out = train_retriever.main(["--dataset_code", "synthetic", "--synthetic", "--export_root", lru_root,
+                                "--max_train_iterations", "30", "--val_iterations", "10"])
+    assert os.path.exists(os.path.join(lru_root, "models", "best_acc_model.pth"))   # trainer/loggers.py:121
     assert os.path.exists(os.path.join(lru_root, "test_metrics.json"))
     r = pickle.load(open(os.path.join(lru_root, "retrieved.pkl"), "rb"))
     assert set(r) == {"val_metrics", "val_users", "val_candidates", "test_probs", "test_labels", "test_metrics",
@@ -70,6 +73,45 @@ def test_entry_points_synthetic(tmp_path):
     assert sub["test_loss"] == -1.0 and set(ov) == {f"test_{m}@{k}" for m in ("Recall", "MRR", "NDCG") for k in (1, 5, 10)}
     n_ret, n_all = r["test_retrieval"]["retrieval_size"], r["test_retrieval"]["original_size"]
     assert abs(ov["test_Recall@10"] - sub["test_Recall@10"] * n_ret / n_all) < 1e-12
+
+
+def test_retriever_training_learns_and_checkpoints(tmp_path):
+    """train_retriever's training half end to end on a learnable synthetic dataset (each user walks the item ids
+    upwards): Recall@10 on the held-out next item goes from chance to high, the best checkpoint is written in the
+    reference's format and the scoring path reloads it."""
+    from types import SimpleNamespace
+
+    from llamarec_amd import data as D
+    from llamarec_amd.lru import LRURec
+    from llamarec_amd.retrieve import LRUEvaluator
+    from llamarec_amd.train import LRUTrainer
+
+    V, U, L = 150, 256, 12
+    rng = np.random.default_rng(0)
+    train, val, test = {}, {}, {}
+    for u in range(1, U + 1):
+        start, n = int(rng.integers(0, V)), int(rng.integers(6, 15))
+        seq = [(start + i) % V + 1 for i in range(n)]
+        train[u], val[u], test[u] = seq[:-2], seq[-2:-1], seq[-1:]
+    ds = {"train": train, "val": val, "test": test, "umap": {u: u for u in train}, "smap": {i: i for i in range(1, V + 1)}}
+    args = SimpleNamespace(num_items=V, bert_max_len=L, bert_num_blocks=2, train_batch_size=64, val_batch_size=64,
+                           lr=3e-3, weight_decay=1e-2, adam_epsilon=1e-9, max_grad_norm=5.0, bert_dropout=0.1,
+                           bert_attn_dropout=0.1, seed=1, num_epochs=60, val_strategy="iteration", val_iterations=40,
+                           early_stopping_patience=50, best_metric="Recall@10", metric_ks=[1, 5, 10],
+                           sliding_window_size=1.0, max_train_iterations=None)
+    root = str(tmp_path / "lru")
+    _, v_ids, v_lab = D.lru_eval_arrays(ds, "val", L)
+    val_loader = list(D.batches(v_ids, v_lab, 64))
+    tr = LRUTrainer(args, export_root=root)
+    losses = tr.train(D.lru_train_sequences(ds, L), val_loader)
+    assert tr.history[0]["Recall@10"] < 0.3 and tr.best_metric > 0.9, (tr.history[0], tr.best_metric)
+    assert losses[-1] < losses[0] - 1.0
+    ckpt = torch.load(os.path.join(root, "models", "best_acc_model.pth"), map_location="cpu", weights_only=False)
+    sd = ckpt["model_state_dict"]
+    assert sd["model.lru_blocks.0.lru_layer.in_proj.weight"].dtype == torch.complex64      # reference dtypes
+    assert tuple(sd["embedding.token.weight"].shape) == (V + 1, 64)
+    again = LRUEvaluator(args, LRURec.from_checkpoint(os.path.join(root, "models", "best_acc_model.pth")), val_loader, []).validate()
+    assert abs(again["Recall@10"] - tr.best_metric) < 1e-9
 
 
 def test_online_single_user_path(golden_dir):

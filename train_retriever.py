@@ -1,10 +1,13 @@
 #!/usr/bin/env python
-"""Entry point compatible with the reference's `python train_retriever.py` for the SCORING half:
-`trainer.test()` and `trainer.generate_candidates(...)` (train_retriever.py:77,80 of the reference).
-Training itself (:76) is outside this implementation's scope: the checkpoint
-experiments/lru/<dataset>/models/best_acc_model.pth must already exist, or pass --synthetic.
+"""Entry point compatible with the reference's `python train_retriever.py` (its :76-80): `trainer.train()`,
+`trainer.test()` and `trainer.generate_candidates(...)`, all on the MI355X kernels (training:
+llamarec_amd/train.py over csrc/lru_train.hip; scoring: llamarec_amd/{lru,retrieve}.py). `--eval_only` skips
+training and needs experiments/lru/<dataset>/models/best_acc_model.pth (as written here or by the reference).
+Under torchrun every rank trains on its share of each global batch and gradients are averaged with one
+all-reduce per step.
 
-Outputs keep the reference layout: experiments/lru/<dataset>/{test_metrics.json, retrieved.pkl}.
+Outputs keep the reference layout: experiments/lru/<dataset>/{models/best_acc_model.pth, test_metrics.json,
+retrieved.pkl}.
 """
 import os
 import sys
@@ -28,14 +31,28 @@ def main(argv=None, export_root=None):
                                                          args.min_uc, args.min_sc))
     args.num_users, args.num_items = len(dataset["umap"]), len(dataset["smap"])
     ckpt = os.path.join(export_root, "models", "best_acc_model.pth")
+    _, v_ids, v_lab = D.lru_eval_arrays(dataset, "val", args.bert_max_len)
+    _, t_ids, t_lab = D.lru_eval_arrays(dataset, "test", args.bert_max_len)
+    if not args.eval_only:
+        from llamarec_amd import dist as DD
+        from llamarec_amd.train import LRUTrainer
+
+        rank, world, local = DD.init_from_env()
+        trainer = LRUTrainer(args, device=f"cuda:{local}", export_root=export_root, rank=rank, world=world)
+        losses = trainer.train(D.lru_train_sequences(dataset, args.bert_max_len, args.sliding_window_size),
+                               list(D.batches(v_ids, v_lab, args.val_batch_size)))
+        if rank == 0:
+            print(f"trained {trainer.iterations} iterations; epoch losses {[round(x, 4) for x in losses[:3]]} ... "
+                  f"{[round(x, 4) for x in losses[-2:]]}; best {args.best_metric} {trainer.best_metric:.4f}")
+        DD.barrier()
+        if rank != 0:
+            return None
     if os.path.exists(ckpt):
         model = LRURec.from_checkpoint(ckpt)
     elif args.synthetic:
         model = LRURec.from_state_dict(init_lru_state_dict(args.num_items, args.seed, args.bert_num_blocks))
     else:
-        raise SystemExit(f"{ckpt} not found: train the retriever with the reference first (or use --synthetic)")
-    _, v_ids, v_lab = D.lru_eval_arrays(dataset, "val", args.bert_max_len)
-    _, t_ids, t_lab = D.lru_eval_arrays(dataset, "test", args.bert_max_len)
+        raise SystemExit(f"{ckpt} not found: train first (drop --eval_only) or use --synthetic")
     ev = LRUEvaluator(args, model, list(D.batches(v_ids, v_lab, args.val_batch_size)),
                       list(D.batches(t_ids, t_lab, args.test_batch_size)), export_root)
     print("******************** Testing Metrics ********************")
