@@ -315,6 +315,11 @@ int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64
  * pre-clipping global norm. */
 int lr_lru_train_apply(lr_lru_train_t* h, float lr, float max_grad_norm, float* out_grad_norm,
                        void* hip_stream);
+/* hipGraph replay: with enable != 0, lr_lru_train_loss_grad and lr_lru_train_apply capture their launch
+ * sequence once per (pointers, B, L) on the caller's stream -- which must not be the default stream -- and
+ * replay it afterwards (one graph launch instead of ~120 kernel launches per step). Pass the same device
+ * buffers every step to stay on the replay path; any change re-captures. */
+int lr_lru_train_set_graph(lr_lru_train_t* h, int32_t enable);
 /* Device pointers of the flat parameter / gradient buffers and their length in floats. */
 int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_t* count);
 /* Offset and length (floats) of a parameter inside those buffers, by its reference state_dict name,

@@ -116,10 +116,14 @@ struct lr_lru_train {
   LrLruTrainConfig cfg;
   float *p, *g, *m, *v;  // flat buffers [total]
   unsigned char* decay;  // [total] 1 = decoupled weight decay applies
-  float* scal;           // [8] device scalars: 0 loss sum, 1 n_valid, 2 grad norm^2
-  long long step;        // optimizer steps taken
-  long long fwd_calls;   // forward passes (dropout stream position)
+  float* scal;              // [8] device scalars: 0 loss sum, 1 n_valid, 2 grad norm^2, 4 lr, 5 clip limit
+  unsigned long long* ctr;  // [4] device counters: optimizer steps, forward passes, current dropout seed
   int device;
+  // optional hipGraph replay of the two launch sequences (keyed by every pointer and shape baked into them)
+  int use_graph;
+  hipGraphExec_t g_fb, g_opt;
+  const void *k_tok, *k_lab, *k_out, *k_ws, *k_norm;
+  int k_B, k_L;
 };
 
 // =============================================================================================
@@ -264,7 +268,8 @@ __device__ __forceinline__ float tr_wave_sum(float v) {
 // x = LN(dropout(E[id])): saves xhat and rstd
 __global__ __launch_bounds__(256) void tr_embed_ln_fwd(const long long* ids, const float* E, int V, const float* w,
                                                        const float* b, float* x, float* xhat, float* rstd, int R,
-                                                       unsigned long long seed, float p) {
+                                                       const unsigned long long* seedp, float p) {
+  const unsigned long long seed = *seedp;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   long long id = ids[row];
@@ -282,7 +287,8 @@ __global__ __launch_bounds__(256) void tr_embed_ln_fwd(const long long* ids, con
 // y = LN(dropout(o) + res)
 __global__ __launch_bounds__(256) void tr_res_ln_fwd(const float* o, const float* res, const float* w, const float* b,
                                                      float* y, float* xhat, float* rstd, int R,
-                                                     unsigned long long seed, unsigned site, float p) {
+                                                     const unsigned long long* seedp, unsigned site, float p) {
+  const unsigned long long seed = *seedp;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const size_t i = (size_t)row * 64 + lane;
@@ -323,13 +329,15 @@ __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* x
 }
 
 // g = dropout(gelu(a)) elementwise; backward: da = dg * mask * gelu'(a)
-__global__ void tr_gelu_fwd(const float* a, float* g, size_t n, unsigned long long seed, unsigned site, float p) {
+__global__ void tr_gelu_fwd(const float* a, float* g, size_t n, const unsigned long long* seedp, unsigned site, float p) {
+  const unsigned long long seed = *seedp;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = a[i];
   g[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)) * tr_drop_scale(seed, site, i, p);
 }
-__global__ void tr_gelu_bwd(const float* a, float* dg_to_da, size_t n, unsigned long long seed, unsigned site, float p) {
+__global__ void tr_gelu_bwd(const float* a, float* dg_to_da, size_t n, const unsigned long long* seedp, unsigned site, float p) {
+  const unsigned long long seed = *seedp;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = a[i];
@@ -337,7 +345,8 @@ __global__ void tr_gelu_bwd(const float* a, float* dg_to_da, size_t n, unsigned 
   dg_to_da[i] = dg_to_da[i] * tr_drop_scale(seed, site, i, p) * d;
 }
 // x *= dropout mask (backward of a dropout whose forward was fused elsewhere)
-__global__ void tr_drop_bwd(float* x, size_t n, unsigned long long seed, unsigned site, float p) {
+__global__ void tr_drop_bwd(float* x, size_t n, const unsigned long long* seedp, unsigned site, float p) {
+  const unsigned long long seed = *seedp;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= tr_drop_scale(seed, site, i, p);
 }
@@ -507,6 +516,27 @@ __global__ __launch_bounds__(256) void tr_ce_kernel(float* logits, long long ld,
   }
   if (threadIdx.x == 0) atomicAdd(scal, logf(se) + mx - picked);
 }
+// device-side counters (so that a captured graph can be replayed): ctr[0] optimizer steps, ctr[1] forward passes,
+// ctr[2] dropout seed of the current pass
+__global__ void tr_begin_pass(unsigned long long* ctr, unsigned long long seedbase) {
+  ctr[2] = seedbase + ctr[1] * 0xA24BAED4963EE407ull;
+  ctr[1] += 1;
+}
+// zero / copy as kernels, not hipMemsetAsync / hipMemcpyAsync: under stream capture those become memset / memcpy
+// graph nodes, and a replayed graph then ran them out of order with the neighbouring kernels (wrong gradients
+// from the second step on); kernel nodes keep the captured stream order
+__global__ void tr_zero_kernel(float* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+__global__ void tr_copy_kernel(float* dst, const float* src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+__global__ void tr_set_step_scalars(float* scal, float lr, float max_norm) {
+  scal[4] = lr;
+  scal[5] = max_norm;
+}
 __global__ void tr_finish_loss(float* scal, float* out) {
   out[0] = scal[0] / fmaxf(scal[1], 1.0f);
   out[1] = scal[1];
@@ -514,7 +544,8 @@ __global__ void tr_finish_loss(float* scal, float* out) {
 
 // embedding backward: dE[id] += de[row]
 __global__ __launch_bounds__(256) void tr_embed_bwd(const float* de, const long long* ids, int V, float* dE, int R,
-                                                    unsigned long long seed, float p) {
+                                                    const unsigned long long* seedp, float p) {
+  const unsigned long long seed = *seedp;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   long long id = ids[row];
@@ -525,18 +556,22 @@ __global__ __launch_bounds__(256) void tr_embed_bwd(const float* de, const long 
 // =============================================================================================
 // optimizer
 // =============================================================================================
-__global__ __launch_bounds__(256) void tr_sumsq_kernel(const float* g, size_t n, float* out) {
+__global__ __launch_bounds__(256) void tr_sumsq_kernel(const float* g, size_t n, float* out, unsigned long long* ctr) {
   __shared__ float sh[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr[0] += 1;  // this optimizer step's number, read by tr_adamw_kernel
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
   s = tr_block_reduce(s, false, sh);
   if (threadIdx.x == 0) atomicAdd(out, s);
 }
+// scal[2] = sum of squared gradients, scal[4] = learning rate, scal[5] = clipping limit of this step
 __global__ void tr_adamw_kernel(float* p, const float* g, float* m, float* v, const unsigned char* decay, size_t n,
-                                const float* scal, float max_norm, float lr, float wd, float b1, float b2, float eps,
-                                float bc1, float bc2_sqrt, float* out_norm) {
+                                const float* scal, const unsigned long long* ctr, float wd, float b1, float b2,
+                                float eps, float* out_norm) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float norm = sqrtf(scal[2]);
+  const float norm = sqrtf(scal[2]), lr = scal[4], max_norm = scal[5];
+  const float t = (float)ctr[0];
+  const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
   if (i == 0 && out_norm) *out_norm = norm;
   if (i >= n) return;
   const float coef = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
@@ -631,7 +666,7 @@ static TrWs tr_carve(const TrLayout& lay, int R, char* base) {
 extern "C" size_t lr_lru_train_state_bytes(int32_t num_items, int32_t num_blocks) {
   if (num_items < 1 || num_blocks < 1 || num_blocks > LR_MAX_LRU_BLOCKS) return 0;
   const size_t n = tr_layout(num_items, num_blocks).total;
-  return 4 * n * sizeof(float) + lr_align_up(n, 256) + 256;
+  return 4 * n * sizeof(float) + lr_align_up(n, 256) + 256;  // + decay mask + 8 float scalars + 4 counters
 }
 
 static int tr_find(const TrLayout& L, const char* name, TrSeg* out) {
@@ -676,6 +711,7 @@ extern "C" int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrai
   h->v = h->m + n;
   h->decay = (unsigned char*)(h->v + n);
   h->scal = (float*)(h->decay + lr_align_up(n, 256));
+  h->ctr = (unsigned long long*)(h->scal + 8);
   LR_CHECK_HIP(hipGetDevice(&h->device));
   // host image of the parameters and the decay mask, one upload each
   float* img = (float*)calloc(n, sizeof(float));
@@ -718,7 +754,7 @@ extern "C" int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrai
   hipError_t e1 = hipMemcpy(h->p, img, n * sizeof(float), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemcpy(h->decay, dec, n, hipMemcpyHostToDevice);
   hipError_t e3 = hipMemset(h->g, 0, 3 * n * sizeof(float));
-  hipError_t e4 = hipMemset(h->scal, 0, 8 * sizeof(float));
+  hipError_t e4 = hipMemset(h->scal, 0, 8 * sizeof(float) + 4 * sizeof(unsigned long long));
   free(img);
   free(dec);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
@@ -729,7 +765,24 @@ extern "C" int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrai
   return LR_OK;
 }
 
-extern "C" void lr_lru_train_destroy(lr_lru_train_t* h) { free(h); }
+static void tr_drop_graphs(lr_lru_train* h) {
+  if (h->g_fb) (void)hipGraphExecDestroy(h->g_fb);
+  if (h->g_opt) (void)hipGraphExecDestroy(h->g_opt);
+  h->g_fb = h->g_opt = nullptr;
+}
+
+extern "C" void lr_lru_train_destroy(lr_lru_train_t* h) {
+  if (!h) return;
+  tr_drop_graphs(h);
+  free(h);
+}
+
+extern "C" int lr_lru_train_set_graph(lr_lru_train_t* h, int32_t enable) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_set_graph: null handle");
+  h->use_graph = enable ? 1 : 0;
+  if (!enable) tr_drop_graphs(h);
+  return LR_OK;
+}
 
 extern "C" size_t lr_lru_train_workspace_bytes(const lr_lru_train_t* h, int32_t B, int32_t L) {
   if (!h || B < 1 || L < 1) return 0;
@@ -764,30 +817,28 @@ extern "C" int lr_lru_train_param_range(const lr_lru_train_t* h, const char* nam
     LR_CHECK_LAUNCH(#kernel);                                                                         \
   } while (0)
 
-extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64_t* labels, int32_t B,
-                                      int32_t L, float* out_loss, void* workspace, size_t workspace_bytes,
-                                      void* hip_stream) {
-  if (!h || !tokens || !labels || !out_loss || !workspace) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: null argument");
-  if (B < 1 || L < 1) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: B=%d L=%d", B, L);
+static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64_t* labels, int32_t B, int32_t L,
+                                float* out_loss, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const TrLayout& lay = h->lay;
   const int R = B * L, V = lay.V, C = V + 1;
   TrWs ws = tr_carve(lay, R, (char*)workspace);
   if (ws.total > workspace_bytes)
     LR_FAIL(LR_EWORKSPACE, "lr_lru_train_loss_grad: workspace needs %zu bytes, have %zu", ws.total, workspace_bytes);
-  hipStream_t st = (hipStream_t)hip_stream;
   const long long* ids = (const long long*)tokens;
   const long long* lab = (const long long*)labels;
   float *P = h->p, *G = h->g;
-  const unsigned long long seed = h->cfg.seed * 0x9E3779B97F4A7C15ull + (unsigned long long)(h->fwd_calls++) * 0xA24BAED4963EE407ull;
+  const unsigned long long* seed = h->ctr + 2;
+  hipLaunchKernelGGL(tr_begin_pass, dim3(1), dim3(1), 0, st, h->ctr, h->cfg.seed * 0x9E3779B97F4A7C15ull);
+  LR_CHECK_LAUNCH("tr_begin_pass");
   const float pd = h->cfg.dropout, pa = h->cfg.attn_dropout;
   const unsigned grid_rows = (unsigned)((R + 3) / 4);
 
-  LR_CHECK_HIP(hipMemsetAsync(G, 0, lay.total * sizeof(float), st));
-  LR_CHECK_HIP(hipMemsetAsync(h->scal, 0, 8 * sizeof(float), st));
+  TR_EW(tr_zero_kernel, lay.total, G, lay.total);
+  TR_EW(tr_zero_kernel, (size_t)4, h->scal, (size_t)4);
   {  // gradients of the derived weights start from zero as well
     const TrDerived& d0 = ws.blk[0].d;
     const TrDerived& dl = ws.blk[lay.nb - 1].d;
-    LR_CHECK_HIP(hipMemsetAsync(ws.derived + d0.wi, 0, (dl.dlam + 256 - d0.wi) * sizeof(float), st));
+    TR_EW(tr_zero_kernel, dl.dlam + 256 - d0.wi, ws.derived + d0.wi, dl.dlam + 256 - d0.wi);
   }
   // ---- forward
   for (int b = 0; b < lay.nb; ++b) {
@@ -823,7 +874,7 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
   hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, h->scal);
   LR_CHECK_LAUNCH("tr_count_valid");
   float* dx = ws.d64b;
-  LR_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)R * 64 * sizeof(float), st));  // its GEMM splits K = V+1 with atomic adds
+  TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // its GEMM splits K = V+1 with atomic adds
   for (int r0 = 0; r0 < R; r0 += ws.rows_chunk) {
     const int rc = (R - r0 < ws.rows_chunk) ? R - r0 : ws.rows_chunk;
     const float* xf = x + (size_t)r0 * 64;
@@ -849,7 +900,7 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
                        G + o.ln2_b, R);
     LR_CHECK_LAUNCH("tr_ln_bwd");
     // dy (residual branch) = dz0; the W2 branch sees dropout(dz0)
-    LR_CHECK_HIP(hipMemcpyAsync(dx, dz0, (size_t)R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));  // dx now = dy partial
+    TR_EW(tr_copy_kernel, (size_t)R * 64, dx, dz0, (size_t)R * 64);  // dx now = dy partial
     if (pd > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dz0, (size_t)R * 64, seed, 12u + 4u * b, pd);
     TR_RUN(tr_linear_bwd_weight(dz0, W.g, G + o.w2, G + o.b2, R, 64, 256, st));
     TR_RUN(tr_linear_bwd_data(dz0, P + o.w2, ws.d256, R, 64, 256, 0, st));  // d g
@@ -861,7 +912,7 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
     hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, W.xhat1, W.rstd1, P + o.ln1_w, dy0, G + o.ln1_w,
                        G + o.ln1_b, R);
     LR_CHECK_LAUNCH("tr_ln_bwd");
-    LR_CHECK_HIP(hipMemcpyAsync(dx, dy0, (size_t)R * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));  // residual: dx_in = dy0 + ...
+    TR_EW(tr_copy_kernel, (size_t)R * 64, dx, dy0, (size_t)R * 64);  // residual: dx_in = dy0 + ...
     if (pa > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dy0, (size_t)R * 64, seed, 10u + 4u * b, pa);
     // out_proj (derived real form [64][256] over (Re h | Im h))
     TR_RUN(tr_linear_bwd_weight(dy0, W.h, D + W.d.dwo, D + W.d.dbo, R, 64, 256, st));
@@ -885,21 +936,79 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
   return LR_OK;
 }
 
+// Runs `enqueue(stream)` directly, or -- with graphs enabled and a capturable (non-default) stream -- captures
+// it once into a hipGraph and replays that: the ~120 launches of a step become one graph launch.
+template <typename F>
+static int tr_run_or_replay(lr_lru_train* h, hipGraphExec_t* exec, bool key_ok, hipStream_t st, F enqueue) {
+  if (!h->use_graph || st == nullptr) return enqueue(st);
+  if (!*exec || !key_ok) {
+    if (*exec) {
+      (void)hipGraphExecDestroy(*exec);
+      *exec = nullptr;
+    }
+    LR_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue(st);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    if (e != hipSuccess || !graph) LR_FAIL(LR_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) {
+      *exec = nullptr;
+      LR_FAIL(LR_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+    }
+  }
+  LR_CHECK_HIP(hipGraphLaunch(*exec, st));
+  return LR_OK;
+}
+
+extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64_t* labels, int32_t B,
+                                      int32_t L, float* out_loss, void* workspace, size_t workspace_bytes,
+                                      void* hip_stream) {
+  if (!h || !tokens || !labels || !out_loss || !workspace) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: null argument");
+  if (B < 1 || L < 1) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: B=%d L=%d", B, L);
+  const bool key_ok = h->k_tok == tokens && h->k_lab == labels && h->k_out == out_loss && h->k_ws == workspace &&
+                      h->k_B == B && h->k_L == L;
+  const int rc = tr_run_or_replay(h, &h->g_fb, key_ok, (hipStream_t)hip_stream, [&](hipStream_t st) {
+    return tr_enqueue_loss_grad(h, tokens, labels, B, L, out_loss, workspace, workspace_bytes, st);
+  });
+  if (rc == LR_OK) {
+    h->k_tok = tokens;
+    h->k_lab = labels;
+    h->k_out = out_loss;
+    h->k_ws = workspace;
+    h->k_B = B;
+    h->k_L = L;
+  }
+  return rc;
+}
+
 extern "C" int lr_lru_train_apply(lr_lru_train_t* h, float lr, float max_grad_norm, float* out_grad_norm,
                                   void* hip_stream) {
   if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_apply: null handle");
   if (max_grad_norm <= 0.f) max_grad_norm = h->cfg.max_grad_norm;
-  hipStream_t st = (hipStream_t)hip_stream;
-  const size_t n = h->lay.total;
-  LR_CHECK_HIP(hipMemsetAsync(h->scal + 2, 0, sizeof(float), st));
-  hipLaunchKernelGGL(tr_sumsq_kernel, dim3(256), dim3(256), 0, st, h->g, n, h->scal + 2);
-  LR_CHECK_LAUNCH("tr_sumsq_kernel");
-  h->step += 1;
-  const LrLruTrainConfig& c = h->cfg;
-  const float bc1 = 1.0f - powf(c.beta1, (float)h->step);
-  const float bc2s = sqrtf(1.0f - powf(c.beta2, (float)h->step));
-  hipLaunchKernelGGL(tr_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->p, h->g, h->m, h->v, h->decay,
-                     n, h->scal, max_grad_norm, lr, c.weight_decay, c.beta1, c.beta2, c.eps, bc1, bc2s, out_grad_norm);
-  LR_CHECK_LAUNCH("tr_adamw_kernel");
-  return LR_OK;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  // this step's learning rate and clipping limit go to device memory (the optimizer kernels may be a replayed
+  // graph with frozen arguments); a 1-thread kernel carries them as launch arguments: no host buffer lifetime
+  hipLaunchKernelGGL(tr_set_step_scalars, dim3(1), dim3(1), 0, stream, h->scal, lr, max_grad_norm);
+  LR_CHECK_LAUNCH("tr_set_step_scalars");
+  const bool key_ok = h->k_norm == out_grad_norm;
+  const int rc = tr_run_or_replay(h, &h->g_opt, key_ok, stream, [&](hipStream_t st) {
+    const size_t n = h->lay.total;
+    const LrLruTrainConfig& c = h->cfg;
+    hipLaunchKernelGGL(tr_zero_kernel, dim3(1), dim3(64), 0, st, h->scal + 2, (size_t)1);
+    LR_CHECK_LAUNCH("tr_zero_kernel");
+    hipLaunchKernelGGL(tr_sumsq_kernel, dim3(256), dim3(256), 0, st, h->g, n, h->scal + 2, h->ctr);
+    LR_CHECK_LAUNCH("tr_sumsq_kernel");
+    hipLaunchKernelGGL(tr_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->p, h->g, h->m, h->v,
+                       h->decay, n, h->scal, h->ctr, c.weight_decay, c.beta1, c.beta2, c.eps, out_grad_norm);
+    LR_CHECK_LAUNCH("tr_adamw_kernel");
+    return (int)LR_OK;
+  });
+  if (rc == LR_OK) h->k_norm = out_grad_norm;
+  return rc;
 }

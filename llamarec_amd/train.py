@@ -32,7 +32,7 @@ class LRUTrainEngine:
     """
 
     def __init__(self, state_dict, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-9, max_grad_norm=5.0,
-                 dropout=0.2, attn_dropout=0.2, seed=42, device="cuda:0"):
+                 dropout=0.2, attn_dropout=0.2, seed=42, device="cuda:0", use_graph=False):
         if not torch.cuda.is_available():
             raise RuntimeError("LRUTrainEngine needs a GPU (MI355X); there is no CPU fallback")
         self.device = torch.device(device)
@@ -65,6 +65,11 @@ class LRUTrainEngine:
         self.grads = f32[(g.value - base) // 4:(g.value - base) // 4 + self._n]
         self._ws = None
         self._out = torch.zeros(3, dtype=torch.float32, device=self.device)  # loss, n_valid, grad norm
+        # the step runs on its own stream (a hipGraph cannot be captured on the default stream) from persistent
+        # token / label buffers, so every step after the first is one graph replay per half
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._tok = self._lab = None
+        check(lib().lr_lru_train_set_graph(self._h, int(bool(use_graph))), "lr_lru_train_set_graph")
 
     def __del__(self):
         try:
@@ -83,25 +88,37 @@ class LRUTrainEngine:
         return (t.to(device=self.device, dtype=torch.int64).contiguous(),
                 l.to(device=self.device, dtype=torch.int64).contiguous())
 
+    def _on_stream(self):
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        return cur
+
     def loss_and_grads(self, tokens, labels):
         """trainer/lru.py:20-28 + loss.backward(): fills `self.grads`, returns the loss as a 0-dim device tensor."""
         t, l = self._batch(tokens, labels)
         B, L = t.shape
-        need = lib().lr_lru_train_workspace_bytes(self._h, B, L)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
-            check(lib().lr_lru_train_loss_grad(self._h, t.data_ptr(), l.data_ptr(), B, L, self._out.data_ptr(),
-                                               self._ws.data_ptr(), self._ws.numel(), stream_ptr()), "lr_lru_train_loss_grad")
+        if self._tok is None or tuple(self._tok.shape) != (B, L):
+            self._tok, self._lab = torch.empty_like(t), torch.empty_like(l)
+            self._ws = torch.empty(lib().lr_lru_train_workspace_bytes(self._h, B, L), dtype=torch.uint8, device=self.device)
+        cur = self._on_stream()
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+            self._tok.copy_(t, non_blocking=True)
+            self._lab.copy_(l, non_blocking=True)
+            check(lib().lr_lru_train_loss_grad(self._h, self._tok.data_ptr(), self._lab.data_ptr(), B, L,
+                                               self._out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                               self._stream.cuda_stream), "lr_lru_train_loss_grad")
+        cur.wait_stream(self._stream)
         return self._out[0]
 
     def apply(self, lr=None, max_grad_norm=None):
         """clip_gradients(limit) + optimizer.step (trainer/base.py:109-110,201-202); returns the pre-clip gradient
         norm (0-dim device tensor)."""
-        with torch.cuda.device(self.device):
+        cur = self._on_stream()
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
             check(lib().lr_lru_train_apply(self._h, float(self.lr if lr is None else lr),
                                            float(0.0 if max_grad_norm is None else max_grad_norm),
-                                           self._out[2:].data_ptr(), stream_ptr()), "lr_lru_train_apply")
+                                           self._out[2:].data_ptr(), self._stream.cuda_stream), "lr_lru_train_apply")
+        cur.wait_stream(self._stream)
         return self._out[2]
 
     def train_step(self, tokens, labels, lr=None, all_reduce=None):

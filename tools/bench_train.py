@@ -17,6 +17,7 @@ from llamarec_amd.train import LRUTrainEngine  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--graph", type=int, default=1)
 a = ap.parse_args()
 for name, B in (("beauty", 64), ("games", 64), ("ml-100k", 16), ("synth-1m", 64)):
     if a.only and name != a.only:
@@ -30,7 +31,7 @@ for name, B in (("beauty", 64), ("games", 64), ("ml-100k", 16), ("synth-1m", 64)
     for i, n in enumerate(short):
         tokens[i, : L - n] = 0
         labels[i, : L - n - 1] = 0
-    eng = LRUTrainEngine(init_lru_state_dict(V, seed=1), seed=3)
+    eng = LRUTrainEngine(init_lru_state_dict(V, seed=1), seed=3, use_graph=bool(a.graph))
     t = torch.from_numpy(tokens).cuda()
     l = torch.from_numpy(labels).cuda()
     for _ in range(3):
@@ -48,5 +49,5 @@ for name, B in (("beauty", 64), ("games", 64), ("ml-100k", 16), ("synth-1m", 64)
     R = B * L
     flops = 3 * 2.0 * R * (V + 1) * 64 + 3 * R * 2 * 2.64e5 / 2    # three V-sized GEMMs + fwd/bwd of the blocks
     ms_fb, ms_opt = (t1 - t0) / a.iters * 1e3, (t2 - t1) / a.iters * 1e3
-    print(f"{name:9s} B={B} L={L} V={V}: fwd+bwd {ms_fb:.3f} ms, clip+AdamW {ms_opt:.3f} ms, "
+    print(f"graph={a.graph} {name:9s} B={B} L={L} V={V}: fwd+bwd {ms_fb:.3f} ms, clip+AdamW {ms_opt:.3f} ms, "
           f"{B / (ms_fb + ms_opt) * 1e3:.0f} sequences/s, {flops / ms_fb / 1e9:.2f} TFLOP/s (f32), loss {float(eng._out[0]):.3f}")
