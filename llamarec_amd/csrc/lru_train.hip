@@ -130,11 +130,11 @@ struct lr_lru_train {
 // generic strided f32 GEMM on v_mfma_f32_32x32x2_f32
 //   C[m][n] (ldc) = sum_k A(m,k) * B(k,n) (+ bias[n]) (+ C[m][n] if accumulate)
 //   A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
-// 64 x 64 tile, BK = 16, 4 waves (2 x 2) of one 32 x 32 MFMA block each.
+// 64 x 64 tile, BK = 32, 4 waves (2 x 2) of one 32 x 32 MFMA block each.
 // =============================================================================================
 #define TG_BM 64
 #define TG_BN 64
-#define TG_BK 16
+#define TG_BK 32
 #define TG_LD 68
 
 // gridDim.z > 1 splits K: every split ADDS its partial product with fp32 atomics (C must hold the value to
@@ -158,27 +158,27 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
   const bool want_rowsum = rowsum != nullptr && blockIdx.x == 0;
   float rs = 0.f;
   for (int k0 = ks0 * TG_BK; k0 < ks1 * TG_BK; k0 += TG_BK) {
-    float va[4], vb[4];
+    float va[8], vb[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int e = tid + 256 * i;
       {
-        const int kk = a_kfast ? (e & 15) : (e >> 6), mm = a_kfast ? (e >> 4) : (e & 63);
+        const int kk = a_kfast ? (e & 31) : (e >> 6), mm = a_kfast ? (e >> 5) : (e & 63);
         const int gm = m0 + mm, gk = k0 + kk;
         va[i] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
       }
       {
-        const int kk = b_kfast ? (e & 15) : (e >> 6), nn = b_kfast ? (e >> 4) : (e & 63);
+        const int kk = b_kfast ? (e & 31) : (e >> 6), nn = b_kfast ? (e >> 5) : (e & 63);
         const int gn = n0 + nn, gk = k0 + kk;
         vb[i] = (gn < N && gk < K) ? B[gk * sbk + gn * sbn] : 0.f;
       }
     }
     __syncthreads();  // previous tile consumed
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int e = tid + 256 * i;
-      As[a_kfast ? (e & 15) : (e >> 6)][a_kfast ? (e >> 4) : (e & 63)] = va[i];
-      Bs[b_kfast ? (e & 15) : (e >> 6)][b_kfast ? (e >> 4) : (e & 63)] = vb[i];
+      As[a_kfast ? (e & 31) : (e >> 6)][a_kfast ? (e >> 5) : (e & 63)] = va[i];
+      Bs[b_kfast ? (e & 31) : (e >> 6)][b_kfast ? (e >> 5) : (e & 63)] = vb[i];
     }
     __syncthreads();
     if (want_rowsum && tid < TG_BM) {
@@ -302,22 +302,28 @@ __global__ __launch_bounds__(256) void tr_res_ln_fwd(const float* o, const float
   if (lane == 0) rstd[row] = rs;
 }
 
-// LN backward for y = LN(e): dx (pre-LN gradient); dw/db accumulated with atomics (one add per workgroup)
+// LN backward for y = LN(e): de (pre-LN gradient); dw/db: each wave sums its 8 rows in registers, the workgroup
+// adds once per column (32 rows per workgroup keeps the atomics on the 64 shared addresses few)
+#define TR_LNB_ROWS 32
 __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* w,
                                                  float* de, float* dw, float* db, int R) {
   __shared__ float sw[4][64], sb[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
+  const float wl = w[lane];
   float gw = 0.f, gb = 0.f;
-  if (row < R) {
-    const size_t i = (size_t)row * 64 + lane;
-    const float g = dy[i], xh = xhat[i];
-    gw = g * xh;
-    gb = g;
-    const float dxh = g * w[lane];
-    const float m1 = tr_wave_sum(dxh) * (1.0f / 64);
-    const float m2 = tr_wave_sum(dxh * xh) * (1.0f / 64);
-    de[i] = rstd[row] * (dxh - m1 - xh * m2);
+#pragma unroll 2
+  for (int j = 0; j < TR_LNB_ROWS / 4; ++j) {
+    const int row = blockIdx.x * TR_LNB_ROWS + j * 4 + wave;
+    if (row < R) {
+      const size_t i = (size_t)row * 64 + lane;
+      const float g = dy[i], xh = xhat[i];
+      gw += g * xh;
+      gb += g;
+      const float dxh = g * wl;
+      const float m1 = tr_wave_sum(dxh) * (1.0f / 64);
+      const float m2 = tr_wave_sum(dxh * xh) * (1.0f / 64);
+      de[i] = rstd[row] * (dxh - m1 - xh * m2);
+    }
   }
   sw[wave][lane] = gw;
   sb[wave][lane] = gb;
@@ -422,13 +428,17 @@ __global__ __launch_bounds__(64) void tr_unprep_kernel(const float* plog, const 
 // =============================================================================================
 // grid: B blocks of 128 threads (thread = complex channel); rows b*L .. b*L+L-1, columns c (re) and 128+c (im)
 __global__ __launch_bounds__(128) void tr_scan_fwd(float* uh, const long long* ids, const float* lam, int L) {
+  extern __shared__ unsigned char live[];  // live[t] = ids[b][t] > 0 (kept out of the dependent chain)
   const int b = blockIdx.x, c = threadIdx.x;
+  for (int t = c; t < L; t += 128) live[t] = ids[(size_t)b * L + t] > 0;
+  __syncthreads();
   const float lr_ = lam[c], li = lam[128 + c];
   float hr = 0.f, hi = 0.f;
   float* base = uh + (size_t)b * L * 256;
+#pragma unroll 4
   for (int t = 0; t < L; ++t) {
     const float ur = base[t * 256 + c], ui = base[t * 256 + 128 + c];
-    const bool carry = t > 0 && ids[(size_t)b * L + t - 1] > 0;
+    const bool carry = t > 0 && live[t - 1];
     const float nr = carry ? ur + (lr_ * hr - li * hi) : ur;
     const float ni = carry ? ui + (lr_ * hi + li * hr) : ui;
     hr = nr;
@@ -439,14 +449,18 @@ __global__ __launch_bounds__(128) void tr_scan_fwd(float* uh, const long long* i
 }
 __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, const long long* ids, const float* lam,
                                                    float* dlam, int L) {
+  extern __shared__ unsigned char live[];
   const int b = blockIdx.x, c = threadIdx.x;
+  for (int t = c; t < L; t += 128) live[t] = ids[(size_t)b * L + t] > 0;
+  __syncthreads();
   const float lr_ = lam[c], li = lam[128 + c];
   float Gr = 0.f, Gi = 0.f, dr = 0.f, di = 0.f;
   float* gb = g + (size_t)b * L * 256;
   const float* hb = h + (size_t)b * L * 256;
+#pragma unroll 4
   for (int t = L - 1; t >= 0; --t) {
     float gr = gb[t * 256 + c], gi = gb[t * 256 + 128 + c];
-    if (t < L - 1 && ids[(size_t)b * L + t] > 0) {  // h_{t+1} = u_{t+1} + lambda h_t : G_t += conj(lambda) G_{t+1}
+    if (t < L - 1 && live[t]) {  // h_{t+1} = u_{t+1} + lambda h_t : G_t += conj(lambda) G_{t+1}
       gr += lr_ * Gr + li * Gi;
       gi += lr_ * Gi - li * Gr;
     }
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, con
     Gi = gi;
     gb[t * 256 + c] = Gr;
     gb[t * 256 + 128 + c] = Gi;
-    if (t > 0 && ids[(size_t)b * L + t - 1] > 0) {  // d lambda += conj(h_{t-1}) G_t
+    if (t > 0 && live[t - 1]) {  // d lambda += conj(h_{t-1}) G_t
       const float pr = hb[(t - 1) * 256 + c], pi = hb[(t - 1) * 256 + 128 + c];
       dr += pr * Gr + pi * Gi;
       di += pr * Gi - pi * Gr;
@@ -550,7 +564,10 @@ __global__ __launch_bounds__(256) void tr_embed_bwd(const float* de, const long 
   if (row >= R) return;
   long long id = ids[row];
   if (id < 0 || id > V) id = 0;
-  atomicAdd(dE + id * 64 + lane, de[(size_t)row * 64 + lane] * tr_drop_scale(seed, 0, (unsigned long long)row * 64 + lane, p));
+  // unlabelled pad positions have an exactly zero gradient; skipping them keeps hundreds of waves off the 64
+  // addresses of table row 0
+  const float v = de[(size_t)row * 64 + lane] * tr_drop_scale(seed, 0, (unsigned long long)row * 64 + lane, p);
+  if (v != 0.f) atomicAdd(dE + id * 64 + lane, v);
 }
 
 // =============================================================================================
@@ -856,7 +873,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     TrBlockWs& W = ws.blk[b];
     const float* D = ws.derived;
     TR_RUN(tr_linear_fwd(x, D + W.d.wi, D + W.d.bi, W.h, R, 256, 64, st));
-    hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), 0, st, W.h, ids, D + W.d.lam, L);
+    hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), (size_t)L, st, W.h, ids, D + W.d.lam, L);
     LR_CHECK_LAUNCH("tr_scan_fwd");
     TR_RUN(tr_linear_fwd(W.h, D + W.d.wo, D + W.d.bo, ws.d64a, R, 64, 256, st));
     hipLaunchKernelGGL(tr_res_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ws.d64a, x, P + o.ln1_w, P + o.ln1_b, W.y,
@@ -896,7 +913,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     const float* xin = b ? ws.blk[b - 1].xout : ws.x0;
     float* dz0 = ws.d64a;
     // LN2: dx -> dz0 (gradient of W2 g + b2 (dropped) + y)
-    hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, W.xhat2, W.rstd2, P + o.ln2_w, dz0, G + o.ln2_w,
+    hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, W.xhat2, W.rstd2, P + o.ln2_w, dz0, G + o.ln2_w,
                        G + o.ln2_b, R);
     LR_CHECK_LAUNCH("tr_ln_bwd");
     // dy (residual branch) = dz0; the W2 branch sees dropout(dz0)
@@ -909,7 +926,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     TR_RUN(tr_linear_bwd_data(ws.d256, P + o.w1, dx, R, 256, 64, 1, st));  // dy += da W1
     // LN1: dy -> dy0 (gradient of dropout(o) + x)
     float* dy0 = ws.d64a;
-    hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, W.xhat1, W.rstd1, P + o.ln1_w, dy0, G + o.ln1_w,
+    hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, W.xhat1, W.rstd1, P + o.ln1_w, dy0, G + o.ln1_w,
                        G + o.ln1_b, R);
     LR_CHECK_LAUNCH("tr_ln_bwd");
     TR_EW(tr_copy_kernel, (size_t)R * 64, dx, dy0, (size_t)R * 64);  // residual: dx_in = dy0 + ...
@@ -917,7 +934,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     // out_proj (derived real form [64][256] over (Re h | Im h))
     TR_RUN(tr_linear_bwd_weight(dy0, W.h, D + W.d.dwo, D + W.d.dbo, R, 64, 256, st));
     TR_RUN(tr_linear_bwd_data(dy0, D + W.d.wo, ws.d256, R, 64, 256, 0, st));  // g_t = direct gradient of h_t
-    hipLaunchKernelGGL(tr_scan_bwd, dim3(B), dim3(128), 0, st, ws.d256, W.h, ids, D + W.d.lam, D + W.d.dlam, L);
+    hipLaunchKernelGGL(tr_scan_bwd, dim3(B), dim3(128), (size_t)L, st, ws.d256, W.h, ids, D + W.d.lam, D + W.d.dlam, L);
     LR_CHECK_LAUNCH("tr_scan_bwd");
     // in_proj (derived, gamma folded): du in d256
     TR_RUN(tr_linear_bwd_weight(ws.d256, xin, D + W.d.dwi, D + W.d.dbi, R, 256, 64, st));
@@ -928,7 +945,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     LR_CHECK_LAUNCH("tr_unprep_kernel");
   }
   // ---- embedding LayerNorm and the lookup
-  hipLaunchKernelGGL(tr_ln_bwd, dim3(grid_rows), dim3(256), 0, st, dx, ws.xhat0, ws.rstd0, P + lay.eln_w, ws.d64a,
+  hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, ws.xhat0, ws.rstd0, P + lay.eln_w, ws.d64a,
                      G + lay.eln_w, G + lay.eln_b, R);
   LR_CHECK_LAUNCH("tr_ln_bwd");
   hipLaunchKernelGGL(tr_embed_bwd, dim3(grid_rows), dim3(256), 0, st, ws.d64a, ids, V, G + lay.emb, R, seed, pd);
