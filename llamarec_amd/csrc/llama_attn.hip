@@ -17,6 +17,8 @@
 //    A workgroup = 4 wave64 = 128 query rows of one (prompt, head); each wave 32 rows, so every K/V
 //    fragment read from LDS feeds two MFMA column tiles. K tile XOR-swizzled by (row&15) for
 //    ds_read_b128; V tile by the dual-use swizzle (row reads + transposed reads).
+#include <stdlib.h>
+
 #include "llama_kernels.h"
 #include "lr_profile.h"
 
@@ -113,12 +115,60 @@ __device__ __forceinline__ void attn_glds16(const void* gsrc, void* lds_wave_bas
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// x[lane] (op) x[lane ^ 16] and x[lane] (op) x[lane ^ 32] without the LDS crossbar: gfx950's row / half swaps
+// (v_permlane16_swap, v_permlane32_swap) hand both partners to every lane at VALU speed; __shfl_xor compiles
+// to ds_bpermute_b32 (~100+ cycles of dependent latency, four of them on every key block's critical path).
+// hipcc pitfall: __builtin_bit_cast(float, r[1]) on the builtin's 2-vector result reads element 0 (the cast
+// takes the vector's address) -- copy the elements into scalars first.
+__device__ __forceinline__ void fa_swap16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void fa_swap32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float fa_max_xor16_32(float v) {
+  float a, b;
+  fa_swap16(v, a, b);
+  fa_swap32(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float fa_sum_xor16_32(float v) {
+  float a, b;
+  fa_swap16(v, a, b);
+  fa_swap32(a + b, a, b);
+  return a + b;
+}
+
 #define FA_TILE_BYTES (FA_KB * 256)        // one K or V tile: 64 keys x 128 dims bf16
 #define FA_STAGE_BYTES (2 * FA_TILE_BYTES)  // K tile + V tile
 
+// Diagnostic stamps (STAMP = true only under LR_ATTN_STAMPS=1, never in the product path): s_memtime deltas of
+// the key-block loop's segments summed over the loop, wave 0 of the first 64 workgroups.
+__device__ unsigned long long g_attn_stamps[64 * 8];
+#define FA_STAMP(slot)                                                         \
+  if (STAMP) {                                                                 \
+    unsigned long long t_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    stamp_acc[(slot)] += t_ - t_prev;                                          \
+    t_prev = t_;                                                               \
+  }
+
+template <bool STAMP>
 __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
                                                               const int32_t* cu, int nh, int nkv,
                                                               int max_qblocks) {
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   // [2 stages][K 16 KiB | V 16 KiB]; filled by LDS-DMA (lane-linear 1 KiB pieces = 4 rows x 256 B),
   // the XOR swizzles are applied to the SOURCE chunk: position p of row r holds chunk p ^ s(r).
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,11 +234,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));
   __syncthreads();
+  FA_STAMP(0)  // prologue: Q fragments + first K/V tile landed
 
   for (int kb = 0; kb <= kb_last; ++kb) {
     const char* Ks = smem + (kb & 1) * FA_STAGE_BYTES;
     const char* Vs = Ks + FA_TILE_BYTES;
     if (kb < kb_last) stage(kb + 1, (kb + 1) & 1);
+    FA_STAMP(1)  // DMA issue
 
     if (kb * FA_KB <= wave_q_last) {  // otherwise every key of the block is masked for this wave
       // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
@@ -220,6 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
             st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][nt], qf[qt][ks], st[qt][nt], 0, 0, 0);
       }
 
+      if (STAMP) asm volatile("" ::"v"(st[0][0]), "v"(st[1][3]));
+      FA_STAMP(2)  // S^T = K Q^T
       // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
       bf16x8 pa[2][2];
       const bool diag = (kb * FA_KB + FA_KB - 1) > (qb * FA_QROWS + wave * 32);  // block needs masking
@@ -237,8 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
             }
             mx = fmaxf(mx, st[qt][nt][r]);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fa_max_xor16_32(mx);
         const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
         const bool grew = m_new > m_run[qt];
         const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
@@ -262,6 +315,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
         }
       }
 
+      if (STAMP) asm volatile("" ::"v"(pa[0][0]), "v"(pa[1][1]));
+      FA_STAMP(3)  // softmax
       // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
       const int qp = li >> 2, p4 = li & 3;
 #pragma unroll
@@ -287,15 +342,16 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
         }
       }
     }
+    if (STAMP) asm volatile("" ::"v"(ot[0][0]), "v"(ot[1][7]));
+    FA_STAMP(4)  // O^T += V^T P^T
     __syncthreads();  // DMA of block kb+1 landed (vmcnt(0)) and every wave is done with block kb
+    FA_STAMP(5)  // barrier + DMA wait
   }
 
   // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = fa_sum_xor16_32(l_run[qt]);
     const float inv = 1.0f / l;
     if (qabs[qt] < T) {
       u16* op = out + (size_t)(tok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
@@ -308,6 +364,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       }
     }
   }
+  if (STAMP) {
+    FA_STAMP(6)  // epilogue
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 64 && tid == 0) {
+      stamp_acc[7] = kb_last + 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g_attn_stamps[wg * 8 + i] = stamp_acc[i];
+    }
+  }
+}
+
+extern "C" int lr_debug_attn_stamps(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > 64 * 8) LR_FAIL(LR_EINVAL, "lr_debug_attn_stamps: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
 }
 
 // attention for a list of query tokens only (the last layer needs just each prompt's last token)
@@ -344,14 +415,22 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
     const int mq = (maxT + FA_QROWS - 1) / FA_QROWS;
     if (mq == 0) return LR_OK;
-    static bool attr_set = false;
+    static bool attr_set = false, stamps = false;
     if (!attr_set) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_kernel),
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
+      const char* e = getenv("LR_ATTN_STAMPS");
+      stamps = e && e[0] == '1';
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_mfma128_kernel, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
-                       nkv, mq);
+    if (stamps)
+      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
+                         nkv, mq);
+    else
+      hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
+                         nkv, mq);
     LR_CHECK_LAUNCH("attn_mfma128_kernel");
   } else if (variant == 1) {
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
