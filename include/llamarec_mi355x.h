@@ -306,7 +306,8 @@ void lr_lru_train_destroy(lr_lru_train_t* h);
 size_t lr_lru_train_workspace_bytes(const lr_lru_train_t* h, int32_t B, int32_t L);
 /* Forward + backward of one batch: tokens/labels DEVICE int64 [B][L], left-padded with 0, label 0 =
  * ignored (dataloader/lru.py:119-131). Fills the gradient buffer (zeroed first) and
- * out_loss[0] = mean CE over labelled positions, out_loss[1] = their count (DEVICE float[2]). */
+ * out_loss[0] = mean CE over labelled positions, out_loss[1] = their count, out_loss[2] = number of labels
+ * outside [0, num_items] (ignored like label 0; torch would raise) -- DEVICE float[3]. */
 int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const int64_t* labels, int32_t B,
                            int32_t L, float* out_loss, void* workspace, size_t workspace_bytes,
                            void* hip_stream);

@@ -481,15 +481,23 @@ __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, con
 // =============================================================================================
 // softmax cross-entropy over a chunk of logit rows, in place: logits -> d logits; loss sum accumulated
 // =============================================================================================
-__global__ void tr_count_valid(const long long* labels, int R, float* scal) {
-  __shared__ int s;
-  if (threadIdx.x == 0) s = 0;
+// labels: 0 = ignored (CrossEntropyLoss(ignore_index=0)); a label outside [0, V] would index past the logit row --
+// torch raises there, here such rows are ignored too and counted in scal[3] (reported as out_loss[2])
+__global__ void tr_count_valid(const long long* labels, int R, int V, float* scal) {
+  __shared__ int s, bad;
+  if (threadIdx.x == 0) s = bad = 0;
   __syncthreads();
-  int c = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) c += labels[i] != 0;
+  int c = 0, b = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
+    const long long l = labels[i];
+    c += l > 0 && l <= V;
+    b += l < 0 || l > V;
+  }
   atomicAdd(&s, c);
+  if (b) atomicAdd(&bad, b);
   __syncthreads();
   if (threadIdx.x == 0 && s) atomicAdd(scal + 1, (float)s);
+  if (threadIdx.x == 0 && bad) atomicAdd(scal + 3, (float)bad);
 }
 __device__ __forceinline__ float tr_block_reduce(float v, bool is_max, float* sh) {
 #pragma unroll
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(256) void tr_ce_kernel(float* logits, long long ld,
   const int row = blockIdx.x;
   float* x = logits + row * ld;
   const long long lab = labels[row];
-  if (lab == 0) {  // ignore_index: no loss, no gradient
+  if (lab <= 0 || lab >= C) {  // ignore_index (or out of range, see tr_count_valid): no loss, no gradient
     for (int j = threadIdx.x; j < C; j += 256) x[j] = 0.f;
     return;
   }
@@ -554,6 +562,7 @@ __global__ void tr_set_step_scalars(float* scal, float lr, float max_norm) {
 __global__ void tr_finish_loss(float* scal, float* out) {
   out[0] = scal[0] / fmaxf(scal[1], 1.0f);
   out[1] = scal[1];
+  out[2] = scal[3];
 }
 
 // embedding backward: dE[id] += de[row]
@@ -888,7 +897,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     x = W.xout;
   }
   // ---- item GEMM + cross-entropy, row chunk by row chunk: d x_final in d64b
-  hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, h->scal);
+  hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, V, h->scal);
   LR_CHECK_LAUNCH("tr_count_valid");
   float* dx = ws.d64b;
   TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // its GEMM splits K = V+1 with atomic adds

@@ -27,7 +27,7 @@ bool lr_prof_begin(int kind, double work, hipStream_t st) {
 
 void lr_prof_end(hipStream_t st) {
   if (!g_on || g_used >= (int)g_pool.size()) return;
-  hipEventRecord(g_pool[g_used].b, st);
+  (void)hipEventRecord(g_pool[g_used].b, st);
   ++g_used;
 }
 

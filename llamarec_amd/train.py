@@ -64,7 +64,7 @@ class LRUTrainEngine:
         self.params = f32[(p.value - base) // 4:(p.value - base) // 4 + self._n]   # views into the state buffer
         self.grads = f32[(g.value - base) // 4:(g.value - base) // 4 + self._n]
         self._ws = None
-        self._out = torch.zeros(3, dtype=torch.float32, device=self.device)  # loss, n_valid, grad norm
+        self._out = torch.zeros(4, dtype=torch.float32, device=self.device)  # loss, n_valid, n_bad_labels, grad norm
         # the step runs on its own stream (a hipGraph cannot be captured on the default stream) from persistent
         # token / label buffers, so every step after the first is one graph replay per half
         self._stream = torch.cuda.Stream(device=self.device)
@@ -110,6 +110,11 @@ class LRUTrainEngine:
         cur.wait_stream(self._stream)
         return self._out[0]
 
+    @property
+    def bad_labels(self):
+        """Labels outside [0, num_items] seen by the last loss_and_grads (they were ignored)."""
+        return int(self._out[2])
+
     def apply(self, lr=None, max_grad_norm=None):
         """clip_gradients(limit) + optimizer.step (trainer/base.py:109-110,201-202); returns the pre-clip gradient
         norm (0-dim device tensor)."""
@@ -117,9 +122,9 @@ class LRUTrainEngine:
         with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
             check(lib().lr_lru_train_apply(self._h, float(self.lr if lr is None else lr),
                                            float(0.0 if max_grad_norm is None else max_grad_norm),
-                                           self._out[2:].data_ptr(), self._stream.cuda_stream), "lr_lru_train_apply")
+                                           self._out[3:].data_ptr(), self._stream.cuda_stream), "lr_lru_train_apply")
         cur.wait_stream(self._stream)
-        return self._out[2]
+        return self._out[3]
 
     def train_step(self, tokens, labels, lr=None, all_reduce=None):
         """One optimizer step. all_reduce: optional callable(tensor) that averages the flat gradient buffer across

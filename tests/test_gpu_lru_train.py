@@ -81,6 +81,22 @@ def test_trained_weights_feed_the_scoring_path(golden_dir):
     assert np.abs(scores - z["final_scores_last"]).max() < 2e-3
 
 
+def test_out_of_range_labels_are_ignored_and_counted(golden_dir):
+    z, names = load(golden_dir)
+    eng = make_engine(z, names)
+    ref = float(eng.loss_and_grads(z["tokens"], z["labels"]))
+    g_ref = eng.grads.clone()
+    assert eng.bad_labels == 0
+    lab = z["labels"].copy()
+    tok = z["tokens"].copy()
+    # two extra rows whose labels are garbage: they must not fault, not change the loss, not add gradient
+    lab2 = np.concatenate([lab, np.full((2, lab.shape[1]), 10 ** 6), np.full((1, lab.shape[1]), -5)])
+    tok2 = np.concatenate([tok, tok[:3]])
+    loss = float(eng.loss_and_grads(tok2, lab2))
+    assert eng.bad_labels == 3 * lab.shape[1]
+    assert abs(loss - ref) < 1e-6 and torch.allclose(eng.grads, g_ref, rtol=1e-4, atol=1e-7)
+
+
 def test_graph_replay_equals_direct_launches(golden_dir):
     """hipGraph replay (default) and plain launches walk the same arithmetic: same losses over several steps,
     including a change of batch shape (re-capture) and of the learning rate / clip limit (device-side scalars)."""
