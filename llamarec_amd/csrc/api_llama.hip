@@ -180,7 +180,7 @@ extern "C" int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_i
   int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
   if (rc) return rc;
   return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : cu_seqlens, h->final_norm, h->lm_head,
-                        label_token_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out_scores, st);
+                        label_token_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out_scores, h->cfg.vocab_size, st);
 }
 
 extern "C" int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
@@ -192,7 +192,7 @@ extern "C" int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, co
   int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
   if (rc) return rc;
   return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : cu_seqlens, h->final_norm, h->lm_head,
-                        nullptr, B, h->cfg.vocab_size, h->cfg.hidden_size, h->cfg.rms_eps, out_logits, st);
+                        nullptr, B, h->cfg.vocab_size, h->cfg.hidden_size, h->cfg.rms_eps, out_logits, h->cfg.vocab_size, st);
 }
 
 extern "C" int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,

@@ -91,7 +91,7 @@ __global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, flo
 // grid (B, ceil(C/32)); out[b][c] = float(bf16(sum_k xn[k] * W[row_c][k])), row_c = ids ? ids[c] : c
 __global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* cu, const u16* norm_w,
                                                    const u16* lm_head, const int32_t* class_ids, int C,
-                                                   int d, float eps, float* out) {
+                                                   int d, float eps, float* out, int vocab) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   u16* xn = reinterpret_cast<u16*>(smem_raw);  // [d]
   __shared__ float red[4];
@@ -113,6 +113,10 @@ __global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* 
     int c = blockIdx.y * 32 + cc;
     if (c >= C) break;
     int r = class_ids ? class_ids[c] : c;
+    if (r < 0 || r >= vocab) {  // a label word outside the vocabulary: NaN score instead of a wild read
+      if (lane == 0) out[(size_t)b * C + c] = __builtin_nanf("");
+      continue;
+    }
     const u16* wr = lm_head + (size_t)r * d;
     float acc = 0.f;
     for (int k = lane * 8; k < d; k += 512) {
@@ -170,10 +174,11 @@ int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st) 
 }
 
 int lr_launch_head(const u16* x, const int32_t* cu, const u16* norm_w, const u16* lm_head,
-                   const int32_t* class_ids, int B, int C, int d, float eps, float* out, hipStream_t st) {
+                   const int32_t* class_ids, int B, int C, int d, float eps, float* out, int vocab,
+                   hipStream_t st) {
   dim3 grid(B, (C + 31) / 32);
   hipLaunchKernelGGL(head_kernel, grid, dim3(256), (size_t)d * sizeof(u16), st, x, cu, norm_w, lm_head,
-                     class_ids, C, d, eps, out);
+                     class_ids, C, d, eps, out, vocab);
   LR_CHECK_LAUNCH("head_kernel");
   return LR_OK;
 }

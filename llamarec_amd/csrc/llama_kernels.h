@@ -39,7 +39,7 @@ int lr_launch_rmsnorm(const unsigned short* x, const unsigned short* w, unsigned
 int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st);
 int lr_launch_head(const unsigned short* x, const int32_t* cu, const unsigned short* norm_w,
                    const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
-                   float* out, hipStream_t st);
+                   float* out, int vocab, hipStream_t st);
 
 // C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 2..4 256x256x64 MFMA tile,
 // 5 = variant 4 with split-K when the tiles alone would leave most CUs idle (needs splitk_ws).

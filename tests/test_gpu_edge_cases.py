@@ -127,6 +127,9 @@ def test_llama_errors(tiny_llama):
     # token ids outside the vocabulary are clamped to id 0 rather than faulting
     out = model.prefill_verbalize([np.array([1, 99999, -5, 7])], list(range(20)))
     assert torch.isfinite(out).all()
+    # a label word outside the vocabulary gives a NaN score for that class only (no wild read of lm_head)
+    bad = model.prefill_verbalize([np.array([1, 5, 7])], [3, cfg["vocab_size"], -1, 4])
+    assert torch.isnan(bad[0, 1]) and torch.isnan(bad[0, 2]) and torch.isfinite(bad[0, [0, 3]]).all()
 
 
 def test_rank_classes_ties_and_histogram_absent_labels():
