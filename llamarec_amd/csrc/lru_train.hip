@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
   const int ks0 = (int)((long long)blockIdx.z * ksteps / gridDim.z), ks1 = (int)((long long)(blockIdx.z + 1) * ksteps / gridDim.z);
   const bool want_rowsum = rowsum != nullptr && blockIdx.x == 0;
   float rs = 0.f;
-  for (int k0 = ks0 * TG_BK; k0 < ks1 * TG_BK; k0 += TG_BK) {
-    float va[8], vb[8];
+  // register double buffer: the global loads of K step k+1 are issued before the MFMAs of step k
+  float va[8], vb[8];
+  auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int e = tid + 256 * i;
@@ -173,6 +174,9 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
         vb[i] = (gn < N && gk < K) ? B[gk * sbk + gn * sbn] : 0.f;
       }
     }
+  };
+  if (ks0 < ks1) load_tile(ks0 * TG_BK);
+  for (int k0 = ks0 * TG_BK; k0 < ks1 * TG_BK; k0 += TG_BK) {
     __syncthreads();  // previous tile consumed
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
       Bs[b_kfast ? (e & 31) : (e >> 6)][b_kfast ? (e >> 5) : (e & 63)] = vb[i];
     }
     __syncthreads();
+    if (k0 + TG_BK < ks1 * TG_BK) load_tile(k0 + TG_BK);
     if (want_rowsum && tid < TG_BM) {
 #pragma unroll
       for (int kk = 0; kk < TG_BK; ++kk) rs += As[kk][tid];
