@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--workload", default="ml-100k")
     ap.add_argument("--layers", type=int, default=32, help="Llama layers (32 = Llama-2-7b; other values are for profiling only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the short Beauty-shape side measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to "
                     "rehearse several ranks on one GPU)")
@@ -225,6 +226,32 @@ def main():
                         "users_counted": total_users},
         }
         out.update(extra)
+        if world == 1 and not args.no_other_shapes and args.workload != "beauty" and args.layers == LLAMA2_7B["num_hidden_layers"]:
+            # north_star also names the Beauty shape (configs[2], the item-GEMM roofline point): a short side
+            # measurement with the same ranker weights -- reported, never the metric
+            wb = WORKLOADS["beauty"]
+            hb, lb, _, Tb = synth_users("beauty", 6 * wb["rerank_batch"])
+            rb = LRURec.from_state_dict(init_lru_state_dict(wb["V"], seed=42), device=dev)
+            pb = TwoStagePipeline(rb, ranker, label_ids, device=dev)
+            bb = []
+            for b in range(6):
+                sl = slice(b * wb["rerank_batch"], (b + 1) * wb["rerank_batch"])
+                pids, cu = synth_prompt_tokens(Tb[sl], seed=77 + b)
+                bb.append((torch.from_numpy(hb[sl]).to(dev), torch.from_numpy(lb[sl]).to(dev), torch.from_numpy(pids).to(dev),
+                           torch.from_numpy(cu).to(dev), cu))
+            for i in range(2):
+                pb.step(*bb[i])
+            pb.reset()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(2, 6):
+                pb.step(*bb[i])
+            pb.finish()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            out["beauty_shape"] = {"users_per_s": 4 * wb["rerank_batch"] / tb, "steps": 4, "users_per_step": wb["rerank_batch"],
+                                   "mean_prompt_tokens_per_step": float(np.mean([b[4][-1] for b in bb[2:]])),
+                                   "ms_per_step": tb / 4 * 1e3}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, hist, T[:4], lru_sd)
         print(json.dumps(out))

@@ -13,9 +13,9 @@ mkdir -p "$OUT" "$ROOT/profiles"
 export TMPDIR=/tmp
 cd /tmp
 
-PMC_BENCH="--steps 1 --warmup 1 --layers 2 --no-cpu-baseline --no-profile"
+PMC_BENCH="--steps 1 --warmup 1 --layers 2 --no-cpu-baseline --no-profile --no-other-shapes"
 echo "[profile] kernel trace of bench.py"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_kt.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-other-shapes > "$OUT/bench_kt.log" 2>&1
 echo "[profile] pmc FETCH_SIZE (2-layer slice: the per-launch GEMM numbers do not depend on depth)"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $PMC_BENCH > "$OUT/bench_pmc_fetch.log" 2>&1
 echo "[profile] pmc WRITE_SIZE"
