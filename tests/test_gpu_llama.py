@@ -282,3 +282,33 @@ def test_last_layer_pruning_matches_full_last_layer(golden_dir):
         orc = LO.last_logits(sd, cfg, seqs, "bf16")
         assert np.abs(pruned - full).max() < 2e-2
         assert np.abs(pruned - orc).max() < 3e-2 and np.abs(full - orc).max() < 3e-2
+
+
+def test_full_depth_llama2_7b_properties():
+    """BASELINE configs[1] size: all 32 Llama-2-7b layers (synthetic bf16 weights, 13.5 GB). The numpy oracle
+    needs minutes per prompt at this size, so the checks are the size-independent ones: run-to-run and
+    batch-composition bit-exactness, last-layer pruning == full last layer and latency mode == default at bf16
+    resolution, and a 1-token / max-context mix staying finite."""
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+
+    model = LlamaRanker.random_init(dict(LLAMA2_7B), seed=3)
+    rng = np.random.default_rng(1)
+    lens = [460, 1, 700, 129, 300]
+    seqs = [np.concatenate([[1], rng.integers(3, 32000, size=n - 1)]) if n > 1 else np.array([1]) for n in lens]
+    label_ids = list(range(319, 339))
+    a = model.prefill_verbalize(seqs, label_ids)
+    b = model.prefill_verbalize(seqs, label_ids)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    alone = model.prefill_verbalize([seqs[2]], label_ids)
+    assert torch.equal(alone[0], a[2])
+    rev = model.prefill_verbalize(seqs[::-1], label_ids)
+    assert torch.equal(rev, a.flip(0))
+    scale = max(1.0, float(a.abs().max()))
+    full_last = model.set_last_layer_pruning(False).prefill_verbalize(seqs, label_ids)
+    model.set_last_layer_pruning(True)
+    assert (full_last - a).abs().max() < 5e-2 * scale
+    lat = model.set_variants(5, 0).prefill_verbalize(seqs[:2], label_ids)
+    model.set_variants(0, 0)
+    assert (lat - a[:2]).abs().max() < 5e-2 * scale
+    # scores are bf16 values (lm_head output of a bf16 model, widened)
+    assert np.array_equal(a.cpu().numpy(), bf16_round(a.cpu().numpy()))

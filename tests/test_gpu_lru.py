@@ -121,3 +121,44 @@ def test_metrics_histogram(env, golden_dir):
         assert abs(got[k] - v) < 1e-6
     oi, _ = O.topk(z["s20"], 20)
     assert np.array_equal(M.rank_classes(torch.from_numpy(z["s20"]).cuda()).cpu().numpy(), oi)
+
+
+def test_full_size_catalog_properties():
+    """BASELINE configs[4] size (1M-item table, L = 200), where the CPU oracle is too slow to rank every user:
+    size-independent properties of the fused retrieve, plus the oracle on a sample of users.
+      * scores come back sorted (desc; ties -> lower id) and equal the materialised scores at the returned ids
+      * nothing from the user's history and no pad id is returned; ids are distinct and in range
+      * top-20 is the prefix of top-50 (what generate_candidates relies on, trainer/lru.py:82-84,113-115)
+      * a user's list does not depend on which other users share the call (chunk geometry changes with B)."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.synth import synth_users
+    from oracle import lru_oracle as O
+
+    V, U = 1_000_000, 300
+    hist, labels, n, T = synth_users("synth-1m", U)
+    sd = init_lru_state_dict(V, seed=42)
+    model = LRURec.from_state_dict(sd)
+    ids = torch.from_numpy(hist).cuda()
+    i50, s50 = model.retrieve_topk(ids, 50, True)
+    i20, s20 = model.retrieve_topk(ids, 20, True)
+    i50n, s50n = i50.cpu().numpy(), s50.cpu().numpy()
+    assert np.array_equal(i20.cpu().numpy(), i50n[:, :20]) and np.array_equal(s20.cpu().numpy(), s50n[:, :20])
+    assert (np.diff(s50n, axis=1) <= 0).all()
+    ties = np.diff(s50n, axis=1) == 0
+    assert (np.diff(i50n, axis=1)[ties] > 0).all()
+    assert i50n.min() >= 1 and i50n.max() <= V
+    for u in range(U):
+        assert len(set(i50n[u])) == 50 and not (set(i50n[u]) & set(hist[u]))
+    # fused scores == materialised scores at the same ids (different kernels, same arithmetic)
+    sub = slice(0, 6)
+    full = model.scores_last(ids[sub], exclude_history=True)
+    assert torch.equal(torch.gather(full, 1, i50[sub].long()), s50[sub])
+    assert torch.equal(full.topk(50, dim=1).values, s50[sub])
+    # batch composition must not matter
+    alone_i, alone_s = model.retrieve_topk(ids[7:8], 50, True)
+    assert torch.equal(alone_i[0], i50[7]) and torch.equal(alone_s[0], s50[7])
+    half_i, _ = model.retrieve_topk(ids[100:229], 50, True)
+    assert torch.equal(half_i, i50[100:229])
+    # and the oracle on two users (about a second each on the CPU)
+    oi, osc = O.LruOracle(sd).retrieve_topk(hist[[3, 211]], 50, True)
+    assert np.array_equal(oi, i50n[[3, 211]]) and np.array_equal(osc, s50n[[3, 211]])
