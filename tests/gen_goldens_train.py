@@ -100,6 +100,18 @@ def main():
     model.eval()
     with torch.no_grad():
         out["final_scores_last"] = model(tokens)[:, -1, :].numpy().astype(np.float32)
+    # a longer trajectory (losses only): 40 more steps at the reference's own limit 5.0
+    model.train()
+    traj = []
+    for step in range(40):
+        opt.zero_grad()
+        logits = model(tokens)
+        loss = ce(logits.view(-1, logits.size(-1)), labels.view(-1))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        traj.append(loss.item())
+    out["traj_loss"] = np.asarray(traj, np.float32)
     out["param_names"] = np.array(names)
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, "lru_train_v120.npz")

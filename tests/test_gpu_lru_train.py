@@ -81,6 +81,19 @@ def test_trained_weights_feed_the_scoring_path(golden_dir):
     assert np.abs(scores - z["final_scores_last"]).max() < 2e-3
 
 
+def test_forty_step_loss_trajectory_matches_reference(golden_dir):
+    """42 optimizer steps on the golden batch: the HIP engine stays on the reference's loss curve."""
+    z, names = load(golden_dir)
+    eng = make_engine(z, names)
+    for step in range(2):
+        eng.loss_and_grads(z["tokens"], z["labels"])
+        eng.apply(max_grad_norm=float(z[f"step{step}/clip_limit"]))
+    ref = z["traj_loss"]
+    for i in range(len(ref)):
+        loss = float(eng.train_step(z["tokens"], z["labels"]))
+        assert abs(loss - float(ref[i])) < 3e-3 * (1 + i / 10), (i, loss, float(ref[i]))
+
+
 def test_out_of_range_labels_are_ignored_and_counted(golden_dir):
     z, names = load(golden_dir)
     eng = make_engine(z, names)
