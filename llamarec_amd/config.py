@@ -64,6 +64,8 @@ def build_parser():
     p.add_argument("--bert_dropout", type=float, default=0.2)
     p.add_argument("--bert_attn_dropout", type=float, default=0.2)
     p.add_argument("--eval_only", action="store_true", help="skip training (a checkpoint must exist)")
+    p.add_argument("--dist_backend", type=str, default=None, help="torch.distributed backend under torchrun (default nccl = RCCL)")
+    p.add_argument("--share_gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (with --dist_backend gloo)")
     p.add_argument("--max_train_iterations", type=int, default=None, help="stop after this many optimizer steps")
     return p
 

@@ -37,13 +37,22 @@ def main(argv=None, export_root=None):
         from llamarec_amd import dist as DD
         from llamarec_amd.train import LRUTrainer
 
-        rank, world, local = DD.init_from_env()
+        if args.share_gpu:
+            os.environ["LOCAL_RANK"] = "0"
+        rank, world, local = DD.init_from_env(args.dist_backend)
         trainer = LRUTrainer(args, device=f"cuda:{local}", export_root=export_root, rank=rank, world=world)
         losses = trainer.train(D.lru_train_sequences(dataset, args.bert_max_len, args.sliding_window_size),
                                list(D.batches(v_ids, v_lab, args.val_batch_size)))
         if rank == 0:
             print(f"trained {trainer.iterations} iterations; epoch losses {[round(x, 4) for x in losses[:3]]} ... "
                   f"{[round(x, 4) for x in losses[-2:]]}; best {args.best_metric} {trainer.best_metric:.4f}")
+        if world > 1:  # replicas must have stayed identical: same averaged gradients, same updates
+            import torch
+
+            p = trainer.engine.params.detach().clone()
+            ref = p.clone()
+            torch.distributed.broadcast(ref, src=0)
+            print(f"rank {rank}: max |param - rank0 param| = {float((p - ref).abs().max()):.3e}")
         DD.barrier()
         if rank != 0:
             return None
