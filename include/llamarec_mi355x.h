@@ -196,8 +196,9 @@ int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_ll
 void lr_llama_destroy(lr_llama_t* h);
 
 /* Kernel selection: 0 = auto (default), 1 = generic kernels, 2 = the MFMA 256x256x64 GEMM /
- * head_dim-128 flash attention, gemm 3 / 4 = ping-pong pipelined 256x256x64 GEMMs (an error if a
- * shape does not fit). gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
+ * head_dim-128 flash attention (K/V by LDS-DMA, 128 query rows per workgroup), attention 3 = the same
+ * arithmetic with register-staged K/V and 256 query rows on 8 waves (measured equal within 3 %, kept for
+ * A/B runs), gemm 3 / 4 = ping-pong pipelined 256x256x64 GEMMs (an error if a shape does not fit). gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
  * variant 4 plus split-K wherever the output tiles alone would leave most CUs idle (a 460-token prompt
  * gives o_proj / down_proj 32 tiles for 256 CUs); shapes that do not fit fall back as in auto. The
  * split-K summation order depends on the token count, so unlike the default a prompt's scores are

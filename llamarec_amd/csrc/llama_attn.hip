@@ -381,6 +381,212 @@ extern "C" int lr_debug_attn_stamps(unsigned long long* out, int n) {
   return LR_OK;
 }
 
+// =============================================================================================
+// MFMA, head_dim 128, register-staged K/V, 8 waves (variant 3)
+// =============================================================================================
+// Same per-wave arithmetic as attn_mfma128_kernel (32 query rows per wave, everything transposed), different
+// data movement: a workgroup is 8 waves = 256 query rows of one (prompt, head), and the next K/V tile is
+// fetched by ordinary global loads into registers right after S = K Q^T has been issued, rides through the
+// softmax and the P V product, and is written to the other LDS buffer (ds_write_b128, swizzles applied on the
+// write side) just before the block's single barrier. The stamps of the LDS-DMA kernel showed ~980 cycles of
+// DMA issue and ~1080 of barrier / DMA wait per 64-key block against ~1450 of MFMA work; here a block costs four
+// loads and four LDS writes per lane, the memory latency hides behind softmax + P V, and twice the query rows
+// share every staged tile.
+#define FB_QROWS 256
+
+__global__ __launch_bounds__(512, 1) void attn_mfma128_rs_kernel(const u16* __restrict__ qkv, u16* out,
+                                                                 const int32_t* cu, int nh, int nkv, int max_qblocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K 16 KiB | V 16 KiB]
+  const int hd = 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qb = max_qblocks - 1 - (int)blockIdx.x;  // heavy (late) query blocks first
+  const int tok0 = cu[b];
+  const int T = cu[b + 1] - tok0;
+  if (qb * FB_QROWS >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = lane >> 4, li = lane & 15;
+  const int kvh = h / (nh / nkv);
+  const int stride = (nh + 2 * nkv) * hd;
+  const u16* kbase = qkv + (size_t)tok0 * stride + (nh + kvh) * hd;
+  const u16* vbase = qkv + (size_t)tok0 * stride + (nh + nkv + kvh) * hd;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): row q, d = 32*ks + 8*quad + 0..7
+  bf16x8 qf[2][4];
+  int qabs[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qabs[qt] = qb * FB_QROWS + wave * 32 + qt * 16 + li;
+    const int qr = min(qabs[qt], T - 1);
+    const u16* qp = qkv + (size_t)(tok0 + qr) * stride + h * hd + quad * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+  }
+  floatx4 ot[2][8];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
+  float l_run[2] = {0.f, 0.f};
+
+  const int q_last = min(qb * FB_QROWS + FB_QROWS - 1, T - 1);
+  const int kb_last = q_last / FA_KB;
+  const int wave_q_first = qb * FB_QROWS + wave * 32;
+  const int wave_q_last = wave_q_first + 31;
+  const bool wave_live = wave_q_first < T;  // a wave whose rows are all past the prompt only helps with staging
+  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+
+  // ---- staging: thread -> (row = tid>>4 [+32], 16-byte chunk = tid&15) of the 64 x 256-byte K and V tiles
+  const int srow = tid >> 4, schunk = tid & 15;
+  u16x8 kreg[2], vreg[2];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = min(kb * FA_KB + srow + 32 * i, T - 1);
+      kreg[i] = *reinterpret_cast<const u16x8*>(kbase + (size_t)key * stride + schunk * 8);
+      vreg[i] = *reinterpret_cast<const u16x8*>(vbase + (size_t)key * stride + schunk * 8);
+    }
+  };
+  auto commit = [&](int buf) {
+    char* Ks = smem + buf * FA_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow + 32 * i;
+      *reinterpret_cast<u16x8*>(Ks + row * 256 + ((schunk ^ (row & 15)) << 4)) = kreg[i];
+      *reinterpret_cast<u16x8*>(Ks + FA_TILE_BYTES + v_off(row, schunk)) = vreg[i];
+    }
+  };
+  fetch(0);
+  commit(0);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));  // Q resident before the loop
+  __syncthreads();
+
+  for (int kb = 0; kb <= kb_last; ++kb) {
+    const char* Ks = smem + (kb & 1) * FA_STAGE_BYTES;
+    const char* Vs = Ks + FA_TILE_BYTES;
+    const bool work = wave_live && kb * FA_KB <= wave_q_last;  // otherwise every key of the block is masked for this wave
+    floatx4 st[2][4];
+    if (work) {
+      // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 kf[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = nt * 16 + li;
+        kf[0][nt] = *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((quad ^ (row & 15)) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int row = nt * 16 + li;
+            kf[(ks + 1) & 1][nt] =
+                *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((((ks + 1) * 4 + quad) ^ (row & 15)) << 4));
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+            st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][nt], qf[qt][ks], st[qt][nt], 0, 0, 0);
+      }
+    }
+    // ---- next tile: global -> registers now, LDS after this block's P V
+    if (kb < kb_last) fetch(kb + 1);
+    if (work) {
+      // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
+      bf16x8 pa[2][2];
+      const bool diag = (kb * FA_KB + FA_KB - 1) > wave_q_first;  // block needs masking
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (diag) {
+              const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
+              st[qt][nt][r] = (key <= qabs[qt]) ? st[qt][nt][r] : -__builtin_inff();
+            }
+            mx = fmaxf(mx, st[qt][nt][r]);
+          }
+        mx = fa_max_xor16_32(mx);
+        const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
+        const bool grew = m_new > m_run[qt];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][nt][r], sl2, -m_new));
+            ps += p;
+            pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
+          }
+        l_run[qt] = l_run[qt] * alpha + ps;
+        if (__any(grew)) {
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
+        }
+      }
+      // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
+      const int qp = li >> 2, p4 = li & 3;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const int row0 = ks2 * 32 + quad * 4 + qp;
+          const int ch = dt * 2 + (p4 >> 1);
+          const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0, ch) + 8 * (p4 & 1)));
+          const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0 + 16, ch) + 8 * (p4 & 1)));
+          bf16x8 vf;
+          const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            vf[r] = b0[r];
+            vf[4 + r] = b1[r];
+          }
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+            ot[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa[qt][ks2], ot[qt][dt], 0, 0, 0);
+        }
+      }
+    }
+    if (kb < kb_last) commit((kb + 1) & 1);  // buffer (kb+1)&1 was last read in block kb-1, before its barrier
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float l = fa_sum_xor16_32(l_run[qt]);
+    const float inv = 1.0f / l;
+    if (qabs[qt] < T) {
+      u16* op = out + (size_t)(tok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(ot[qt][dt][r] * inv);
+        *reinterpret_cast<u16x4*>(op + dt * 16) = o;
+      }
+    }
+  }
+}
+
 // attention for a list of query tokens only (the last layer needs just each prompt's last token)
 int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B, const int32_t* q_rows,
                              int n_rows, int nh, int nkv, int hd, hipStream_t st) {
@@ -408,8 +614,23 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     double T = cu_host[b + 1] - cu_host[b];
     work += 4.0 * nh * hd * (T * (T + 1) / 2);
   }
-  LrProfScope prof(variant == 2 ? LR_PROF_ATTN_MFMA : LR_PROF_ATTN_GENERIC, work, st);
-  if (variant == 2) {
+  LrProfScope prof(variant >= 2 ? LR_PROF_ATTN_MFMA : LR_PROF_ATTN_GENERIC, work, st);
+  if (variant == 3) {
+    if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 3 needs head_dim 128 (got %d)", hd);
+    int maxT = 0;
+    for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
+    const int mq = (maxT + FB_QROWS - 1) / FB_QROWS;
+    if (mq == 0) return LR_OK;
+    static bool attr_set3 = false;
+    if (!attr_set3) {
+      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_rs_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
+      attr_set3 = true;
+    }
+    hipLaunchKernelGGL(attn_mfma128_rs_kernel, dim3(mq, nh, B), dim3(512), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh, nkv,
+                       mq);
+    LR_CHECK_LAUNCH("attn_mfma128_rs_kernel");
+  } else if (variant == 2) {
     if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 2 needs head_dim 128 (got %d)", hd);
     int maxT = 0;
     for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);

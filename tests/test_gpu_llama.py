@@ -149,7 +149,8 @@ def attention_ref(qkv, cu, nh, nkv, hd):
     return out
 
 
-@pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 1), (4, 2, 16, 1), (2, 2, 64, 1)])
+@pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 3), (4, 2, 128, 3), (4, 4, 128, 1),
+                                               (4, 2, 16, 1), (2, 2, 64, 1)])
 def test_attention_vs_numpy(nh, nkv, hd, variant):
     lens = [1, 63, 64, 65, 128, 129, 300, 2]
     cu = np.concatenate([[0], np.cumsum(lens)])
@@ -171,7 +172,7 @@ def load_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,variants", [("tiny_hd16", (0, 0)), ("tiny_gqa", (0, 0)), ("tiny_hd128", (1, 1)),
-                                           ("tiny_hd128", (2, 2)), ("tiny_hd128", (0, 0))])
+                                           ("tiny_hd128", (2, 2)), ("tiny_hd128", (2, 3)), ("tiny_hd128", (0, 0))])
 def test_prefill_logits_vs_oracle_and_reference(golden_dir, name, variants):
     from llamarec_amd.llm import LlamaRanker
     from oracle import llama_oracle as LO
