@@ -68,6 +68,60 @@ def g4(functions_from, OUT, REF):
               open(os.path.join(OUT, "prompts.json"), "w"), indent=1, ensure_ascii=False)
 
 
+class _Recording:
+    """Delegates to a real tokenizer and remembers the texts it was called with."""
+
+    def __init__(self, tok):
+        self._tok, self.seen_texts = tok, []
+
+    def __getattr__(self, name):
+        return getattr(self._tok, name)
+
+    def __call__(self, text, **kw):
+        self.seen_texts.append(text)
+        return self._tok(text, **kw)
+
+
+def g4hf(functions_from, load_by_path, OUT, REF):
+    """G4 again with a REAL HF fast tokenizer built offline (tests/local_tokenizer.py): sub-word title truncation,
+    metaspace decoding, BOS handling and HF's left truncation are the reference's, not a stand-in's. Also the
+    verbalizer's label-word ids for that tokenizer (trainer/verb.py:486-522 via demo/verb.py, identical class)."""
+    from tests.local_tokenizer import build_llama_like_tokenizer
+
+    argv, cwd = sys.argv, os.getcwd()
+    sys.argv = ["x"]
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    try:
+        import dataloader.llm as DL  # noqa
+        from dataloader.utils import Prompter
+        import config as ref_config
+
+        prompter = Prompter()
+        ref_args = ref_config.args
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    cases = []
+    for title_len, text_len in ((32, 1536), (3, 1536), (4, 48)):
+        args = SimpleNamespace(llm_max_title_len=title_len, llm_max_text_len=text_len,
+                               llm_system_template=ref_args.llm_system_template,
+                               llm_input_template=ref_args.llm_input_template, llm_train_on_inputs=False)
+        for seq, cands, label in (([1, 2, 3], [4, 5, 2], 5), ([7], [8, 9, 10, 6], 8),
+                                  ([1, 2, 3, 4, 5, 6, 7, 8, 9], [10, 1], 10)):
+            tok = _Recording(build_llama_like_tokenizer())
+            ev = DL.seq_to_token_ids(args, seq, cands, label, TITLES, tok, prompter, eval=True)
+            cases.append({"llm_max_title_len": title_len, "llm_max_text_len": text_len, "seq": seq,
+                          "candidates": cands, "label": label, "prompt_eval": tok.seen_texts[-1],
+                          "eval": {k: [int(x) for x in ev[k]] if isinstance(ev[k], (list, tuple)) else int(ev[k])
+                                   for k in ("input_ids", "attention_mask", "labels")}})
+    V = load_by_path("ref_demo_verb_hf", os.path.join(REF, "demo", "verb.py"))
+    verb = V.ManualVerbalizer(tokenizer=build_llama_like_tokenizer(), prefix="", post_log_softmax=False,
+                              classes=list(range(20)), label_words={i: chr(ord("A") + i) for i in range(20)})
+    json.dump({"cases": cases, "label_words_ids": verb.label_words_ids.detach().numpy().tolist()},
+              open(os.path.join(OUT, "prompts_hf.json"), "w"), indent=1, ensure_ascii=False)
+
+
 LLAMA_CONFIGS = {
     # name: (vocab, hidden, inter, layers, heads, kv_heads)
     "tiny_hd16": (320, 64, 128, 2, 4, 4),
@@ -170,6 +224,7 @@ def g7(methods_from, OUT, REF):
 def run(which, load_by_path, methods_from, functions_from, OUT, REF):
     if "g4" in which:
         g4(functions_from, OUT, REF)
+        g4hf(functions_from, load_by_path, OUT, REF)
     if "g5" in which:
         g5(OUT, REF)
     if "g6" in which:

@@ -72,3 +72,31 @@ def test_overall_metric_merge(golden_dir):
     assert list(overall.keys()) == list(g["overall_metrics_json"].keys())
     for k, v in g["overall_metrics_json"].items():
         assert abs(overall[k] - v) < 1e-12
+
+
+def test_prompts_and_label_ids_with_a_real_hf_tokenizer(golden_dir, prompts):
+    """Same cases as above through a REAL HF fast tokenizer (tests/local_tokenizer.py, built offline): sub-word
+    title truncation + convert_tokens_to_string, BOS, HF's left truncation (BOS survives, the oldest tokens go),
+    and the verbalizer's label-word ids -- against what the reference's own functions produced with it."""
+    from llamarec_amd.verb import ManualVerbalizer
+    from tests.gen_goldens_llm import _Recording
+    from tests.local_tokenizer import build_llama_like_tokenizer
+
+    g = json.load(open(os.path.join(golden_dir, "prompts_hf.json")))
+    for c in g["cases"]:
+        tok = _Recording(build_llama_like_tokenizer())
+        out = P.seq_to_token_ids(c["seq"], c["candidates"], c["label"], prompts["titles"], tok,
+                                 max_title_len=c["llm_max_title_len"], max_text_len=c["llm_max_text_len"])
+        assert tok.seen_texts[-1] == c["prompt_eval"]
+        assert list(out["input_ids"]) == c["eval"]["input_ids"]
+        assert list(out["attention_mask"]) == c["eval"]["attention_mask"]
+        assert out["labels"] == c["eval"]["labels"]
+        assert len(out["input_ids"]) <= c["llm_max_text_len"] and out["input_ids"][0] == tok.bos_token_id
+    # a title longer than 4 sub-word tokens really was cut, and a truncated prompt kept its BOS and its tail
+    short = [c for c in g["cases"] if c["llm_max_text_len"] == 48]
+    assert short and all(len(c["eval"]["input_ids"]) == 48 for c in short)
+    verb = ManualVerbalizer(tokenizer=build_llama_like_tokenizer(), prefix="", post_log_softmax=False,
+                            classes=list(range(20)), label_words={i: chr(ord("A") + i) for i in range(20)})
+    ref_ids = np.asarray(g["label_words_ids"])
+    assert ref_ids.shape[:2] == (20, 1)
+    assert list(verb.label_token_ids) == ref_ids[:, 0, 0].tolist()
