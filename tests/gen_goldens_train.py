@@ -37,7 +37,39 @@ def to_np(t):
     return t.numpy().astype(np.float32)
 
 
+def datasets_golden():
+    """G9: LRUTrainDataset / LRUValidDataset / LRUTestDataset of the reference (dataloader/lru.py:92-180) on a small
+    synthetic user->sequence map -> tests/golden/lru_datasets.json (every sample, in order)."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("ref_dataloader_lru", os.path.join(REF, "dataloader", "lru.py"))
+    DL = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(DL)
+    rng = np.random.default_rng(5)
+    train, val, test = {}, {}, {}
+    for u, n in enumerate([3, 9, 10, 11, 17, 18, 19, 26, 40, 7, 2, 1], start=1):
+        items = rng.integers(1, 60, size=n + 2).tolist()
+        train[u], val[u], test[u] = items[:-2], items[-2:-1], items[-1:]
+    val[10], test[11] = [], []          # users the eval datasets must drop
+    out = {"train": {str(k): v for k, v in train.items()}, "val": {str(k): v for k, v in val.items()},
+           "test": {str(k): v for k, v in test.items()}, "cases": []}
+    args = SimpleNamespace(num_items=60)
+    for max_len, sliding in ((8, 1.0), (8, 0.5), (5, 1.0)):
+        ds = DL.LRUTrainDataset(args, train, max_len, sliding, rng)
+        samples = [[t.tolist() for t in ds[i]] for i in range(len(ds))]
+        vd = DL.LRUValidDataset(args, train, val, max_len, rng)
+        td = DL.LRUTestDataset(args, train, val, test, max_len, rng)
+        out["cases"].append({"max_len": max_len, "sliding_window_size": sliding, "train_samples": samples,
+                             "val_users": list(vd.users), "val": [[t.tolist() for t in vd[i]] for i in range(len(vd))],
+                             "test_users": list(td.users), "test": [[t.tolist() for t in td[i]] for i in range(len(td))]})
+    path = os.path.join(OUT, "lru_datasets.json")
+    json.dump(out, open(path, "w"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    datasets_golden()
     sys.path.insert(0, REF)
     from model.lru import LRURec  # reference import
 

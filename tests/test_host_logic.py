@@ -100,3 +100,24 @@ def test_prompts_and_label_ids_with_a_real_hf_tokenizer(golden_dir, prompts):
     ref_ids = np.asarray(g["label_words_ids"])
     assert ref_ids.shape[:2] == (20, 1)
     assert list(verb.label_token_ids) == ref_ids[:, 0, 0].tolist()
+
+
+def test_lru_datasets_match_reference(golden_dir):
+    """llamarec_amd.data mirrors of LRUTrainDataset / LRUValidDataset / LRUTestDataset (dataloader/lru.py:92-180)
+    against every sample the reference classes produced (tests/gen_goldens_train.py G9)."""
+    from llamarec_amd import data as D
+
+    g = json.load(open(os.path.join(golden_dir, "lru_datasets.json")))
+    ds = {k: {int(u): v for u, v in g[k].items()} for k in ("train", "val", "test")}
+    for c in g["cases"]:
+        L = c["max_len"]
+        seqs = D.lru_train_sequences(ds, L, c["sliding_window_size"])
+        tok, lab = D.lru_train_batch(seqs, L)
+        assert len(seqs) == len(c["train_samples"])
+        assert tok.tolist() == [s[0] for s in c["train_samples"]] and lab.tolist() == [s[1] for s in c["train_samples"]]
+        users, ids, labels = D.lru_eval_arrays(ds, "val", L)
+        assert users == c["val_users"] and ids.tolist() == [s[0] for s in c["val"]]
+        assert labels.tolist() == [s[1][:1] for s in c["val"]]
+        users, ids, labels = D.lru_eval_arrays(ds, "test", L)
+        assert users == c["test_users"] and ids.tolist() == [s[0] for s in c["test"]]
+        assert labels.tolist() == [s[1][:1] for s in c["test"]]
