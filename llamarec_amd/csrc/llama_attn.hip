@@ -281,16 +281,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       for (int qt = 0; qt < 2; ++qt) {
         // raw-score row maximum (the scale is positive, so max commutes with it)
         float mx = -__builtin_inff();
+        if (diag) {  // a real (wave-uniform) branch: written as a select inside the loop below, hipcc predicates
+                     // all 32 scores of every block -- ~100 wasted VALU instructions on the off-diagonal blocks
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+          for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (diag) {
+            for (int r = 0; r < 4; ++r) {
               const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
               st[qt][nt][r] = (key <= qabs[qt]) ? st[qt][nt][r] : -__builtin_inff();
             }
-            mx = fmaxf(mx, st[qt][nt][r]);
-          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][nt][r]);
         mx = fa_max_xor16_32(mx);
         const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
         const bool grew = m_new > m_run[qt];
@@ -508,16 +513,21 @@ __global__ __launch_bounds__(512, 1) void attn_mfma128_rs_kernel(const u16* __re
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         float mx = -__builtin_inff();
+        if (diag) {  // a real (wave-uniform) branch: written as a select inside the loop below, hipcc predicates
+                     // all 32 scores of every block -- ~100 wasted VALU instructions on the off-diagonal blocks
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+          for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (diag) {
+            for (int r = 0; r < 4; ++r) {
               const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
               st[qt][nt][r] = (key <= qabs[qt]) ? st[qt][nt][r] : -__builtin_inff();
             }
-            mx = fmaxf(mx, st[qt][nt][r]);
-          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][nt][r]);
         mx = fa_max_xor16_32(mx);
         const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
         const bool grew = m_new > m_run[qt];
