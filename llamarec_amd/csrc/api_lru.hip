@@ -95,12 +95,28 @@ extern "C" void lr_lru_destroy(lr_lru_t* h) { free(h); }
 
 static size_t q_bytes(int B) { return lr_align_up((size_t)B * 64 * sizeof(float), 256); }
 
+// Encoder dispatch: the batched MFMA encoder when the caller's workspace has room for it (what
+// lr_lru_workspace_bytes asks for), else the one-workgroup-per-user kernel (no workspace); LR_ENCODER=1 forces
+// the latter for A/B runs. Both produce the same bits.
+static int encode(lr_lru_t* h, const int64_t* ids, int B, int L, float* q, void* ws, size_t ws_bytes, hipStream_t st) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("LR_ENCODER");
+    forced = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (!forced && ws && ws_bytes >= lr_encoder_mfma_workspace_bytes(B, L))
+    return lr_launch_lru_encode_mfma(h, ids, B, L, q, ws, ws_bytes, st);
+  return lr_launch_lru_encode(h, ids, B, L, q, st);
+}
+
 extern "C" size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k, int32_t max_len) {
   (void)h;
   if (max_users < 1) max_users = 1;
   if (max_k < 1) max_k = 1;
   if (max_len < 1) max_len = 1;
-  return q_bytes(max_users) + lr_topk_workspace_bytes(max_users, max_k, max_len);
+  // [q | encoder scratch or top-K scratch (never live together)]
+  const size_t enc = lr_encoder_mfma_workspace_bytes(max_users, max_len), tk = lr_topk_workspace_bytes(max_users, max_k, max_len);
+  return q_bytes(max_users) + (enc > tk ? enc : tk);
 }
 
 static int check_ids(const char* fn, const lr_lru_t* h, const void* ids, int B, int L) {
@@ -111,12 +127,10 @@ static int check_ids(const char* fn, const lr_lru_t* h, const void* ids, int B, 
 
 extern "C" int lr_lru_encode_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, float* out_q,
                                   void* workspace, size_t workspace_bytes, void* hip_stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   int rc = check_ids("lr_lru_encode_last", h, ids, B, L);
   if (rc) return rc;
   if (!out_q) LR_FAIL(LR_EINVAL, "lr_lru_encode_last: out_q is null");
-  return lr_launch_lru_encode(h, ids, B, L, out_q, (hipStream_t)hip_stream);
+  return encode(h, ids, B, L, out_q, workspace, workspace_bytes, (hipStream_t)hip_stream);
 }
 
 extern "C" int lr_lru_retrieve_topk(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, int32_t K,
@@ -129,7 +143,7 @@ extern "C" int lr_lru_retrieve_topk(lr_lru_t* h, const int64_t* ids, int32_t B, 
   if (workspace_bytes < q_bytes(B)) LR_FAIL(LR_EWORKSPACE, "lr_lru_retrieve_topk: workspace too small");
   float* q = (float*)workspace;
   hipStream_t st = (hipStream_t)hip_stream;
-  rc = lr_launch_lru_encode(h, ids, B, L, q, st);
+  rc = encode(h, ids, B, L, q, (char*)workspace + q_bytes(B), workspace_bytes - q_bytes(B), st);
   if (rc) return rc;
   return lr_launch_item_topk(h, q, ids, B, L, K, exclude_history, out_idx, out_score,
                              (char*)workspace + q_bytes(B), workspace_bytes - q_bytes(B), st);
@@ -144,7 +158,7 @@ extern "C" int lr_lru_scores_last(lr_lru_t* h, const int64_t* ids, int32_t B, in
   if (workspace_bytes < q_bytes(B)) LR_FAIL(LR_EWORKSPACE, "lr_lru_scores_last: workspace too small");
   float* q = (float*)workspace;
   hipStream_t st = (hipStream_t)hip_stream;
-  rc = lr_launch_lru_encode(h, ids, B, L, q, st);
+  rc = encode(h, ids, B, L, q, (char*)workspace + q_bytes(B), workspace_bytes - q_bytes(B), st);
   if (rc) return rc;
   return lr_launch_item_scores(h, q, ids, B, L, exclude_history, out_scores, st);
 }

@@ -108,6 +108,10 @@ struct lr_lru {
 // ---- stage-1 launchers (lru_encoder.hip, lru_topk.hip, metrics.hip) -------------------------
 int lr_launch_lru_encode(const lr_lru* h, const int64_t* ids, int B, int L, float* out_q,
                          hipStream_t st);
+// batched MFMA encoder (lru_encoder_mfma.hip): same result as lr_launch_lru_encode, needs a workspace
+size_t lr_encoder_mfma_workspace_bytes(int B, int L);
+int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L, float* out_q, void* ws,
+                              size_t ws_bytes, hipStream_t st);
 size_t lr_topk_workspace_bytes(int B, int K, int L);
 int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int B, int L, int K,
                         int exclude_history, int32_t* out_idx, float* out_score, void* ws,

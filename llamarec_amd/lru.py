@@ -182,8 +182,9 @@ class LRURec:
         q = torch.empty((B, 64), dtype=torch.float32, device=self.device)
         if B == 0:
             return q
+        ws = self._workspace(B, 1, L)
         with torch.cuda.device(self.device):
-            check(lib().lr_lru_encode_last(self._h, ids.data_ptr(), B, L, q.data_ptr(), None, 0,
+            check(lib().lr_lru_encode_last(self._h, ids.data_ptr(), B, L, q.data_ptr(), ws.data_ptr(), ws.numel(),
                                            stream_ptr()), "lr_lru_encode_last")
         return q
 
@@ -193,7 +194,7 @@ class LRURec:
         out = torch.empty((B, self.num_items + 1), dtype=torch.float32, device=self.device)
         if B == 0:
             return out
-        ws = self._workspace(B, 1)
+        ws = self._workspace(B, 1, L)
         with torch.cuda.device(self.device):
             check(lib().lr_lru_scores_last(self._h, ids.data_ptr(), B, L, int(bool(exclude_history)),
                                            out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
