@@ -327,6 +327,7 @@ __global__ __launch_bounds__(128) void em_scan_kernel(EmChunk c, const float* la
   float* base = U + (size_t)c.off[u] * 256;
   const float lr_ = lam_re[ch], li = lam_im[ch];
   float h_r = 0.f, h_i = 0.f;
+#pragma unroll 4
   for (int t = 0; t < n; ++t) {
     const float br = base[(size_t)t * 256 + ch], bi = base[(size_t)t * 256 + 128 + ch];
     if (t == 0) {
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(128) void em_scan_kernel(EmChunk c, const float* la
 }
 
 // =============================================================================================
-#define EM_CHUNK_ROWS (1 << 18)
+#define EM_CHUNK_ROWS (1 << 21)  // rows per chunk of users (workspace: 1.5 KB per row, at most 3.2 GB; proportional to B*L below that)
 
 static size_t em_chunk_users(int L) {
   size_t u = EM_CHUNK_ROWS / (size_t)L;
