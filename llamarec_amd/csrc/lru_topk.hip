@@ -515,7 +515,9 @@ __global__ void mask_history_kernel(float* scores, int n_rows, const int64_t* id
 }
 
 // Split the item tiles into chunks so that (user tiles x chunks) fills the 256 CUs in whole rounds:
-// minimise rounds x (tiles per chunk + the per-chunk finalisation, ~8 tile-times).
+// minimise rounds x (tiles per chunk + the per-chunk fixed cost). The fixed cost -- the unfiltered first tiles
+// while the thresholds settle, plus compaction + sort of 128 users' lists at the end -- measures ~130 tile-times
+// (Beauty sweep: 1.41 / 1.97 / 2.27 / 2.00 / 2.28 ms for 1..5 chunks = rounds x (0.36 ms + 2.8 us x tiles)).
 static void topk_geometry(int n_tiles, int B, int* n_chunks, int* tiles_per_chunk) {
   const int n_ut = (B + TK_USERS - 1) / TK_USERS;
   int max_chunks = TK_MAX_WGS / n_ut;
@@ -528,12 +530,18 @@ static void topk_geometry(int n_tiles, int B, int* n_chunks, int* tiles_per_chun
     const int tpc = (n_tiles + c - 1) / c;
     const int real = (n_tiles + tpc - 1) / tpc;
     const long rounds = ((long)n_ut * real + 255) / 256;
-    const long cost = rounds * (tpc + 8);
+    const long cost = rounds * (tpc + 128);
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       best = c;
     }
   }
+  static int forced = -1;  // LR_TOPK_CHUNKS=n: tuning knob (0 / unset = the model above)
+  if (forced < 0) {
+    const char* e = getenv("LR_TOPK_CHUNKS");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced > 0 && forced <= max_chunks) best = forced;
   *tiles_per_chunk = (n_tiles + best - 1) / best;
   *n_chunks = (n_tiles + *tiles_per_chunk - 1) / *tiles_per_chunk;
 }

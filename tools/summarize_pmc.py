@@ -29,7 +29,7 @@ def main():
         _, path = spec.split("=", 1)
         by, dur = load(path)
         for k, ctrs in by.items():
-            if not any(t in k for t in ("gemm", "attn", "rmsnorm", "rope", "lru_", "item_", "topk", "head", "embed")):
+            if not any(t in k for t in ("gemm", "attn", "rmsnorm", "rope", "lru_", "item_", "topk", "head", "embed", "em_")):
                 continue
             e = res[k]
             e["launches_profiled"] = max(e.get("launches_profiled", 0), len(dur[k]))
