@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
     for (int j = lane; j < K; j += 64) dst[j] = j < cu ? buf[ul * TK_BSTRIDE + j] : 0ull;
   }
   if (STAMP) {
+    TK_STAMP(6)  // drain + final compaction / sort / write-out
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (wg < 16 && tid == 0) {
 #pragma unroll
@@ -493,16 +494,86 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeParams p) {
 }
 
 // ---- compatibility path: materialised last-position scores ----------------------------------
-__global__ __launch_bounds__(256) void item_scores_kernel(const float* emb, const float* bias,
-                                                          int n_rows, const float* q, int B,
-                                                          float* out) {
-  __shared__ float qs[64];
-  const int user = blockIdx.y;
-  if (threadIdx.x < 64) qs[threadIdx.x] = q[(size_t)user * 64 + threadIdx.x];
+// MFMA version of the materialised scores: the same 32-MFMA chain per (32 items x 32 users) as item_topk_kernel
+// (bit-identical scores), the tile written out through a per-wave LDS transpose so that every user row gets 128
+// contiguous bytes. Workgroup = 128 users x a range of item tiles; grid.x walks the tile ranges.
+#define IS_TS 36  // floats per user row of the transpose tile (16-byte aligned rows)
+__global__ __launch_bounds__(256) void item_scores_mfma_kernel(const float* emb, const float* bias, int n_rows, int n_tiles,
+                                                               const float* q, int B, int tiles_per_wg, float* out) {
+  __shared__ __attribute__((aligned(16))) float etile[2][32 * TK_ESTRIDE];
+  __shared__ __attribute__((aligned(16))) float btile[2][32];
+  __shared__ __attribute__((aligned(16))) float tr[4][32 * IS_TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int user = blockIdx.y * TK_USERS + wave * 32 + col;
+  const bool user_ok = user < B;
+  const int tile_begin = blockIdx.x * tiles_per_wg, tile_end = min(n_tiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+  float bq[32];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(user_ok ? user : 0) * 64 + 32 * half);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = user_ok ? qp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bq[4 * j + 0] = v.x; bq[4 * j + 1] = v.y; bq[4 * j + 2] = v.z; bq[4 * j + 3] = v.w;
+    }
+  }
+  auto stage = [&](int tile, int bufi) {
+    const float4* src = reinterpret_cast<const float4*>(emb + (size_t)tile * 32 * 64);
+    const float4 e0 = src[tid], e1 = src[tid + 256];
+    float* e_ = etile[bufi];
+    *reinterpret_cast<float4*>(e_ + (tid >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e0;
+    *reinterpret_cast<float4*>(e_ + ((tid + 256) >> 4) * TK_ESTRIDE + (tid & 15) * 4) = e1;
+    if (tid < 32) btile[bufi][tid] = bias[tile * 32 + tid];
+  };
+  stage(tile_begin, 0);
   __syncthreads();
-  int item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= n_rows) return;
-  out[(size_t)user * n_rows + item] = lr_item_score(emb + (size_t)item * 64, qs, bias[item]);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int cur = (tile - tile_begin) & 1;
+    if (tile + 1 < tile_end) stage(tile + 1, cur ^ 1);
+    float a[32];
+    {
+      const float* er = etile[cur] + col * TK_ESTRIDE + 32 * half;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(er + 4 * j);
+        a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+      }
+    }
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], acc, 0, 0, 0);
+    // lane = user `col`, register r = item row (r&3) + 8*(r>>2) + 4*half  ->  tr[user][item]
+    float* t = tr[wave];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4*>(&btile[cur][8 * g + 4 * half]);
+      float4 o;
+      o.x = acc[4 * g + 0] + b4.x;
+      o.y = acc[4 * g + 1] + b4.y;
+      o.z = acc[4 * g + 2] + b4.z;
+      o.w = acc[4 * g + 3] + b4.w;
+      *reinterpret_cast<float4*>(t + col * IS_TS + 8 * g + 4 * half) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {  // lane -> (user = lane>>1, 16 items): 64 contiguous bytes per lane, 128 per user row
+      const int ul = lane >> 1, i0 = (lane & 1) * 16;
+      const int gu = blockIdx.y * TK_USERS + wave * 32 + ul;
+      if (gu < B) {
+        float* dst = out + (size_t)gu * n_rows + tile * 32 + i0;
+        const float* srcp = t + ul * IS_TS + i0;
+        if (tile * 32 + i0 + 16 <= n_rows) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) dst[j] = srcp[j];
+        } else {
+          for (int j = 0; j < 16 && tile * 32 + i0 + j < n_rows; ++j) dst[j] = srcp[j];
+        }
+      }
+    }
+    __syncthreads();  // next tile staged; this tile's LDS reads done
+  }
 }
 
 __global__ void mask_history_kernel(float* scores, int n_rows, const int64_t* ids, int B, int L) {
@@ -623,10 +694,16 @@ int lr_launch_item_scores(const lr_lru* h, const float* q, const int64_t* ids, i
                           int exclude_history, float* out_scores, hipStream_t st) {
   if (B <= 0) return LR_OK;
   int n_rows = h->lay.num_items + 1;
-  dim3 grid((n_rows + 255) / 256, B);
-  hipLaunchKernelGGL(item_scores_kernel, grid, dim3(256), 0, st, h->img + h->lay.item_emb,
-                     h->img + h->lay.item_bias, n_rows, q, B, out_scores);
-  LR_CHECK_LAUNCH("item_scores_kernel");
+  {
+    const int n_tiles = h->lay.rows_padded / LR_ITEM_TILE, n_ut = (B + TK_USERS - 1) / TK_USERS;
+    int chunks = (1024 + n_ut - 1) / n_ut;  // ~4 workgroups per CU in flight
+    if (chunks > n_tiles) chunks = n_tiles;
+    const int tpw = (n_tiles + chunks - 1) / chunks;
+    dim3 grid((n_tiles + tpw - 1) / tpw, n_ut);
+    hipLaunchKernelGGL(item_scores_mfma_kernel, grid, dim3(256), 0, st, h->img + h->lay.item_emb, h->img + h->lay.item_bias,
+                       n_rows, n_tiles, q, B, tpw, out_scores);
+    LR_CHECK_LAUNCH("item_scores_mfma_kernel");
+  }
   if (exclude_history) {
     hipLaunchKernelGGL(mask_history_kernel, dim3(B), dim3(256), 0, st, out_scores, n_rows, ids, B, L);
     LR_CHECK_LAUNCH("mask_history_kernel");

@@ -22,6 +22,8 @@ np.set_printoptions(precision=0, suppress=True, linewidth=200)
 print("s_memtime ticks summed over the tile loop, wave 0 of 16 workgroups")
 print("cols: frag reads | thr/bias/mask | chain+filter+inserts | make_room | store(+vmcnt) | barrier (first col also holds the loop-entry offset) | compactions (count) | inserts (count)")
 tpc = (n_tiles + 7) // 8 if name == "synth-1m" else n_tiles
+if os.environ.get("LR_TOPK_CHUNKS"): tpc = (n_tiles + int(os.environ["LR_TOPK_CHUNKS"]) - 1) // int(os.environ["LR_TOPK_CHUNKS"])
 print("per tile (assuming", tpc, "tiles per chunk):")
 print(s / tpc)
 print("mean:", s.mean(0) / tpc, " total:", s.mean(0).sum() / tpc)
+print("totals per workgroup (ticks): loop", s[:, :6].sum(1).mean(), " final", s[:, 6].mean(), " compactions", s[:, 6 if False else 6].mean() * 0, " inserts/tile", s[:, 7].mean() / tpc)
