@@ -126,11 +126,14 @@ __global__ __launch_bounds__(256) void em_proj64_kernel(const float* __restrict_
                                                         const int* __restrict__ rows, const int* n_rows_ptr, int n_rows_fixed,
                                                         float* OUT, int tiles_cap) {
   __shared__ __attribute__((aligned(16))) float xs[EM_TILE * EM_XS];
+  __shared__ float erf_lds[LR_ERF_NINT * (LR_ERF_DEG + 1)];  // lane-divergent coefficient gathers: LDS, not global
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int n_rows = n_rows_ptr ? *n_rows_ptr : n_rows_fixed;
   const int n_tiles = (n_rows + EM_TILE - 1) / EM_TILE;
   if ((int)blockIdx.x >= n_tiles) return;
+  if (EPI == 1)
+    for (int i = tid; i < LR_ERF_NINT * (LR_ERF_DEG + 1); i += 256) erf_lds[i] = em_erf_tab[i];
   // B operand: weights of my two output blocks, de-interleaved k: step s of half h uses k = 2s + h
   float wq[2][32], bq[2], gq[2];
 #pragma unroll
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void em_proj64_kernel(const float* __restrict_
       for (int r = 0; r < 16; ++r) {
         const int gr = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (gr < n_rows) {
-          const float v = EPI == 0 ? acc[r] * gq[j] : lr_gelu_tab(acc[r], em_erf_tab);
+          const float v = EPI == 0 ? acc[r] * gq[j] : lr_gelu_tab(acc[r], erf_lds);
           OUT[(size_t)gr * 256 + out] = v;
         }
       }
@@ -407,7 +410,7 @@ int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L,
     const int* n_rows_ptr = c.off + c.users;
     const int max_tiles = (int)(((size_t)c.users * L + EM_TILE - 1) / EM_TILE);
     const int grid64 = max_tiles < 1024 ? max_tiles : 1024;
-    const int grid256 = (max_tiles + 3) / 4 < 512 ? (max_tiles + 3) / 4 : 512;
+    const int grid256 = (max_tiles + 3) / 4 < 256 ? (max_tiles + 3) / 4 : 256;  // one workgroup per CU stages the 64 KiB of weights once
     const int last_tiles = (c.users + EM_TILE - 1) / EM_TILE;
     hipLaunchKernelGGL(em_live_kernel, dim3((c.users + 3) / 4), dim3(256), 0, st, c);
     LR_CHECK_LAUNCH("em_live_kernel");
