@@ -98,7 +98,10 @@ size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_
  * (model/lru.py:38-41,57-60,73-83; consumers slice [:, -1, :]: trainer/lru.py:33,67,105,
  * demo/inference.py:48).
  *   ids: DEVICE int64 [B][L] row-major, 0 = pad (left padded by the reference's datasets,
- *        dataloader/lru.py:142-151; zeros anywhere are honoured: mask = ids > 0). */
+ *        dataloader/lru.py:142-151; zeros anywhere are honoured: mask = ids > 0).
+ *   workspace: with at least lr_lru_workspace_bytes(h, B, 1, L) bytes the batched MFMA encoder runs (live
+ *        tokens of all users packed into one row matrix); with less (or NULL) a one-workgroup-per-user
+ *        kernel that needs no scratch -- same bits either way. */
 int lr_lru_encode_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, float* out_q,
                        void* workspace, size_t workspace_bytes, void* hip_stream);
 
