@@ -1,11 +1,10 @@
-"""Stage-1 (retrieve) throughput at the BASELINE shapes, one call over many users, plus a
-bit-exactness spot check against the CPU oracle on a sample."""
+"""Stage-1 (retrieve) throughput at the BASELINE shapes, one call over many users (parity at these shapes:
+tests/test_gpu_lru.py::test_baseline_shapes_sample_vs_oracle and ::test_full_size_catalog_properties)."""
 import sys, time
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd.lru import LRURec, init_lru_state_dict
 from llamarec_amd.synth import WORKLOADS, synth_users
-from oracle import lru_oracle as O
 
 for name, U in (("ml-100k", 610), ("beauty", 22332), ("games", 15264), ("synth-1m", 4096)):
     w = WORKLOADS[name]
@@ -23,8 +22,5 @@ for name, U in (("ml-100k", 610), ("beauty", 22332), ("games", 15264), ("synth-1
     ms = float(np.median(ts))
     flops = 2.0 * 64 * (w["V"] + 1) * U
     table_bytes = (w["V"] + 1) * 65 * 4
-    sample = np.arange(0, U, max(1, U // 16))[:16]
-    oi, os_ = O.LruOracle(sd).retrieve_topk(hist[sample], 50, True)
-    ok = np.array_equal(idx[sample].cpu().numpy(), oi) and np.array_equal(sc[sample].cpu().numpy().view(np.uint32), os_.view(np.uint32))
     print(f"{name:9s} U={U:6d} V={w['V']:8d} L={w['L']:3d} mean_hist={n.mean():6.1f}: {ms:8.3f} ms  {U/ms*1e3:10.0f} users/s  "
-          f"item-GEMM {flops/ms/1e9:7.2f} TF/s(f32)  table {table_bytes/1e6:7.1f} MB  bit-exact(sample16)={ok}  (setup {time.time()-t0:.1f}s)", flush=True)
+          f"item-GEMM {flops/ms/1e9:7.2f} TF/s(f32)  table {table_bytes/1e6:7.1f} MB  (setup {time.time()-t0:.1f}s)", flush=True)

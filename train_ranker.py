@@ -34,8 +34,7 @@ def main(argv=None, export_root=None):
         cfg.EXPERIMENT_ROOT, args.llm_base_model.rstrip("/").split("/")[-1], args.dataset_code)
     retrieved = pickle.load(open(os.path.join(args.llm_retrieved_path, "retrieved.pkl"), "rb"))
     if args.synthetic:
-        from llamarec_amd.synth import synth_llama_state
-        from tests.fake_tokenizer import FakeTokenizer
+        from llamarec_amd.synth import FakeTokenizer, synth_llama_state
 
         dataset = D.synthetic_dataset(num_users=300, num_items=1000, seed=args.seed)
         tokenizer = FakeTokenizer()
