@@ -297,6 +297,8 @@ typedef struct {
   float dropout;        /* bert_dropout      0.2 config.py:216 (embedding, FFN activation, FFN output) */
   float attn_dropout;   /* bert_attn_dropout 0.2 config.py:217 (LRU layer output) */
   uint64_t seed;        /* dropout stream (own counter-based generator: torch's masks cannot be reproduced) */
+  int32_t ce_mode;      /* item GEMM + cross-entropy: 0 = auto, 1 = store the [B*L][V+1] logits (<= 256 MB problems),
+                           2 = fused, logits never stored (large catalogs) */
 } LrLruTrainConfig;
 
 typedef struct lr_lru_train lr_lru_train_t;

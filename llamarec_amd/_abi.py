@@ -114,7 +114,7 @@ class LrLruTrainConfig(C.Structure):
     """include/llamarec_mi355x.h: LrLruTrainConfig."""
     _fields_ = [("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("dropout", C.c_float), ("attn_dropout", C.c_float),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("ce_mode", C.c_int32)]
 
 
 def lru_desc_from_state_dict(sd) -> tuple[LrLruWeightsDesc, list]:

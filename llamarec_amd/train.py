@@ -32,7 +32,7 @@ class LRUTrainEngine:
     """
 
     def __init__(self, state_dict, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-9, max_grad_norm=5.0,
-                 dropout=0.2, attn_dropout=0.2, seed=42, device="cuda:0", use_graph=False):
+                 dropout=0.2, attn_dropout=0.2, seed=42, device="cuda:0", use_graph=False, ce_mode=0):
         if not torch.cuda.is_available():
             raise RuntimeError("LRUTrainEngine needs a GPU (MI355X); there is no CPU fallback")
         self.device = torch.device(device)
@@ -44,7 +44,8 @@ class LRUTrainEngine:
         desc, keep = A.lru_desc_from_state_dict(sd)
         self.num_items, self.num_blocks = int(desc.num_items), int(desc.num_blocks)
         cfg = A.LrLruTrainConfig(weight_decay=weight_decay, beta1=betas[0], beta2=betas[1], eps=eps,
-                                 max_grad_norm=max_grad_norm, dropout=dropout, attn_dropout=attn_dropout, seed=seed)
+                                 max_grad_norm=max_grad_norm, dropout=dropout, attn_dropout=attn_dropout, seed=seed,
+                                 ce_mode=ce_mode)
         nbytes = lib().lr_lru_train_state_bytes(self.num_items, self.num_blocks)
         if nbytes == 0:
             raise ValueError("unsupported LRURec shape")

@@ -28,11 +28,12 @@ def make_engine(z, names, **kw):
     return LRUTrainEngine({n: z["init/" + n] for n in names}, dropout=0.0, attn_dropout=0.0, **kw)
 
 
-def test_loss_and_gradients_match_reference_and_oracle(golden_dir):
+@pytest.mark.parametrize("ce_mode", [1, 2])   # stored logits / fused item GEMM + cross-entropy
+def test_loss_and_gradients_match_reference_and_oracle(golden_dir, ce_mode):
     from oracle import lru_train_oracle as TO
 
     z, names = load(golden_dir)
-    eng = make_engine(z, names)
+    eng = make_engine(z, names, ce_mode=ce_mode)
     loss = float(eng.loss_and_grads(z["tokens"], z["labels"]))
     assert abs(loss - float(z["step0/loss"])) < 2e-5
     o_loss, o_grads = TO.loss_and_grads({n: z["init/" + n] for n in names}, z["tokens"], z["labels"])
@@ -81,10 +82,11 @@ def test_trained_weights_feed_the_scoring_path(golden_dir):
     assert np.abs(scores - z["final_scores_last"]).max() < 2e-3
 
 
-def test_forty_step_loss_trajectory_matches_reference(golden_dir):
+@pytest.mark.parametrize("ce_mode", [1, 2])
+def test_forty_step_loss_trajectory_matches_reference(golden_dir, ce_mode):
     """42 optimizer steps on the golden batch: the HIP engine stays on the reference's loss curve."""
     z, names = load(golden_dir)
-    eng = make_engine(z, names)
+    eng = make_engine(z, names, ce_mode=ce_mode)
     for step in range(2):
         eng.loss_and_grads(z["tokens"], z["labels"])
         eng.apply(max_grad_norm=float(z[f"step{step}/clip_limit"]))
@@ -107,7 +109,8 @@ def test_out_of_range_labels_are_ignored_and_counted(golden_dir):
     tok2 = np.concatenate([tok, tok[:3]])
     loss = float(eng.loss_and_grads(tok2, lab2))
     assert eng.bad_labels == 3 * lab.shape[1]
-    assert abs(loss - ref) < 1e-6 and torch.allclose(eng.grads, g_ref, rtol=1e-4, atol=1e-7)
+    # the loss sum is accumulated with fp32 atomics: the extra rows change their order, not the terms
+    assert abs(loss - ref) < 1e-5 and torch.allclose(eng.grads, g_ref, rtol=1e-4, atol=1e-7)
 
 
 def test_graph_replay_equals_direct_launches(golden_dir):
