@@ -333,6 +333,92 @@ int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_
  * e.g. "model.lru_blocks.1.lru_layer.in_proj.weight" (complex: 2 floats per element). */
 int lr_lru_train_param_range(const lr_lru_train_t* h, const char* name, size_t* offset, size_t* count);
 
+/* ------------------------------------------------------------------------------------------
+ * Ranker LoRA fine-tuning step.
+ * Replaces the HF Trainer loop of trainer/llm.py:103-136 over the patched LlamaForCausalLM
+ * (model/llm.py:89-127: shifted CrossEntropyLoss on the tokens whose label is not -100; the
+ * reference labels only the answer letter and EOS, dataloader/llm.py:55-58) with peft LoRA on
+ * q_proj / v_proj (train_ranker.py:71-79, config.py:257-260: r 8, alpha 32, dropout 0.05).
+ * Deviations, both documented in DESIGN.md: the frozen base is bf16 (the reference's is NF4 through
+ * bitsandbytes, absent here), and the optimizer is plain fp32 AdamW with HF's defaults (the
+ * reference's "adamw_bnb_8bit" keeps block-quantised moments).
+ *
+ * The base handle must hold the UNMERGED base weights. The data-gradient GEMMs run on transposed
+ * copies of the frozen matrices (same packed row / column orders), owned by the caller and made
+ * once with lr_transpose_bf16.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct LrLlamaLayerWeightsT {
+  const uint16_t* wqkv_t;   /* [hidden][(nh+2*nkv)*hd]  = wqkv^T  */
+  const uint16_t* wo_t;     /* [nh*hd][hidden]          = wo^T    */
+  const uint16_t* wgu_t;    /* [hidden][2*inter]        = wgu^T   */
+  const uint16_t* wdown_t;  /* [inter][hidden]          = wdown^T */
+} LrLlamaLayerWeightsT;
+
+typedef struct LrLlamaWeightsTDesc {
+  const LrLlamaLayerWeightsT* layers; /* HOST array [num_layers] of device pointers */
+  const uint16_t* lm_head_t;          /* [hidden][vocab] = lm_head^T */
+} LrLlamaWeightsTDesc;
+
+typedef struct LrLoraTrainConfig {
+  int32_t r;            /* config.py:257, 1..16 */
+  float alpha;          /* config.py:258; scaling = alpha / r */
+  float dropout;        /* config.py:259, on the adapters' input only */
+  float beta1, beta2, eps, weight_decay; /* HF TrainingArguments defaults: 0.9, 0.999, 1e-8, 0 */
+  uint64_t seed;        /* dropout stream (own counter-based generator) */
+} LrLoraTrainConfig;
+
+typedef struct lr_llama_lora lr_llama_lora_t;
+
+/* dst[c][r] = src[r][c], bf16, DEVICE pointers. */
+int lr_transpose_bf16(const uint16_t* src, int32_t rows, int32_t cols, uint16_t* dst, void* hip_stream);
+
+/* DEVICE bytes for the adapters: fp32 parameters, gradients, Adam moments, bf16 working copies. */
+size_t lr_llama_lora_state_bytes(const lr_llama_t* base, const LrLoraTrainConfig* cfg);
+/* Gradients, moments and the step counter start at zero; the PARAMETERS are the caller's to fill
+ * through lr_llama_lora_buffers (peft: A ~ kaiming-uniform, B = 0). `base` must outlive the handle. */
+int lr_llama_lora_create(lr_llama_t* base, const LrLlamaWeightsTDesc* wt, const LrLoraTrainConfig* cfg,
+                         void* state_dev, size_t state_bytes, void* hip_stream, lr_llama_lora_t** out);
+void lr_llama_lora_destroy(lr_llama_lora_t* h);
+/* Flat fp32 DEVICE buffers of n floats each. Per layer: q_proj.lora_A [r][hidden], q_proj.lora_B
+ * [nh*hd][r], v_proj.lora_A [r][hidden], v_proj.lora_B [nkv*hd][r] -- peft's layouts and HF's
+ * (unpermuted) row order. Data-parallel training all-reduces `grads` between loss_grad and apply. */
+int lr_llama_lora_buffers(lr_llama_lora_t* h, float** params, float** grads, float** m, float** v, size_t* n);
+/* which: 0 q_proj, 1 v_proj; ab: 0 lora_A, 1 lora_B. */
+int lr_llama_lora_param_range(const lr_llama_lora_t* h, int32_t layer, int32_t which, int32_t ab,
+                              size_t* offset, size_t* count);
+size_t lr_llama_lora_workspace_bytes(const lr_llama_lora_t* h, int32_t max_tokens, int32_t max_seqs,
+                                     int32_t max_loss_rows);
+/* One micro-batch: forward over the packed prompts (as lr_llama_prefill_verbalize packs them), loss
+ * = mean over the m labelled rows of -log softmax(logits[loss_rows[i]])[loss_targets[i]] (row p of a
+ * prompt predicts token p+1: the caller passes the rows whose NEXT token is labelled, each once),
+ * backward, gradients * grad_scale ADDED to the gradient buffer (accumulate != 0) or written over it.
+ * grad_scale = 1 / gradient_accumulation_steps (HF Trainer). out: DEVICE float[3] = {loss, m,
+ * targets outside the vocabulary (ignored, should be 0)}. All pointers DEVICE except cu_seqlens_host. */
+int lr_llama_lora_loss_grad(lr_llama_lora_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                            const int32_t* cu_seqlens_host, int32_t B, const int32_t* loss_rows,
+                            const int32_t* loss_targets, int32_t m, float grad_scale, int32_t accumulate,
+                            float* out, void* workspace, size_t workspace_bytes, void* hip_stream);
+/* clip_grad_norm_(max_grad_norm; <= 0: none) + one AdamW step at learning rate lr. out_norm
+ * (DEVICE float, optional) = gradient norm before clipping. */
+int lr_llama_lora_apply(lr_llama_lora_t* h, float lr, float max_grad_norm, float* out_norm, void* hip_stream);
+/* lr_llama_prefill_verbalize with the adapters as they are now (validation during training). */
+size_t lr_llama_lora_eval_workspace_bytes(const lr_llama_lora_t* h, int32_t max_tokens, int32_t max_seqs);
+int lr_llama_lora_prefill_verbalize(lr_llama_lora_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                                    const int32_t* cu_seqlens_host, int32_t B, const int32_t* label_token_ids,
+                                    int32_t C, float* out_scores, void* workspace, size_t workspace_bytes,
+                                    void* hip_stream);
+/* Varlen causal attention backward (exposed for parity tests): qkv as lr_attention_varlen; out / d_out
+ * bf16 [total][nh*hd]; lse fp32 [total][nh] from lr_attention_varlen_lse; dqkv bf16 like qkv.
+ * scratch: DEVICE, lr_attention_bwd_scratch_bytes. */
+int lr_attention_varlen_lse(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu_seqlens,
+                            const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads, int32_t num_kv_heads,
+                            int32_t head_dim, int32_t variant, void* hip_stream);
+size_t lr_attention_bwd_scratch_bytes(int32_t total, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim);
+int lr_attention_varlen_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* d_out, const float* lse,
+                            uint16_t* dqkv, const int32_t* cu_seqlens, const int32_t* cu_seqlens_host, int32_t B,
+                            int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t variant,
+                            void* scratch, size_t scratch_bytes, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

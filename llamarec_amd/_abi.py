@@ -117,6 +117,21 @@ class LrLruTrainConfig(C.Structure):
                 ("seed", C.c_uint64), ("ce_mode", C.c_int32)]
 
 
+class LrLlamaLayerWeightsT(C.Structure):
+    """include/llamarec_mi355x.h: transposed copies of the frozen matrices (data-gradient GEMMs)."""
+    _fields_ = [("wqkv_t", C.c_void_p), ("wo_t", C.c_void_p), ("wgu_t", C.c_void_p), ("wdown_t", C.c_void_p)]
+
+
+class LrLlamaWeightsTDesc(C.Structure):
+    _fields_ = [("layers", C.POINTER(LrLlamaLayerWeightsT)), ("lm_head_t", C.c_void_p)]
+
+
+class LrLoraTrainConfig(C.Structure):
+    """include/llamarec_mi355x.h: LrLoraTrainConfig."""
+    _fields_ = [("r", C.c_int32), ("alpha", C.c_float), ("dropout", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("seed", C.c_uint64)]
+
+
 def lru_desc_from_state_dict(sd) -> tuple[LrLruWeightsDesc, list]:
     """Build the C weight descriptor from an LRURec state_dict (torch tensors or numpy arrays).
 

@@ -70,6 +70,30 @@ PROTOTYPES = {
                                      C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_attention_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lr_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lr_llama_lora_state_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(A.LrLoraTrainConfig)]),
+    "lr_llama_lora_create": (C.c_int, [C.c_void_p, C.POINTER(A.LrLlamaWeightsTDesc), C.POINTER(A.LrLoraTrainConfig),
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lr_llama_lora_destroy": (None, [C.c_void_p]),
+    "lr_llama_lora_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "lr_llama_lora_param_range": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_size_t)]),
+    "lr_llama_lora_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "lr_llama_lora_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
+    "lr_llama_lora_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "lr_llama_lora_eval_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "lr_llama_lora_prefill_verbalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p]),
+    "lr_attention_varlen_lse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lr_attention_bwd_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "lr_attention_varlen_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 

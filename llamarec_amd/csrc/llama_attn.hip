@@ -35,7 +35,7 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 // =============================================================================================
 __global__ __launch_bounds__(256) void attn_generic_kernel(const u16* qkv, u16* out, const int32_t* cu, int B,
                                                            int n_tok, int nh, int nkv, int hd,
-                                                           const int32_t* q_rows) {
+                                                           const int32_t* q_rows, float* lse) {
   __shared__ float qs[4][256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave;  // (token, head)
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const u16* qkv, u16* 
     int d = lane + 64 * i;
     if (d < hd) op[d] = f2bf(o[i] / l);
   }
+  if (lse && lane == 0) lse[(size_t)orow * nh + h] = m + logf(l);  // log-sum-exp of the scaled scores (training)
 }
 
 // =============================================================================================
@@ -166,7 +167,7 @@ __device__ unsigned long long g_attn_stamps[64 * 8];
 template <bool STAMP>
 __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
                                                               const int32_t* cu, int nh, int nkv,
-                                                              int max_qblocks) {
+                                                              int max_qblocks, float* lse) {
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   // [2 stages][K 16 KiB | V 16 KiB]; filled by LDS-DMA (lane-linear 1 KiB pieces = 4 rows x 256 B),
@@ -359,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     const float l = fa_sum_xor16_32(l_run[qt]);
     const float inv = 1.0f / l;
     if (qabs[qt] < T) {
+      if (lse && quad == 0)  // natural-log log-sum-exp of the scaled scores, kept for the backward pass
+        lse[(size_t)(tok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
       u16* op = out + (size_t)(tok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
@@ -604,7 +607,7 @@ int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B,
   if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
   const int items = n_rows * nh;
   hipLaunchKernelGGL(attn_generic_kernel, dim3((items + 3) / 4), dim3(256), 0, st, qkv, out, cu, B, n_rows,
-                     nh, nkv, hd, q_rows);
+                     nh, nkv, hd, q_rows, (float*)nullptr);
   LR_CHECK_LAUNCH("attn_generic_kernel(rows)");
   return LR_OK;
 }
@@ -613,7 +616,7 @@ int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B,
 int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32_t* cu_host,
                         const int32_t* tok_pos, const int32_t* tok_seq, int B, int n_tok, int nh, int nkv,
                         int hd, int variant, void* scratch, hipStream_t st) {
-  (void)scratch;
+  float* lse = (float*)scratch;  // optional [n_tok][nh] log-sum-exp output (variants 1 and 2)
   (void)tok_pos;
   (void)tok_seq;
   if (n_tok <= 0 || B <= 0) return LR_OK;
@@ -627,6 +630,7 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
   LrProfScope prof(variant >= 2 ? LR_PROF_ATTN_MFMA : LR_PROF_ATTN_GENERIC, work, st);
   if (variant == 3) {
     if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 3 needs head_dim 128 (got %d)", hd);
+    if (lse) LR_FAIL(LR_EUNSUPPORTED, "attention variant 3 does not emit the softmax statistics");
     int maxT = 0;
     for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
     const int mq = (maxT + FB_QROWS - 1) / FB_QROWS;
@@ -658,19 +662,27 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     }
     if (stamps)
       hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
-                         nkv, mq);
+                         nkv, mq, lse);
     else
       hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
-                         nkv, mq);
+                         nkv, mq, lse);
     LR_CHECK_LAUNCH("attn_mfma128_kernel");
   } else if (variant == 1) {
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
     const int items = n_tok * nh;
     hipLaunchKernelGGL(attn_generic_kernel, dim3((items + 3) / 4), dim3(256), 0, st, qkv, out, cu, B,
-                       n_tok, nh, nkv, hd, (const int32_t*)nullptr);
+                       n_tok, nh, nkv, hd, (const int32_t*)nullptr, lse);
     LR_CHECK_LAUNCH("attn_generic_kernel");
   } else {
     LR_FAIL(LR_EINVAL, "attention: unknown variant %d", variant);
   }
   return LR_OK;
+}
+
+// forward with the softmax statistics kept for llama_attn_bwd.hip (training): variant 0 auto, 1 generic, 2 MFMA
+int lr_launch_attention_lse(const u16* qkv, u16* out, float* lse, const int32_t* cu, const int32_t* cu_host, int B,
+                            int n_tok, int nh, int nkv, int hd, int variant, hipStream_t st) {
+  if (!lse) LR_FAIL(LR_EINVAL, "attention (training): null statistics buffer");
+  if (variant == 3) variant = 2;
+  return lr_launch_attention(qkv, out, cu, cu_host, nullptr, nullptr, B, n_tok, nh, nkv, hd, variant, lse, st);
 }

@@ -1,0 +1,221 @@
+"""Ranker LoRA fine-tuning -- host-side mirror of the reference's `LLMTrainer.train()` path
+(trainer/llm.py:76-136 over the patched LlamaForCausalLM of model/llm.py:89-127 with peft LoRA on
+q_proj / v_proj, train_ranker.py:71-79), backed by the HIP training step of
+`csrc/api_llama_train.hip` (no torch compute, no fallback).
+
+  LoraTrainEngine   one replica: frozen bf16 base (a LlamaRanker built WITHOUT a merged adapter), fp32 LoRA
+                    parameters / gradients / Adam moments in one flat buffer each, loss_and_grads / apply / scores
+  lora_samples      LLMTrainDataset.__getitem__ (dataloader/llm.py:236-283): 19 sampled negatives + shuffle, prompt with
+                    the answer letter appended, labels[:-2] = -100
+  LoraRankerTrainer the Trainer loop: gradient accumulation (train_batch_size / lora_micro_batch_size), linear warm-up
+                    and decay, clipping at 1.0, validation every lora_val_iterations with best-adapter checkpoint and
+                    early stopping on rerank_best_metric, adapter saved in PEFT's on-disk format
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from ._lib import check, lib, stream_ptr
+from .llm import LlamaRanker, pack_prompts
+
+IGNORE = -100
+PEFT_KEY = "base_model.model.model.layers.{l}.self_attn.{p}_proj.lora_{ab}.weight"
+
+
+def loss_rows_and_targets(seqs, labels):
+    """Shift of model/llm.py:118-120 on packed prompts: row p of a prompt predicts token p+1, so the rows that enter the
+    loss are those whose NEXT token carries a label. Returns (rows int32 [m], targets int32 [m])."""
+    rows, tgts, base = [], [], 0
+    for s, lab in zip(seqs, labels):
+        lab = np.asarray(lab)
+        if len(lab) != len(s):
+            raise ValueError("labels and input_ids differ in length")
+        p = np.nonzero(lab[1:] != IGNORE)[0]
+        rows.append(base + p)
+        tgts.append(lab[1:][p])
+        base += len(s)
+    return np.concatenate(rows).astype(np.int32), np.concatenate(tgts).astype(np.int32)
+
+
+class LoraTrainEngine:
+    def __init__(self, ranker: LlamaRanker, r=8, alpha=32, dropout=0.05, seed=42, beta1=0.9, beta2=0.999, eps=1e-8,
+                 weight_decay=0.0, init=None):
+        self.ranker, self.device = ranker, ranker.device
+        self.r, self.alpha = int(r), float(alpha)
+        c = ranker.config
+        self.L = c["num_hidden_layers"]
+        T, L_ = ranker._tensors, lib()
+        self._t = {}
+        with torch.cuda.device(self.device):
+            def transposed(w):
+                out = torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=self.device)
+                check(L_.lr_transpose_bf16(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr(), stream_ptr()),
+                      "lr_transpose_bf16")
+                return out
+
+            arr = (A.LrLlamaLayerWeightsT * self.L)()
+            for i in range(self.L):
+                for f in ("wqkv", "wo", "wgu", "wdown"):
+                    self._t[f"{i}.{f}_t"] = transposed(T[f"{i}.{f}"])
+                    setattr(arr[i], f + "_t", self._t[f"{i}.{f}_t"].data_ptr())
+            self._t["lm_head_t"] = transposed(T["lm_head"])
+            desc = A.LrLlamaWeightsTDesc(layers=arr, lm_head_t=self._t["lm_head_t"].data_ptr())
+            cfg = A.LrLoraTrainConfig(r=self.r, alpha=self.alpha, dropout=float(dropout), beta1=beta1, beta2=beta2,
+                                      eps=eps, weight_decay=weight_decay, seed=int(seed))
+            nbytes = L_.lr_llama_lora_state_bytes(ranker._h, C.byref(cfg))
+            if nbytes == 0:
+                check(1, "lr_llama_lora_state_bytes")
+            self._state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            h = C.c_void_p()
+            check(L_.lr_llama_lora_create(ranker._h, C.byref(desc), C.byref(cfg), self._state.data_ptr(), nbytes,
+                                          stream_ptr(), C.byref(h)), "lr_llama_lora_create")
+            self._h, self._arr = h, arr
+            ptrs = [C.c_void_p() for _ in range(4)]
+            n = C.c_size_t()
+            check(L_.lr_llama_lora_buffers(h, *[C.byref(p) for p in ptrs], C.byref(n)), "lr_llama_lora_buffers")
+            base = self._state.data_ptr()
+
+            def view(p):
+                off = p.value - base
+                return self._state[off:off + 4 * n.value].view(torch.float32)
+
+            self.params, self.grads, self.m, self.v = (view(p) for p in ptrs)
+        self._ws = self._eval_ws = None
+        self._out = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.load(init if init is not None else self.peft_init(seed))
+
+    # -- parameters -------------------------------------------------------------------------------------
+    def _range(self, layer, which, ab):
+        off, cnt = C.c_size_t(), C.c_size_t()
+        check(lib().lr_llama_lora_param_range(self._h, layer, which, ab, C.byref(off), C.byref(cnt)),
+              "lr_llama_lora_param_range")
+        return off.value, cnt.value
+
+    def shapes(self):
+        c = self.ranker.config
+        d, hd = c["hidden_size"], self.ranker.hd
+        return {("q", "A"): (self.r, d), ("q", "B"): (c["num_attention_heads"] * hd, self.r),
+                ("v", "A"): (self.r, d), ("v", "B"): (c["num_key_value_heads"] * hd, self.r)}
+
+    def named(self, buf=None):
+        """{"layers.{l}.{q,v}_proj.lora_{A,B}": view into the flat buffer (default: parameters)}."""
+        buf = self.params if buf is None else buf
+        out, sh = {}, self.shapes()
+        for l in range(self.L):
+            for wi, p in enumerate("qv"):
+                for ai, ab in enumerate("AB"):
+                    off, cnt = self._range(l, wi, ai)
+                    out[f"layers.{l}.{p}_proj.lora_{ab}"] = buf[off:off + cnt].view(sh[(p, ab)])
+        return out
+
+    def peft_init(self, seed):
+        """peft's default: lora_A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)), lora_B = 0."""
+        g = torch.Generator().manual_seed(int(seed))
+        out = {}
+        for (p, ab), shape in self.shapes().items():
+            for l in range(self.L):
+                if ab == "A":
+                    bound = 1.0 / math.sqrt(shape[1])
+                    out[f"layers.{l}.{p}_proj.lora_A"] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+                else:
+                    out[f"layers.{l}.{p}_proj.lora_B"] = torch.zeros(shape)
+        return out
+
+    def load(self, weights):
+        views = self.named()
+        for k, v in views.items():
+            src = weights[k]
+            src = torch.from_numpy(np.ascontiguousarray(src)) if not isinstance(src, torch.Tensor) else src
+            v.copy_(src.to(torch.float32).reshape(v.shape))
+        return self
+
+    def export(self):
+        """PEFT-named CPU tensors (adapter_model.safetensors keys)."""
+        out = {}
+        for k, v in self.named().items():
+            parts = k.split(".")   # layers.{l}.{q,v}_proj.lora_{A,B}
+            out[PEFT_KEY.format(l=parts[1], p=parts[2][0], ab=parts[3][-1])] = v.detach().cpu().clone()
+        return out
+
+    def save_adapter(self, path, base_model=""):
+        """adapter_config.json + adapter_model.safetensors, loadable by peft and by LlamaRanker.from_pretrained."""
+        from safetensors.torch import save_file
+
+        os.makedirs(path, exist_ok=True)
+        json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": self.r, "lora_alpha": self.alpha,
+                   "lora_dropout": 0.0, "bias": "none", "target_modules": ["q_proj", "v_proj"],
+                   "base_model_name_or_path": base_model, "fan_in_fan_out": False, "inference_mode": True},
+                  open(os.path.join(path, "adapter_config.json"), "w"), indent=1)
+        save_file(self.export(), os.path.join(path, "adapter_model.safetensors"))
+
+    # -- the step ---------------------------------------------------------------------------------------
+    def _workspace(self, n, B, m):
+        need = lib().lr_llama_lora_workspace_bytes(self._h, n, B, m)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def loss_and_grads(self, seqs, labels, grad_scale=1.0, accumulate=False):
+        """One micro-batch. Returns the loss as a device scalar (mean over the labelled tokens); gradients * grad_scale
+        are written to (or, with accumulate, added to) `self.grads`."""
+        ids, cu = pack_prompts(seqs)
+        rows, tgts = loss_rows_and_targets(seqs, labels)
+        if len(rows) == 0:
+            raise ValueError("no labelled token in the micro-batch")
+        dev = self.device
+        ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+        rows_d, tgts_d = torch.from_numpy(rows).to(dev), torch.from_numpy(tgts).to(dev)
+        B, n, m = len(seqs), int(cu[-1]), len(rows)
+        ws = self._workspace(n, B, m)
+        with torch.cuda.device(dev):
+            check(lib().lr_llama_lora_loss_grad(self._h, ids_d.data_ptr(), cu_d.data_ptr(), cu.ctypes.data, B,
+                                                rows_d.data_ptr(), tgts_d.data_ptr(), m, float(grad_scale),
+                                                int(bool(accumulate)), self._out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                stream_ptr()), "lr_llama_lora_loss_grad")
+        self._keep = (ids_d, cu_d, rows_d, tgts_d)
+        return self._out[0]
+
+    @property
+    def bad_targets(self):
+        return int(self._out[2].item())
+
+    def apply(self, lr, max_grad_norm=1.0):
+        """clip_grad_norm_ + AdamW; returns the gradient norm before clipping (device scalar)."""
+        with torch.cuda.device(self.device):
+            check(lib().lr_llama_lora_apply(self._h, float(lr), float(max_grad_norm), self._out[3:].data_ptr(),
+                                            stream_ptr()), "lr_llama_lora_apply")
+        return self._out[3]
+
+    def scores(self, seqs, label_token_ids):
+        """fp32 [B, C] verbalizer scores with the adapters as they are now (no dropout)."""
+        ids, cu = pack_prompts(seqs)
+        dev = self.device
+        ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+        lab = torch.as_tensor(np.asarray(label_token_ids, dtype=np.int32)).to(dev)
+        B, n = len(seqs), int(cu[-1])
+        need = lib().lr_llama_lora_eval_workspace_bytes(self._h, n, B)
+        if self._eval_ws is None or self._eval_ws.numel() < need:
+            self._eval_ws = None
+            self._eval_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, lab.numel()), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().lr_llama_lora_prefill_verbalize(self._h, ids_d.data_ptr(), cu_d.data_ptr(), cu.ctypes.data, B,
+                                                        lab.data_ptr(), lab.numel(), out.data_ptr(),
+                                                        self._eval_ws.data_ptr(), self._eval_ws.numel(), stream_ptr()),
+                  "lr_llama_lora_prefill_verbalize")
+        return out
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                lib().lr_llama_lora_destroy(self._h)
+        except Exception:
+            pass

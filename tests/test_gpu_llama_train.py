@@ -1,0 +1,234 @@
+"""GPU parity of the ranker's LoRA training step through the C ABI: attention backward against a
+torch fp32 autograd reference of the same op, loss / LoRA gradients / AdamW steps against the goldens made by the
+reference's training forward (tests/gen_goldens_rank_train.py) and against the float64 oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = ["tiny_hd16", "tiny_hd128", "tiny_gqa"]
+
+
+def _attention_ref(q, k, v, lens, scale):
+    """q [n, nh, hd], k/v [n, nkv, hd] fp32 (requires_grad) -> o [n, nh, hd]; causal within each prompt."""
+    outs, s0 = [], 0
+    rep = q.shape[1] // k.shape[1]
+    for T in lens:
+        qs, ks, vs = q[s0:s0 + T], k[s0:s0 + T].repeat_interleave(rep, 1), v[s0:s0 + T].repeat_interleave(rep, 1)
+        s = torch.einsum("qhd,khd->hqk", qs, ks) * scale
+        s = s.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool, device=q.device))[None], float("-inf"))
+        outs.append(torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vs))
+        s0 += T
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("nh,nkv,hd,variant,lens", [
+    (2, 2, 128, 2, [200, 64, 1, 129, 77]),      # MFMA passes: ragged tails, a 1-token prompt, exact block multiples
+    (4, 2, 128, 2, [130, 300]),                 # grouped-query: the dK/dV pass walks the heads of its group
+    (4, 2, 32, 1, [37, 5, 64]),                 # generic kernel (test models)
+    (2, 2, 128, 1, [70, 33]),                   # generic kernel on the MFMA shape
+])
+def test_attention_backward_matches_autograd(nh, nkv, hd, variant, lens):
+    from llamarec_amd._lib import check, lib, stream_ptr
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = sum(lens)
+    qw = (nh + 2 * nkv) * hd
+    qkv = (torch.randn(n, qw, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    d_out = (torch.randn(n, nh * hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cu_d = torch.from_numpy(cu).to(dev)
+    out = torch.empty(n, nh * hd, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(n, nh, dtype=torch.float32, device=dev)
+    dqkv = torch.full((n, qw), float("nan"), dtype=torch.bfloat16, device=dev)
+    L = lib()
+    check(L.lr_attention_varlen_lse(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), cu_d.data_ptr(), cu.ctypes.data,
+                                    len(lens), nh, nkv, hd, variant, stream_ptr()), "lr_attention_varlen_lse")
+    sb = L.lr_attention_bwd_scratch_bytes(n, nh, nkv, hd)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    check(L.lr_attention_varlen_bwd(qkv.data_ptr(), out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                    cu_d.data_ptr(), cu.ctypes.data, len(lens), nh, nkv, hd, variant,
+                                    scratch.data_ptr(), sb, stream_ptr()), "lr_attention_varlen_bwd")
+    torch.cuda.synchronize()
+    x = qkv.float()
+    q = x[:, :nh * hd].reshape(n, nh, hd).clone().requires_grad_(True)
+    k = x[:, nh * hd:(nh + nkv) * hd].reshape(n, nkv, hd).clone().requires_grad_(True)
+    v = x[:, (nh + nkv) * hd:].reshape(n, nkv, hd).clone().requires_grad_(True)
+    o = _attention_ref(q, k, v, lens, 1.0 / np.sqrt(hd))
+    # the statistics the backward consumes
+    assert torch.allclose(out.float(), o.detach().reshape(n, -1), atol=2e-2, rtol=2e-2)
+    o.backward(d_out.float().reshape(n, nh, hd))
+    ref = torch.cat([q.grad.reshape(n, -1), k.grad.reshape(n, -1), v.grad.reshape(n, -1)], 1)
+    got = dqkv.float()
+    assert torch.isfinite(got).all()
+    for name, a, b in (("dq", 0, nh * hd), ("dk", nh * hd, (nh + nkv) * hd), ("dv", (nh + nkv) * hd, qw)):
+        err = (got[:, a:b] - ref[:, a:b]).abs().max().item()
+        scale = ref[:, a:b].abs().max().item()
+        assert err <= 2e-2 * scale, (name, err, scale)   # bf16 P / dS operands and bf16 outputs
+
+
+def _load(golden_dir, name):
+    from llamarec_amd.synth import synth_llama_state
+
+    z = np.load(os.path.join(golden_dir, f"llama_lora_train_{name}.npz"))
+    cfg = json.loads(str(z["config"]))
+    sd = synth_llama_state(cfg, int(z["weight_seed"]))
+    names = [str(n) for n in z["param_names"]]
+    return z, cfg, sd, names
+
+
+def _unpack(z, step):
+    lens = z[f"step{step}/lens"]
+    ids, lab = z[f"step{step}/packed_ids"], z[f"step{step}/packed_labels"]
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    return ([ids[cu[i]:cu[i + 1]] for i in range(len(lens))], [lab[cu[i]:cu[i + 1]] for i in range(len(lens))])
+
+
+def _engine(z, cfg, sd, names, **kw):
+    from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.rank_train import LoraTrainEngine
+
+    ranker = LlamaRanker.from_state_dict(sd, cfg)
+    init = {n: z["init/" + n] for n in names}
+    kw.setdefault("dropout", 0.0)
+    return LoraTrainEngine(ranker, r=int(z["lora_r"]), alpha=float(z["lora_alpha"]), init=init, **kw)
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_loss_and_lora_gradients_match_reference(golden_dir, name):
+    """bf16 HIP step vs the reference's fp32 run. The reference's own bf16-autocast run differs from its fp32 run by
+    0.6 % (gradient, relative L2, stored in the goldens): the bar here is 3 % per tensor and 1.5 % overall."""
+    z, cfg, sd, names = _load(golden_dir, name)
+    eng = _engine(z, cfg, sd, names)
+    seqs, labels = _unpack(z, 0)
+    loss = float(eng.loss_and_grads(seqs, labels))
+    assert eng.bad_targets == 0
+    assert abs(loss - float(z["step0/loss"])) < 4e-3
+    got = {k: v.detach().cpu().numpy() for k, v in eng.named(eng.grads).items()}
+    for n in names:
+        assert _rel(got[n], z["step0/grad/" + n]) < 3e-2, (n, _rel(got[n], z["step0/grad/" + n]))
+    allg = np.concatenate([got[n].ravel() for n in names])
+    allr = np.concatenate([z["step0/grad/" + n].ravel() for n in names])
+    ref_bf16 = np.concatenate([z["bf16/grad/" + n].ravel() for n in names])
+    assert _rel(allg, allr) < 1.5e-2
+    assert _rel(allg, allr) < 3 * _rel(ref_bf16, allr) + 2e-3     # as close as the reference's own bf16 arithmetic
+
+
+@pytest.mark.parametrize("name", ["tiny_hd128"])
+def test_gradients_match_float64_oracle(golden_dir, name):
+    from oracle import llama_train_oracle as LO
+
+    z, cfg, sd, names = _load(golden_dir, name)
+    eng = _engine(z, cfg, sd, names)
+    seqs, labels = _unpack(z, 1)
+    loss = float(eng.loss_and_grads(seqs, labels))
+    ol, og = LO.loss_and_grads(sd, cfg, {n: z["init/" + n] for n in names}, [s.tolist() for s in seqs],
+                               [l.tolist() for l in labels], int(z["lora_r"]), int(z["lora_alpha"]))
+    assert abs(loss - ol) < 4e-3
+    got = eng.named(eng.grads)
+    for n in names:
+        assert _rel(got[n].cpu().numpy(), og[n]) < 3e-2, n
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_two_adamw_steps_follow_reference(golden_dir, name):
+    z, cfg, sd, names = _load(golden_dir, name)
+    eng = _engine(z, cfg, sd, names)
+    lr = 2e-4
+    for step in range(2):
+        seqs, labels = _unpack(z, step)
+        loss = float(eng.loss_and_grads(seqs, labels))
+        assert abs(loss - float(z[f"step{step}/loss"])) < 1e-2   # bf16 logits, 6-8 labelled tokens
+        norm = float(eng.apply(lr, float(z[f"step{step}/clip_limit"])))
+        assert abs(norm - float(z[f"step{step}/grad_norm"])) < 2e-2 * float(z[f"step{step}/grad_norm"])
+        p = eng.named()
+        for n in names:
+            ref = z[f"step{step}/param/" + n]
+            diff = np.abs(p[n].cpu().numpy() - ref)
+            g = np.abs(z["step0/grad/" + n])
+            if step == 0:
+                # Adam's first step is lr * g / (|g| + eps): where the gradient is well above the bf16 noise the update
+                # agrees closely; elsewhere it is bounded by 2 lr (a sign flip)
+                big = g > 0.05 * g.max()
+                assert diff[big].max() < 0.1 * lr, n
+            assert diff.max() <= 2.05 * lr * (step + 1), n
+            assert diff.mean() < 0.25 * lr, n
+
+
+def test_gradient_accumulation_and_scale(golden_dir):
+    """HF Trainer's accumulation: two micro-batches at grad_scale 1/2, the second added to the first."""
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd16")
+    eng = _engine(z, cfg, sd, names)
+    s0, l0 = _unpack(z, 0)
+    s1, l1 = _unpack(z, 1)
+    eng.loss_and_grads(s0, l0)
+    g0 = eng.grads.clone()
+    eng.loss_and_grads(s1, l1)
+    g1 = eng.grads.clone()
+    eng.loss_and_grads(s0, l0, grad_scale=0.5)
+    eng.loss_and_grads(s1, l1, grad_scale=0.5, accumulate=True)
+    want = 0.5 * (g0 + g1)
+    assert torch.allclose(eng.grads, want, rtol=2e-2, atol=2e-3 * want.abs().max().item())
+
+
+def test_live_adapter_scores_equal_merged_inference(golden_dir):
+    """Validation during training scores with the adapters live; the inference path merges them at load
+    (W + (alpha/r) B A). Same scores to bf16 resolution."""
+    from llamarec_amd.llm import LlamaRanker
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd128")
+    eng = _engine(z, cfg, sd, names)
+    seqs, _ = _unpack(z, 0)
+    label_ids = np.arange(10, 30, dtype=np.int32)
+    live = eng.scores(seqs, label_ids).cpu().numpy()
+    weights = {}
+    for n in names:
+        _, l, proj, ab = n.split(".")
+        weights[f"model.layers.{l}.self_attn.{proj}.{ab}.weight"] = z["init/" + n]
+    merged = LlamaRanker.from_state_dict(sd, cfg, lora=dict(r=int(z["lora_r"]), alpha=float(z["lora_alpha"]),
+                                                            weights=weights))
+    ref = merged.prefill_verbalize(seqs, label_ids).cpu().numpy()
+    assert np.abs(live - ref).max() < 3e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_dropout_changes_the_adapter_path_only_and_is_reproducible(golden_dir):
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd16")
+    seqs, labels = _unpack(z, 0)
+    base = float(_engine(z, cfg, sd, names).loss_and_grads(seqs, labels))
+    a = _engine(z, cfg, sd, names, dropout=0.3, seed=9)
+    b = _engine(z, cfg, sd, names, dropout=0.3, seed=9)
+    la, lb = float(a.loss_and_grads(seqs, labels)), float(b.loss_and_grads(seqs, labels))
+    assert la == lb and torch.equal(a.grads, b.grads) or torch.allclose(a.grads, b.grads, rtol=1e-3, atol=1e-6)
+    assert la != base and abs(la - base) < 0.2          # only the rank-8 path is perturbed
+    l2 = float(a.loss_and_grads(seqs, labels))          # next pass: another mask
+    assert l2 != la
+
+
+def test_bad_arguments_fail_loudly(golden_dir):
+    from llamarec_amd._lib import LlamaRecError
+    from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.rank_train import LoraTrainEngine
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd16")
+    ranker = LlamaRanker.from_state_dict(sd, cfg)
+    with pytest.raises(LlamaRecError):
+        LoraTrainEngine(ranker, r=17)
+    eng = _engine(z, cfg, sd, names)
+    seqs, labels = _unpack(z, 0)
+    with pytest.raises(ValueError):
+        eng.loss_and_grads(seqs, [np.full(len(s), -100) for s in seqs])
+    bad = [l.copy() for l in labels]
+    bad[0][-1] = 10 ** 6                                  # not a token id: ignored and counted, no fault
+    eng.loss_and_grads(seqs, bad)
+    assert eng.bad_targets == 1
+    assert torch.isfinite(eng.grads).all()
