@@ -1,7 +1,7 @@
 """Flags of the scoring path and of retriever training, with the reference's names and defaults
 (config.py:151-274 and the per-dataset defaults of set_template, :12-148). Parsed only when an entry point
 asks (the reference parses sys.argv at import, config.py:274, and may block on input(), :13-27 -- neither
-is reproduced). Ranker-training flags are accepted and ignored so existing command lines keep working.
+is reproduced).
 """
 from __future__ import annotations
 
@@ -39,6 +39,18 @@ def build_parser():
     p.add_argument("--llm_retrieved_path", type=str, default=None)
     p.add_argument("--lora_r", type=int, default=8)
     p.add_argument("--lora_alpha", type=int, default=32)
+    # ranker LoRA fine-tuning (config.py:203,236-241,257-269; defaults filled in set_template like config.py:81-102)
+    p.add_argument("--lora_dropout", type=float, default=0.05)
+    p.add_argument("--lora_num_epochs", type=int, default=1)
+    p.add_argument("--lora_val_iterations", type=int, default=None)
+    p.add_argument("--lora_val_delay", type=int, default=None)
+    p.add_argument("--lora_early_stopping_patience", type=int, default=None)
+    p.add_argument("--lora_max_steps", type=int, default=None)
+    p.add_argument("--lora_lr", type=float, default=2e-4)
+    p.add_argument("--lora_micro_batch_size", type=int, default=None)
+    p.add_argument("--llm_train_on_inputs", action="store_true")
+    p.add_argument("--rerank_best_metric", type=str, default=None)
+    p.add_argument("--lora_max_val_samples", type=int, default=None, help="validate on the first N retrieved users")
     # additions of this implementation (local assets only; nothing is downloaded)
     p.add_argument("--data_root", type=str, default=RAW_DATASET_ROOT_FOLDER)
     p.add_argument("--export_root", type=str, default=None)
@@ -54,7 +66,7 @@ def build_parser():
     p.add_argument("--max_grad_norm", type=float, default=5.0)
     p.add_argument("--enable_lr_schedule", action="store_true")
     p.add_argument("--enable_lr_warmup", action="store_true")
-    p.add_argument("--warmup_steps", type=int, default=100)
+    p.add_argument("--warmup_steps", type=int, default=None)
     p.add_argument("--decay_step", type=int, default=10000)
     p.add_argument("--gamma", type=float, default=1.0)
     p.add_argument("--val_strategy", type=str, default=None, choices=["epoch", "iteration"])
@@ -77,8 +89,8 @@ def set_template(args):
         args.bert_max_len = 200 if ml else 50
     if args.bert_num_blocks is None:
         args.bert_num_blocks = 2
-    if args.train_batch_size is None:                      # config.py:103-107
-        args.train_batch_size = 16 if ml else 64
+    if args.train_batch_size is None:                      # config.py:90-107
+        args.train_batch_size = (32 if ml else 16) if args.model_code == "llm" else (16 if ml else 64)
     if args.lr is None:                                    # config.py:121-124
         args.lr = 1e-3
     if args.weight_decay is None:
@@ -93,7 +105,21 @@ def set_template(args):
         args.metric_ks = [1, 5, 10, 20, 50]
     if args.rerank_metric_ks is None:
         args.rerank_metric_ks = [1, 5, 10]
+    if args.warmup_steps is None:                          # config.py:133-134
+        args.warmup_steps = 100
+    if args.lora_val_iterations is None:                   # config.py:81-88
+        args.lora_val_iterations = 100
+    if args.lora_val_delay is None:
+        args.lora_val_delay = 0
+    if args.lora_early_stopping_patience is None:
+        args.lora_early_stopping_patience = 20
+    if args.lora_max_steps is None:
+        args.lora_max_steps = -1
+    if args.rerank_best_metric is None:                    # config.py:142-143
+        args.rerank_best_metric = "NDCG@10"
     if args.model_code == "llm":
+        if args.lora_micro_batch_size is None:             # config.py:90-97
+            args.lora_micro_batch_size = 8 if args.dataset_code == "beauty" else 16
         if args.test_batch_size is None:
             args.test_batch_size = 32 if ml else 16
         if args.val_batch_size is None:

@@ -66,6 +66,19 @@ def unpad_left(input_ids, attention_mask=None):
     return out
 
 
+def load_peft_adapter(adapter_path):
+    """A local PEFT LoRA directory (adapter_config.json + adapter_model.safetensors) -> the `lora` argument of
+    LlamaRanker.from_state_dict."""
+    from safetensors import safe_open
+
+    ac = json.load(open(os.path.join(adapter_path, "adapter_config.json")))
+    w = {}
+    with safe_open(os.path.join(adapter_path, "adapter_model.safetensors"), framework="pt", device="cpu") as f:
+        for k in f.keys():
+            w[k.replace("base_model.model.", "").replace(".default", "")] = f.get_tensor(k).float().numpy()
+    return dict(r=ac["r"], alpha=ac["lora_alpha"], weights=w)
+
+
 class LlamaRanker:
     """One replica of the ranker's weights on one MI355X + the prefill/verbalizer entry points."""
 
@@ -164,15 +177,7 @@ class LlamaRanker:
                 with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
                     for k in f.keys():
                         sd[k] = f.get_tensor(k)
-        lora = None
-        if adapter_path:
-            ac = json.load(open(os.path.join(adapter_path, "adapter_config.json")))
-            w = {}
-            with safe_open(os.path.join(adapter_path, "adapter_model.safetensors"), framework="pt", device="cpu") as f:
-                for k in f.keys():
-                    w[k.replace("base_model.model.", "").replace(".default", "")] = f.get_tensor(k).float().numpy()
-            lora = dict(r=ac["r"], alpha=ac["lora_alpha"], weights=w)
-        return cls.from_state_dict(sd, cfg, device, lora)
+        return cls.from_state_dict(sd, cfg, device, load_peft_adapter(adapter_path) if adapter_path else None)
 
     def _interleave_rope_rows(self, w):
         """Rows of every head reordered to (0, hd/2, 1, hd/2+1, ...): rotation pairs become adjacent

@@ -91,6 +91,47 @@ def seq_to_token_ids(seq, candidates, label, text_dict, tokenizer, prompter=None
     return out
 
 
+def seq_to_token_ids_train(seq, candidates, label, text_dict, tokenizer, prompter=None,
+                           max_title_len=LLM_MAX_TITLE_LEN, max_text_len=LLM_MAX_TEXT_LEN,
+                           system_template=DEFAULT_SYSTEM_TEMPLATE, input_template=DEFAULT_INPUT_TEMPLATE,
+                           train_on_inputs=False):
+    """Train branch of dataloader/llm.py:64-98 + generate_and_tokenize_train (:33-61): the prompt with the answer
+    letter appended, EOS / BOS added when the tokenizer did not, labels = input_ids with everything except the last
+    two tokens (letter, EOS) set to -100."""
+    prompter = prompter or Prompter()
+    candidates = list(candidates)
+    output = chr(ord("A") + candidates.index(label))
+    text = build_input_text(seq, candidates, text_dict, tokenizer, max_title_len, input_template)
+    full = prompter.generate_prompt(system_template, text, output)
+    tok = tokenizer(full, truncation=True, max_length=max_text_len, padding=False, return_tensors=None)
+    ids, mask = list(tok["input_ids"]), list(tok["attention_mask"])
+    if ids[-1] != tokenizer.eos_token_id:
+        ids.append(tokenizer.eos_token_id)
+        mask.append(1)
+    if ids[0] != tokenizer.bos_token_id:
+        ids.insert(0, tokenizer.bos_token_id)
+        mask.insert(0, 1)
+    labels = list(ids)
+    if not train_on_inputs:
+        labels[:-2] = [-100] * len(labels[:-2])
+    return {"input_ids": ids, "attention_mask": mask, "labels": labels}
+
+
+def train_pack(batch, llm_max_length=LLM_MAX_TEXT_LEN, eos_token_id=2):
+    """The packed (unpadded) equivalent of llama_collate_fn_w_truncation(eval=False) (trainer/llm.py:15-60): per-prompt
+    ids and labels after the same left truncation and the same sanity checks; padding never reaches the GPU."""
+    longest = max(len(b["input_ids"]) for b in batch)
+    max_length = min(llm_max_length, longest)
+    seqs, labels = [], []
+    for b in batch:
+        ids, lab = list(b["input_ids"])[-max_length:], list(b["labels"])[-max_length:]
+        assert ids[-1] == eos_token_id                          # trainer/llm.py:46-48
+        assert lab[-3] == -100 and lab[-2] != -100
+        seqs.append(np.asarray(ids, dtype=np.int32))
+        labels.append(np.asarray(lab, dtype=np.int64))
+    return seqs, labels
+
+
 def eval_collate(batch, llm_max_length=LLM_MAX_TEXT_LEN):
     """llama_collate_fn_w_truncation(eval=True) (trainer/llm.py:15-60): left-truncate to
     min(llm_max_length, longest), left-pad ids with 0 and the mask with 0; labels [B,1].

@@ -163,9 +163,13 @@ class LoraTrainEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    merged = False
+
     def loss_and_grads(self, seqs, labels, grad_scale=1.0, accumulate=False):
         """One micro-batch. Returns the loss as a device scalar (mean over the labelled tokens); gradients * grad_scale
         are written to (or, with accumulate, added to) `self.grads`."""
+        if self.merged:
+            raise RuntimeError("the adapter was merged into the base weights: build a new engine to train further")
         ids, cu = pack_prompts(seqs)
         rows, tgts = loss_rows_and_targets(seqs, labels)
         if len(rows) == 0:
@@ -213,9 +217,199 @@ class LoraTrainEngine:
                   "lr_llama_lora_prefill_verbalize")
         return out
 
+    prefill_verbalize = scores   # the evaluator's call (llamarec_amd.rerank.LLMEvaluator)
+
+    def merge_into_base_(self):
+        """W_q, W_v += (alpha/r) B A in the ranker's packed bf16 weights (what LlamaRanker.from_state_dict(lora=...) does
+        at load) so that the plain scoring path serves the tuned model. The engine must not be trained further: its
+        transposed copies and the now-merged base no longer describe 'base + adapter'."""
+        rk, s = self.ranker, self.alpha / self.r
+        c = rk.config
+        nq, nkv = c["num_attention_heads"] * rk.hd, c["num_key_value_heads"] * rk.hd
+        p = self.named()
+        for l in range(self.L):
+            w = rk._tensors[f"{l}.wqkv"]
+            dq = rk._interleave_rope_rows(s * (p[f"layers.{l}.q_proj.lora_B"] @ p[f"layers.{l}.q_proj.lora_A"]))
+            dv = s * (p[f"layers.{l}.v_proj.lora_B"] @ p[f"layers.{l}.v_proj.lora_A"])
+            w[:nq] = (w[:nq].float() + dq).to(torch.bfloat16)
+            w[nq + nkv:] = (w[nq + nkv:].float() + dv).to(torch.bfloat16)
+        self.merged = True
+        return rk
+
     def __del__(self):
         try:
             if self._h.value:
                 lib().lr_llama_lora_destroy(self._h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# training samples
+# ---------------------------------------------------------------------------------------------
+class LLMTrainSamples:
+    """LLMTrainDataset (dataloader/llm.py:236-283): one sample per prefix seq[:i], i >= 2, of every user's training
+    sequence (users in sorted order); the answer is the prefix's last item, the history the llm_max_history items
+    before it; llm_negative_sample_size negatives drawn from 5x as many uniform item ids (skipping the user's history
+    and the answer), candidates shuffled. `rng` needs numpy's legacy `randint` / `shuffle` (the reference passes the
+    `np.random` module; a `np.random.RandomState` reproduces it under a seed)."""
+
+    def __init__(self, args, u2seq, text_dict, tokenizer, prompter=None, rng=None):
+        from . import prompt as P
+
+        self.P, self.args = P, args
+        self.max_len = getattr(args, "llm_max_history", P.LLM_MAX_HISTORY)
+        self.num_items = args.num_items
+        self.neg = getattr(args, "llm_negative_sample_size", 19)
+        self.rng = rng if rng is not None else np.random
+        self.text_dict, self.tokenizer = text_dict, tokenizer
+        self.prompter = prompter or P.Prompter()
+        self.kw = dict(max_title_len=getattr(args, "llm_max_title_len", P.LLM_MAX_TITLE_LEN),
+                       max_text_len=getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN),
+                       system_template=getattr(args, "llm_system_template", None) or P.DEFAULT_SYSTEM_TEMPLATE,
+                       input_template=getattr(args, "llm_input_template", None) or P.DEFAULT_INPUT_TEMPLATE,
+                       train_on_inputs=bool(getattr(args, "llm_train_on_inputs", False)))
+        self.all_seqs = []
+        for u in sorted(u2seq.keys()):
+            seq = u2seq[u]
+            for i in range(2, len(seq) + 1):
+                self.all_seqs.append(seq[:i])
+
+    def __len__(self):
+        return len(self.all_seqs)
+
+    def candidates(self, index):
+        tokens = self.all_seqs[index]
+        answer, original_seq = tokens[-1], tokens[:-1]
+        seq = original_seq[-self.max_len:]
+        cur, cands = 0, [answer]
+        samples = self.rng.randint(1, self.num_items + 1, size=5 * self.neg)
+        while len(cands) < self.neg + 1:
+            item = samples[cur]
+            cur += 1
+            if item in original_seq or item == answer:
+                continue
+            cands.append(item)
+        self.rng.shuffle(cands)
+        return seq, cands, answer
+
+    def __getitem__(self, index):
+        seq, cands, answer = self.candidates(index)
+        return self.P.seq_to_token_ids_train(seq, cands, answer, self.text_dict, self.tokenizer, self.prompter,
+                                             **self.kw)
+
+
+def linear_schedule(warmup_steps, total_steps):
+    """transformers.get_linear_schedule_with_warmup (HF Trainer's default lr_scheduler_type="linear")."""
+    def f(step):
+        if step < warmup_steps:
+            return step / max(1, warmup_steps)
+        return max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
+    return f
+
+
+# ---------------------------------------------------------------------------------------------
+# the Trainer loop
+# ---------------------------------------------------------------------------------------------
+class LoraRankerTrainer:
+    """Mirror of LLMTrainer(...).train() (trainer/llm.py:76-136, HF Trainer semantics for the arguments it sets):
+    micro-batches of lora_micro_batch_size, train_batch_size // lora_micro_batch_size of them per optimizer step,
+    AdamW at lora_lr with linear warm-up over warmup_steps and linear decay to 0, clipping at HF's default 1.0,
+    lora_num_epochs epochs (or lora_max_steps), validation every lora_val_iterations steps on the retriever's
+    validation candidates with `rerank_best_metric` deciding the kept adapter, EarlyStoppingCallback patience,
+    load_best_model_at_end. Data parallel: rank r takes micro-batches r, r + world, ... of every step and the flat
+    gradient buffer is averaged with ONE all-reduce before the optimizer step (DDP's semantics)."""
+
+    MAX_GRAD_NORM = 1.0   # TrainingArguments default
+
+    def __init__(self, args, engine: LoraTrainEngine, train_samples, val_items, verbalizer, export_root=None, rank=0,
+                 world=1, log=print):
+        self.args, self.engine, self.samples, self.val_items = args, engine, train_samples, val_items
+        self.verbalizer, self.export_root, self.rank, self.world, self.log = verbalizer, export_root, rank, world, log
+        self.micro = args.lora_micro_batch_size
+        self.accum = max(1, args.train_batch_size // args.lora_micro_batch_size)
+        per_step = self.micro * self.accum * world
+        steps_per_epoch = max(1, len(train_samples) // per_step)
+        self.total_steps = args.lora_max_steps if args.lora_max_steps and args.lora_max_steps > 0 \
+            else steps_per_epoch * args.lora_num_epochs
+        self.schedule = linear_schedule(args.warmup_steps, self.total_steps)
+        self.ks = list(getattr(args, "rerank_metric_ks", [1, 5, 10]))
+        self.best_metric, self.best_state, self.bad_evals = None, None, 0
+        self.history = []
+
+    def _order(self, epoch):
+        return np.random.RandomState(self.args.seed + epoch).permutation(len(self.samples))
+
+    def evaluate(self):
+        """Verbalizer scores with the live adapters -> Recall/MRR/NDCG@ks on the validation prompts (rank 0's shard of
+        nothing: every rank evaluates the same items, cheap next to training)."""
+        from . import metrics as M
+        from . import prompt as P
+
+        items = self.val_items
+        n = getattr(self.args, "lora_max_val_samples", None)
+        if n:
+            items = items[:n]
+        ncls = self.verbalizer.num_classes
+        hist = torch.zeros(ncls + 1, dtype=torch.int64, device=self.engine.device)
+        bs = getattr(self.args, "val_batch_size", None) or 16
+        for i in range(0, len(items), bs):
+            seqs, labels = P.eval_pack(items[i:i + bs], getattr(self.args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN))
+            scores = self.engine.scores(seqs, self.verbalizer.label_token_ids)
+            M.rank_histogram(M.rank_classes(scores), torch.from_numpy(labels).to(self.engine.device), hist)
+        return M.metrics_from_histogram(hist, self.ks) if len(items) else {}
+
+    def _maybe_validate(self, step):
+        a = self.args
+        if not self.val_items or step % a.lora_val_iterations != 0 or step < a.lora_val_delay:
+            return False
+        m = self.evaluate()
+        cur = m.get(a.rerank_best_metric, 0.0)
+        self.history.append({"step": step, **{"eval_" + k: v for k, v in m.items()}})
+        self.log(f"[step {step}] eval {a.rerank_best_metric} = {cur:.4f}")
+        if self.best_metric is None or cur > self.best_metric:
+            self.best_metric, self.bad_evals = cur, 0
+            self.best_state = self.engine.params.clone()
+            if self.export_root and self.rank == 0:
+                self.engine.save_adapter(os.path.join(self.export_root, "best_adapter"),
+                                         getattr(a, "llm_base_model", ""))
+        else:
+            self.bad_evals += 1
+        return self.bad_evals >= a.lora_early_stopping_patience
+
+    def train(self):
+        from . import prompt as P
+        from .train import average_gradients_
+
+        a, eng = self.args, self.engine
+        step, epoch, losses = 0, 0, []
+        eos = getattr(eng.ranker, "eos_token_id", None) or getattr(self.samples.tokenizer, "eos_token_id", 2)
+        stop = False
+        while step < self.total_steps and not stop:
+            order = self._order(epoch)
+            per_step = self.micro * self.accum * self.world
+            for s0 in range(0, len(order) - per_step + 1, per_step):
+                for k in range(self.accum):
+                    lo = s0 + (k * self.world + self.rank) * self.micro
+                    batch = [self.samples[int(i)] for i in order[lo:lo + self.micro]]
+                    seqs, labels = P.train_pack(batch, getattr(a, "llm_max_text_len", P.LLM_MAX_TEXT_LEN), eos)
+                    losses.append(eng.loss_and_grads(seqs, labels, grad_scale=1.0 / self.accum, accumulate=k > 0))
+                average_gradients_(eng.grads)
+                eng.apply(a.lora_lr * self.schedule(step), self.MAX_GRAD_NORM)
+                step += 1
+                if step % 10 == 0 or step == self.total_steps:      # logging_steps=10 (trainer/llm.py:115)
+                    self.log(f"[step {step}/{self.total_steps}] loss {float(torch.stack(losses).mean()):.4f} "
+                             f"lr {a.lora_lr * self.schedule(step):.2e}")
+                    losses = []
+                if self._maybe_validate(step):
+                    self.log(f"early stopping at step {step}")
+                    stop = True
+                if stop or step >= self.total_steps:
+                    break
+            epoch += 1
+        if self.best_state is not None:                              # load_best_model_at_end=True
+            eng.params.copy_(self.best_state)
+        if self.export_root and self.rank == 0:
+            eng.save_adapter(os.path.join(self.export_root, "adapter"), getattr(a, "llm_base_model", ""))
+            json.dump(self.history, open(os.path.join(self.export_root, "lora_eval_history.json"), "w"), indent=1)
+        return step

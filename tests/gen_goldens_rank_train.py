@@ -167,6 +167,53 @@ def run(name, ci):
           float(np.linalg.norm(gbf - g32) / np.linalg.norm(g32)))
 
 
+def train_dataset_golden():
+    """G11: LLMTrainDataset.__getitem__ (dataloader/llm.py:236-283) with the deterministic stand-in tokenizer and a
+    seeded RandomState, and the reference's train collate on those samples -> tests/golden/llm_train_dataset.json."""
+    from types import SimpleNamespace
+
+    from tests.fake_tokenizer import FakeTokenizer
+    from tests.gen_goldens_llm import TITLES
+
+    argv, cwd = sys.argv, os.getcwd()
+    sys.argv = ["x"]
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    try:
+        import dataloader.llm as DL  # noqa
+        from dataloader.utils import Prompter
+        import config as ref_config
+
+        prompter, ref_args = Prompter(), ref_config.args
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    u2seq = {3: [1, 2, 3, 4], 1: [5, 6, 7], 2: [8, 9, 10, 1, 2, 3, 4, 5]}
+    titles = dict(TITLES)
+    for i in range(11, 41):
+        titles[i] = f"Film number {i} ({1950 + i})"
+    out = {"u2seq": {str(k): v for k, v in u2seq.items()}, "titles": {str(k): v for k, v in titles.items()},
+           "cases": []}
+    fns = functions_from(os.path.join(REF, "trainer", "llm.py"), ["llama_collate_fn_w_truncation"], {"torch": torch})
+    for max_hist, neg, text_len, seed in ((20, 3, 1536, 7), (2, 4, 1536, 8), (3, 3, 60, 9)):
+        args = SimpleNamespace(num_items=40, llm_negative_sample_size=neg, llm_max_title_len=32,
+                               llm_max_text_len=text_len, llm_system_template=ref_args.llm_system_template,
+                               llm_input_template=ref_args.llm_input_template, llm_train_on_inputs=False)
+        ds = DL.LLMTrainDataset(args, u2seq, max_hist, np.random.RandomState(seed), titles, FakeTokenizer(), prompter)
+        samples = [ds[i] for i in range(len(ds))]
+        coll = fns["llama_collate_fn_w_truncation"](48, eval=False)(samples[:4])
+        out["cases"].append({"llm_max_history": max_hist, "llm_negative_sample_size": neg, "llm_max_text_len": text_len,
+                             "seed": seed, "all_seqs": ds.all_seqs,
+                             "samples": [{k: [int(x) for x in s[k]] for k in ("input_ids", "attention_mask", "labels")}
+                                         for s in samples],
+                             "collate_max_length": 48, "collate_first4": {k: v.tolist() for k, v in coll.items()}})
+    path = os.path.join(OUT, "llm_train_dataset.json")
+    json.dump(out, open(path, "w"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    for ci, name in enumerate(LLAMA_CONFIGS):
-        run(name, ci)
+    train_dataset_golden()
+    if "--data-only" not in sys.argv:
+        for ci, name in enumerate(LLAMA_CONFIGS):
+            run(name, ci)

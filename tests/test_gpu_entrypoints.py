@@ -67,7 +67,26 @@ def test_entry_points_synthetic(tmp_path):
         pytest.skip("random retriever retrieved nobody")
     llm_root = str(tmp_path / "experiments" / "tiny" / "synthetic")
     metrics, overall = train_ranker.main(["--dataset_code", "synthetic", "--synthetic", "--llm_retrieved_path", lru_root,
-                                          "--export_root", llm_root])
+                                          "--export_root", llm_root, "--lora_max_steps", "6", "--lora_val_iterations", "3",
+                                          "--warmup_steps", "2", "--lora_micro_batch_size", "4", "--train_batch_size", "8",
+                                          "--lora_max_val_samples", "16", "--llm_max_history", "5"])
+    # trainer.train() ran (train_ranker.py:110): the tuned adapter is on disk in PEFT's format, B is no longer zero
+    from safetensors import safe_open
+
+    for sub_dir in ("adapter", "best_adapter"):
+        assert json.load(open(os.path.join(llm_root, sub_dir, "adapter_config.json")))["r"] == 8
+        with safe_open(os.path.join(llm_root, sub_dir, "adapter_model.safetensors"), framework="pt") as f:
+            keys = list(f.keys())
+            assert "base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight" in keys and len(keys) == 8
+            assert float(f.get_tensor(keys[0]).abs().max()) > 0
+    hist = json.load(open(os.path.join(llm_root, "lora_eval_history.json")))
+    assert [h["step"] for h in hist] == [3, 6] and "eval_NDCG@10" in hist[0]
+    # scoring only, with the saved adapter merged at load: the same test metrics as the run that trained it
+    m2, _ = train_ranker.main(["--dataset_code", "synthetic", "--synthetic", "--llm_retrieved_path", lru_root,
+                               "--export_root", str(tmp_path / "again"), "--eval_only", "--llm_adapter_path",
+                               os.path.join(llm_root, "best_adapter"), "--llm_max_history", "5"])
+    for k in ("test_Recall@10", "test_NDCG@10", "test_MRR@5"):
+        assert abs(m2[k] - metrics[k]) < 0.05
     sub = json.load(open(os.path.join(llm_root, "subset_metrics.json")))
     ov = json.load(open(os.path.join(llm_root, "overall_metrics.json")))
     assert sub["test_loss"] == -1.0 and set(ov) == {f"test_{m}@{k}" for m in ("Recall", "MRR", "NDCG") for k in (1, 5, 10)}

@@ -232,3 +232,67 @@ def test_bad_arguments_fail_loudly(golden_dir):
     eng.loss_and_grads(seqs, bad)
     assert eng.bad_targets == 1
     assert torch.isfinite(eng.grads).all()
+
+
+def test_training_reduces_the_loss_from_peft_init(golden_dir):
+    """peft's init (B = 0): the first step moves only B, then both; 40 steps on one batch must fit it."""
+    from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.rank_train import LoraTrainEngine
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd128")
+    eng = LoraTrainEngine(LlamaRanker.from_state_dict(sd, cfg), dropout=0.05, seed=3)
+    seqs, labels = _unpack(z, 0)
+    first = float(eng.loss_and_grads(seqs, labels))
+    g = eng.named(eng.grads)
+    assert all(float(g[f"layers.{l}.{p}_proj.lora_A"].abs().max()) == 0.0 for l in range(2) for p in "qv")
+    assert all(float(g[f"layers.{l}.{p}_proj.lora_B"].abs().max()) > 0.0 for l in range(2) for p in "qv")
+    for _ in range(40):
+        eng.apply(3e-3, 1.0)
+        last = float(eng.loss_and_grads(seqs, labels))
+    assert last < first - 1.0, (first, last)
+
+
+def test_full_size_llama2_7b_properties():
+    """BASELINE.json's model (32 layers, hidden 4096, 32 heads of 128, vocab 32000), random weights, every kernel on
+    its production shape. Size-independent properties: with B = 0 the adapters are inert, so (1) the loss equals the
+    cross-entropy computed from the INFERENCE path's logits (an independent code path: fused-rotary GEMM epilogue,
+    fused SwiGLU, pruned last layer), (2) d A is exactly zero while d B is not; (3) gradients are linear in
+    grad_scale; (4) the loss does not depend on the order of the prompts in the micro-batch."""
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+    from llamarec_amd.rank_train import LoraTrainEngine
+
+    ranker = LlamaRanker.random_init(LLAMA2_7B, seed=5)
+    eng = LoraTrainEngine(ranker, dropout=0.0, seed=1)
+    rng = np.random.default_rng(2)
+    lens = [257, 130, 301, 64]
+    seqs = [np.concatenate([[1], rng.integers(3, 32000, size=n - 2), [2]]).astype(np.int32) for n in lens]
+    labels = []
+    for s in seqs:
+        l = np.full(len(s), -100, np.int64)
+        l[-2:] = s[-2:]
+        labels.append(l)
+    loss = float(eng.loss_and_grads(seqs, labels))
+    g1 = eng.grads.clone()
+    assert np.isfinite(loss) and torch.isfinite(g1).all()
+    # (1) inference-path logits of the prefixes that predict the two labelled tokens
+    ref = 0.0
+    for s in seqs:
+        for cut in (2, 1):
+            logits = ranker.last_logits([s[:-cut]])[0].double()
+            ref += float(torch.logsumexp(logits, 0) - logits[int(s[len(s) - cut])])
+    ref /= 2 * len(seqs)
+    assert abs(loss - ref) < 2e-2, (loss, ref)
+    # (2)
+    g = eng.named(g1)
+    for l in (0, 15, 31):
+        for p in "qv":
+            assert float(g[f"layers.{l}.{p}_proj.lora_A"].abs().max()) == 0.0
+            assert float(g[f"layers.{l}.{p}_proj.lora_B"].abs().max()) > 0.0
+    # (3)
+    eng.loss_and_grads(seqs, labels, grad_scale=0.25)
+    assert torch.allclose(eng.grads, 0.25 * g1, rtol=2e-2, atol=2e-3 * float(g1.abs().max()))
+    # (4)
+    perm = [2, 0, 3, 1]
+    loss_p = float(eng.loss_and_grads([seqs[i] for i in perm], [labels[i] for i in perm]))
+    assert abs(loss_p - loss) < 2e-3
+    assert torch.allclose(eng.grads, g1, rtol=5e-2, atol=5e-3 * float(g1.abs().max()))

@@ -121,3 +121,69 @@ def test_lru_datasets_match_reference(golden_dir):
         users, ids, labels = D.lru_eval_arrays(ds, "test", L)
         assert users == c["test_users"] and ids.tolist() == [s[0] for s in c["test"]]
         assert labels.tolist() == [s[1][:1] for s in c["test"]]
+
+
+def test_train_prompt_and_labels(prompts):
+    """Train branch (dataloader/llm.py:33-61): prompt + answer letter, EOS appended, labels[:-2] = -100."""
+    titles = {int(k): v for k, v in prompts["titles"].items()}
+    for c in prompts["cases"]:
+        tok = FakeTokenizer()
+        out = P.seq_to_token_ids_train(c["seq"], c["candidates"], c["label"], titles, tok,
+                                       max_title_len=c["llm_max_title_len"], max_text_len=c["llm_max_text_len"])
+        assert tok.seen_texts[-1] == c["prompt_train"]
+        for k in ("input_ids", "attention_mask", "labels"):
+            assert out[k] == c["train"][k], k
+        assert out["labels"][-3] == -100 and out["labels"][-2] != -100
+
+
+def test_llm_train_dataset_and_collate_match_reference(golden_dir):
+    """LLMTrainDataset (dataloader/llm.py:236-283: prefix expansion, negative sampling from numpy's legacy stream,
+    candidate shuffle) and the train collate (trainer/llm.py:15-60) in its packed form."""
+    from types import SimpleNamespace
+
+    from llamarec_amd.rank_train import LLMTrainSamples, loss_rows_and_targets
+
+    g = json.load(open(os.path.join(golden_dir, "llm_train_dataset.json")))
+    u2seq = {int(k): v for k, v in g["u2seq"].items()}
+    titles = {int(k): v for k, v in g["titles"].items()}
+    for c in g["cases"]:
+        args = SimpleNamespace(num_items=40, llm_negative_sample_size=c["llm_negative_sample_size"],
+                               llm_max_history=c["llm_max_history"], llm_max_title_len=32,
+                               llm_max_text_len=c["llm_max_text_len"])
+        ds = LLMTrainSamples(args, u2seq, titles, FakeTokenizer(), rng=np.random.RandomState(c["seed"]))
+        assert ds.all_seqs == c["all_seqs"]
+        samples = [ds[i] for i in range(len(ds))]
+        for got, ref in zip(samples, c["samples"]):
+            for k in ("input_ids", "attention_mask", "labels"):
+                assert [int(x) for x in got[k]] == ref[k], k
+        # packed form of the reference's left-padded train batch
+        seqs, labels = P.train_pack(samples[:4], c["collate_max_length"], eos_token_id=2)
+        ref = c["collate_first4"]
+        for b in range(4):
+            n = int(np.sum(ref["attention_mask"][b]))
+            assert seqs[b].tolist() == ref["input_ids"][b][-n:]
+            assert labels[b].tolist() == ref["labels"][b][-n:]
+            assert all(x == -100 for x in ref["labels"][b][:-n])         # padding never carries a label
+        rows, tgts = loss_rows_and_targets(seqs, labels)
+        assert len(rows) == 2 * 4                                         # answer letter + EOS per prompt
+        cu = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+        for b in range(4):
+            assert rows[2 * b] == cu[b + 1] - 3 and rows[2 * b + 1] == cu[b + 1] - 2
+            assert tgts[2 * b] == seqs[b][-2] and tgts[2 * b + 1] == seqs[b][-1] == 2
+
+
+def test_linear_schedule_is_hf_linear_with_warmup():
+    from llamarec_amd.rank_train import linear_schedule
+
+    f = linear_schedule(100, 1000)
+    assert f(0) == 0.0 and f(50) == 0.5 and f(100) == 1.0 and abs(f(550) - 0.5) < 1e-12 and f(1000) == 0.0
+    try:
+        from transformers import get_linear_schedule_with_warmup
+        import torch
+
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        sch = get_linear_schedule_with_warmup(opt, 100, 1000)
+        for step in range(0, 1000, 37):
+            assert abs(sch.lr_lambdas[0](step) - f(step)) < 1e-12
+    except ImportError:
+        pass
