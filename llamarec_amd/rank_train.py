@@ -383,7 +383,7 @@ class LoraRankerTrainer:
 
         a, eng = self.args, self.engine
         step, epoch, losses = 0, 0, []
-        eos = getattr(eng.ranker, "eos_token_id", None) or getattr(self.samples.tokenizer, "eos_token_id", 2)
+        eos = getattr(getattr(self.samples, "tokenizer", None), "eos_token_id", 2)
         stop = False
         while step < self.total_steps and not stop:
             order = self._order(epoch)
