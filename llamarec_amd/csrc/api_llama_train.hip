@@ -62,7 +62,7 @@ static int check_cfg(const lr_llama_t* base, const LrLoraTrainConfig* cfg, const
   const LrLlamaConfig& c = base->cfg;
   if (c.hidden_size % 64 != 0 || (c.num_heads * c.head_dim) % 64 != 0 || (c.num_kv_heads * c.head_dim) % 64 != 0)
     LR_FAIL(LR_EUNSUPPORTED, "%s: hidden size and q / v widths must be multiples of 64", who);
-  if (c.head_dim % 2 != 0) LR_FAIL(LR_EUNSUPPORTED, "%s: odd head_dim", who);
+  if (c.head_dim % 8 != 0) LR_FAIL(LR_EUNSUPPORTED, "%s: head_dim %d (must be a multiple of 8)", who, c.head_dim);
   return LR_OK;
 }
 
@@ -375,10 +375,10 @@ extern "C" int lr_llama_lora_loss_grad(lr_llama_lora_t* h, const int32_t* packed
                               0, 0.f, st));
     // attention block: xmid = x + o_proj(attention(q, k, v))
     RUN(lr_launch_gemm(ws.dx, wt.wo_t, ws.datt, nullptr, n, nh * hd, d, LR_EPI_STORE, gv, st));
+    // ... down to the gradient of the UNROTATED q, k, v (the inverse rotation rides in the attention passes)
     RUN(lr_launch_attention_bwd(s.qkv, s.att, ws.datt, s.lse, ws.dqkv, ws.dsum, ws.dkv32, cu_seqlens, cu_seqlens_host, B,
-                                n, nh, nkv, hd, h->base->attn_variant, st));
-    RUN(lr_launch_rope_bwd_db(ws.dqkv, n, qw, h->qcols, h->kcols, hd, s.t, r, scaling, ws.tok_pos, ws.rope, dbq, dbv,
-                              st));
+                                n, nh, nkv, hd, h->base->attn_variant, st, ws.tok_pos, ws.rope));
+    RUN(lr_launch_lora_db(ws.dqkv, n, qw, h->qcols, h->kcols, hd, s.t, r, scaling, dbq, dbv, st));
     // d t = scaling * (d q B_q | d v B_v), then d A and the adapters' share of d xn
     RUN(lr_launch_skinny(ws.dqkv, qw, n, h->qcols, bq_t, 1, ws.dt, 2 * LT_RP, 0, scaling, 0, 0.f, st));
     RUN(lr_launch_skinny(ws.dqkv + h->qcols + h->kcols, qw, n, h->vcols, bv_t, 1, ws.dt, 2 * LT_RP, LT_RP, scaling, 0,

@@ -157,13 +157,26 @@ __device__ __forceinline__ bf16x8 ab_read_tr(const char* tile, int ks2, int dt, 
   return f;
 }
 
+// Optional epilogue: gradient w.r.t. the UNROTATED q / k. A lane holds dims dt*16 + 4*quad + 0..3 = rotation pairs
+// i0 = dt*8 + 2*quad and i0 + 1 of its row (packed layout: pair (x1_i, x2_i) adjacent); transpose of the rotation.
+__device__ __forceinline__ void ab_unrotate(float (&v)[4], const float* rope_cs, int pos, int dt, int quad) {
+  if (!rope_cs) return;
+  const float4 cs = *reinterpret_cast<const float4*>(rope_cs + ((size_t)pos * 64 + dt * 8 + 2 * quad) * 2);
+  const float a0 = v[0], a1 = v[1], b0 = v[2], b1 = v[3];
+  v[0] = a0 * cs.x + a1 * cs.y;
+  v[1] = a1 * cs.x - a0 * cs.y;
+  v[2] = b0 * cs.z + b1 * cs.w;
+  v[3] = b1 * cs.z - b0 * cs.w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dQ pass
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restrict__ qkv, const u16* __restrict__ d_out,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ dsum, u16* dqkv,
-                                                             const int32_t* cu, int nh, int nkv, int max_qblocks) {
+                                                             const int32_t* cu, int nh, int nkv, int max_qblocks,
+                                                             const float* __restrict__ rope_cs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | V tile]
   const int hd = 128;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -294,9 +307,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
       u16* op = dqkv + (size_t)(tok0 + qabs[qt]) * stride + h * hd + quad * 4;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = dqt[qt][dt][r] * 0.08838834764831845f;
+        ab_unrotate(v, rope_cs, qabs[qt], dt, quad);
         u16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(dqt[qt][dt][r] * 0.08838834764831845f);
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
         *reinterpret_cast<u16x4*>(op + dt * 16) = o;
       }
     }
@@ -310,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
                                                               const u16* __restrict__ d_out,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ dsum, u16* dqkv,
-                                                              const int32_t* cu, int nh, int nkv) {
+                                                              const int32_t* cu, int nh, int nkv,
+                                                              const float* __restrict__ rope_cs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][Q tile | dO tile], then stats
   float* stats = reinterpret_cast<float*>(smem + 2 * AB_STAGE_BYTES);  // [2 stages][lse2[64] | D[64]]
   const int hd = 128;
@@ -415,9 +433,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
       u16x4 ok, ov;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = dkt[dt][r] * 0.08838834764831845f;
+      ab_unrotate(v, rope_cs, kabs, dt, quad);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        ok[r] = f2bf(dkt[dt][r] * 0.08838834764831845f);
+        ok[r] = f2bf(v[r]);
         ov[r] = f2bf(dvt[dt][r]);
       }
       *reinterpret_cast<u16x4*>(kp + dt * 16) = ok;
@@ -429,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
 // =============================================================================================
 int lr_launch_attention_bwd(const u16* qkv, const u16* out, const u16* d_out, const float* lse, u16* dqkv, float* dsum,
                             float* dkv32, const int32_t* cu, const int32_t* cu_host, int B, int n_tok, int nh, int nkv,
-                            int hd, int variant, hipStream_t st) {
+                            int hd, int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs) {
   if (n_tok <= 0 || B <= 0) return LR_OK;
   if (nh % nkv != 0) LR_FAIL(LR_EINVAL, "attention backward: num_heads %d not a multiple of num_kv_heads %d", nh, nkv);
   if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention backward: head_dim %d > 256", hd);
@@ -457,10 +479,10 @@ int lr_launch_attention_bwd(const u16* qkv, const u16* out, const u16* d_out, co
     }
     const int mq = (maxT + AB_QROWS - 1) / AB_QROWS, mk = (maxT + AB_KB - 1) / AB_KB;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(mq, nh, B), dim3(256), 2 * AB_STAGE_BYTES, st, qkv, d_out, lse, dsum,
-                       dqkv, cu, nh, nkv, mq);
+                       dqkv, cu, nh, nkv, mq, rope_cs);
     LR_CHECK_LAUNCH("attn_bwd_dq_kernel");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(mk, nkv, B), dim3(256), dkv_lds, st, qkv, d_out, lse, dsum, dqkv, cu,
-                       nh, nkv);
+                       nh, nkv, rope_cs);
     LR_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   } else if (variant == 1) {
     if (!dkv32) LR_FAIL(LR_EINVAL, "attention backward (generic): null fp32 scratch");
@@ -473,6 +495,11 @@ int lr_launch_attention_bwd(const u16* qkv, const u16* out, const u16* d_out, co
     hipLaunchKernelGGL(attn_bwd_kv_to_bf16_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
                        st, dkv32, dqkv, n_tok, nh * hd, kvcols);
     LR_CHECK_LAUNCH("attn_bwd_kv_to_bf16_kernel");
+    if (rope_cs) {
+      if (!tok_pos) LR_FAIL(LR_EINVAL, "attention backward: rotary table without token positions");
+      rc = lr_launch_rope_bwd(dqkv, n_tok, (nh + 2 * nkv) * hd, (nh + nkv) * hd, hd, tok_pos, rope_cs, st);
+      if (rc) return rc;
+    }
   } else {
     LR_FAIL(LR_EINVAL, "attention backward: unknown variant %d", variant);
   }

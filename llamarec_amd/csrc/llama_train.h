@@ -16,9 +16,10 @@ int lr_launch_skinny(const unsigned short* X, int ldx, int n, int K, const unsig
 int lr_launch_lora_rope_fwd(unsigned short* qkv, int n, int qw, int qcols, int kcols, int hd, const unsigned short* t,
                             const unsigned short* bq_t, const unsigned short* bv_t, int r, float scaling,
                             const int32_t* tok_pos, const float* rope_cs, hipStream_t st);
-int lr_launch_rope_bwd_db(unsigned short* dqkv, int n, int qw, int qcols, int kcols, int hd, const unsigned short* t,
-                          int r, float scaling, const int32_t* tok_pos, const float* rope_cs, float* dbq, float* dbv,
-                          hipStream_t st);
+int lr_launch_rope_bwd(unsigned short* dqkv, int n, int qw, int rot_cols, int hd, const int32_t* tok_pos,
+                       const float* rope_cs, hipStream_t st);
+int lr_launch_lora_db(const unsigned short* dqkv, int n, int qw, int qcols, int kcols, int hd, const unsigned short* t,
+                      int r, float scaling, float* dbq, float* dbv, hipStream_t st);
 int lr_launch_lora_da(const unsigned short* xn, int n, int d, const unsigned short* dt, int r, uint32_t drop_stream,
                       float drop_p, float* daq, float* dav, hipStream_t st);
 int lr_launch_swiglu_fwd(const unsigned short* gu, unsigned short* h, int n, int f, hipStream_t st);
@@ -41,11 +42,12 @@ uint32_t lr_lora_drop_stream(uint64_t seed, uint32_t pass, uint32_t layer);
 int lr_launch_attention_lse(const unsigned short* qkv, unsigned short* out, float* lse, const int32_t* cu,
                             const int32_t* cu_host, int B, int n_tok, int nh, int nkv, int hd, int variant,
                             hipStream_t st);
-// dqkv [n][(nh+2nkv)*hd] (gradient w.r.t. the rotated q, k and v), fully written. dsum: [n][nh] fp32 scratch,
-// dkv32: [n][2*nkv*hd] fp32 scratch (generic path only).
+// dqkv [n][(nh+2nkv)*hd], fully written: the gradient w.r.t. the rotated q, k and v -- or, when rope_cs / tok_pos are
+// given, w.r.t. the UNROTATED ones (the inverse rotation is pair-local in the packed layout and rides in the MFMA
+// passes' epilogues). dsum: [n][nh] fp32 scratch, dkv32: [n][2*nkv*hd] fp32 scratch (generic path only).
 int lr_launch_attention_bwd(const unsigned short* qkv, const unsigned short* out, const unsigned short* d_out,
                             const float* lse, unsigned short* dqkv, float* dsum, float* dkv32, const int32_t* cu,
                             const int32_t* cu_host, int B, int n_tok, int nh, int nkv, int hd, int variant,
-                            hipStream_t st);
+                            hipStream_t st, const int32_t* tok_pos = nullptr, const float* rope_cs = nullptr);
 
 #endif

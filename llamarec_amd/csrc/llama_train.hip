@@ -8,6 +8,8 @@
 //
 // All of these are HBM-bound row or column sweeps; none is reshaped into a GEMM except the two rank-r products
 // (x A^T and dq B), which are 16-column MFMA tiles reading each activation row exactly once.
+#include <stdlib.h>
+
 #include "llama_train.h"
 
 typedef unsigned short u16;
@@ -116,23 +118,25 @@ int lr_launch_prep_lora(const float* aq, const float* bq, const float* av, const
 // =============================================================================================
 // rank-r products: out[n][ldo] (NT 16-column tiles from column `ocol`) = scale * drop(X)[n][K] . W[16*NT][K]^T
 // =============================================================================================
-// One wave = 16 rows, workgroup = 64 rows; a K step of 64: lane (row li, group g) reads 32 contiguous bytes of its
-// row (k0 + 16 g ..), so a row's 128-byte line is read by its 4 lanes and every activation byte is read once. The
+// A workgroup = 16 rows; its 4 waves take the K steps (64 wide) round-robin and add their partial tiles through LDS,
+// so even a 7 k-token batch is ~450 workgroups of short loops. Lane (row li, group g) reads 32 contiguous bytes of its
+// row (k0 + 16 g ..): a row's 128-byte line is read by its 4 lanes and every activation byte is read once. The
 // k -> (instruction, slot) assignment is the same for X and W, which is all a dot product needs.
 template <int NT>
 __global__ __launch_bounds__(256) void lt_skinny_kernel(const u16* __restrict__ X, int ldx, int n, int K,
                                                         const u16* __restrict__ W, u16* out, int ldo, int ocol,
                                                         float scale, uint32_t drop_stream, uint32_t drop_thresh,
                                                         float drop_scale) {
+  __shared__ floatx4 part[3][NT][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int row = blockIdx.x * 64 + wave * 16 + li;
+  const int row = blockIdx.x * 16 + li;
   const int rr = min(row, n - 1);
   const u16* xp = X + (size_t)rr * ldx + g * 16;
   floatx4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 64) {
+  for (int k0 = wave * 64; k0 < K; k0 += 256) {
     u16x8 x0 = *reinterpret_cast<const u16x8*>(xp + k0);
     u16x8 x1 = *reinterpret_cast<const u16x8*>(xp + k0 + 8);
     if (drop_thresh) {
@@ -155,14 +159,22 @@ __global__ __launch_bounds__(256) void lt_skinny_kernel(const u16* __restrict__ 
                                                        acc[t], 0, 0, 0);
     }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) part[wave - 1][t][lane] = acc[t];
+  }
+  __syncthreads();
+  if (wave > 0) return;
   // accumulator: column = li (weight row), rows 4g + i
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    const floatx4 a = acc[t] + part[0][t][lane] + part[1][t][lane] + part[2][t][lane];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int orow = blockIdx.x * 64 + wave * 16 + g * 4 + i;
-      if (orow < n) out[(size_t)orow * ldo + ocol + t * 16 + li] = f2bf(acc[t][i] * scale);
+      const int orow = blockIdx.x * 16 + g * 4 + i;
+      if (orow < n) out[(size_t)orow * ldo + ocol + t * 16 + li] = f2bf(a[i] * scale);
     }
+  }
 }
 int lr_launch_skinny(const u16* X, int ldx, int n, int K, const u16* W, int nt, u16* out, int ldo, int ocol, float scale,
                      uint32_t drop_stream, float drop_p, hipStream_t st) {
@@ -170,7 +182,7 @@ int lr_launch_skinny(const u16* X, int ldx, int n, int K, const u16* W, int nt, 
   if (K % 64 != 0 || ldx % 8 != 0) LR_FAIL(LR_EUNSUPPORTED, "rank-r product: K=%d must be a multiple of 64", K);
   const uint32_t th = lt_drop_thresh(drop_p);
   const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-  const dim3 grid((n + 63) / 64);
+  const dim3 grid((n + 15) / 16);
   if (nt == 1)
     hipLaunchKernelGGL(lt_skinny_kernel<1>, grid, dim3(256), 0, st, X, ldx, n, K, W, out, ldo, ocol, scale, drop_stream,
                        th, ds);
@@ -187,199 +199,289 @@ int lr_launch_skinny(const u16* X, int ldx, int n, int K, const u16* W, int nt, 
 // forward: qkv (plain GEMM output, packed column order) += LoRA on q and v, then rotary embedding on q and k
 // =============================================================================================
 // peft: result = base(x) + lora_B(lora_A(drop(x))) * scaling, every Linear output a bf16 tensor under autocast.
-__global__ __launch_bounds__(256) void lt_lora_rope_fwd_kernel(u16* qkv, int qw, int qcols, int kcols, int hd,
+// A workgroup sweeps LT_ROWS rows; a thread owns 8 consecutive columns (4 rotation pairs, one 16-byte access) of all of
+// them, so the r rows of B^T it needs are fetched (from L2) once per LT_ROWS activation rows.
+#define LT_ROWS 4
+__global__ __launch_bounds__(256) void lt_lora_rope_fwd_kernel(u16* qkv, int n, int qw, int qcols, int kcols, int hd,
                                                                const u16* t /*[n][2*LT_RP]*/, const u16* bq_t,
                                                                const u16* bv_t, int r, float scaling,
                                                                const int32_t* tok_pos, const float* rope_cs) {
-  __shared__ float ts[2 * LT_RP];
-  const int row = blockIdx.x;
-  if (threadIdx.x < 2 * LT_RP) ts[threadIdx.x] = bf2f(t[(size_t)row * 2 * LT_RP + threadIdx.x]);
+  __shared__ float ts[LT_ROWS][2 * LT_RP];
+  __shared__ int pos[LT_ROWS];
+  const int row0 = blockIdx.x * LT_ROWS;
+  const int nrows = min(LT_ROWS, n - row0);
+  if (threadIdx.x < LT_ROWS * 2 * LT_RP) {
+    const int rr = threadIdx.x / (2 * LT_RP), j = threadIdx.x % (2 * LT_RP);
+    ts[rr][j] = rr < nrows ? bf2f(t[(size_t)(row0 + rr) * 2 * LT_RP + j]) : 0.f;
+  }
+  if (threadIdx.x < LT_ROWS) pos[threadIdx.x] = threadIdx.x < nrows ? tok_pos[row0 + threadIdx.x] : 0;
   __syncthreads();
-  u16* x = qkv + (size_t)row * qw;
   const int half = hd >> 1, vcols = qw - qcols - kcols;
-  const float* cs = rope_cs + (size_t)tok_pos[row] * half * 2;
-  for (int p = threadIdx.x; p < qw / 2; p += 256) {
-    const int c = 2 * p;
-    const u16x2 in = *reinterpret_cast<const u16x2*>(x + c);
-    float v0 = bf2f(in[0]), v1 = bf2f(in[1]);
-    if (c < qcols || c >= qcols + kcols) {
-      const bool isq = c < qcols;
+  for (int c = threadIdx.x * 8; c < qw; c += 256 * 8) {
+    const bool isq = c < qcols, isv = c >= qcols + kcols;
+    float v[LT_ROWS][8];
+#pragma unroll
+    for (int rr = 0; rr < LT_ROWS; ++rr) {
+      const u16x8 in = *reinterpret_cast<const u16x8*>(qkv + (size_t)(row0 + min(rr, nrows - 1)) * qw + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[rr][e] = bf2f(in[e]);
+    }
+    if (isq || isv) {
       const u16* bt = isq ? bq_t + c : bv_t + (c - qcols - kcols);
-      const int ld = isq ? qcols : vcols;
-      const float* tt = isq ? ts : ts + LT_RP;
-      float l0 = 0.f, l1 = 0.f;
+      const int ld = isq ? qcols : vcols, toff = isq ? 0 : LT_RP;
+      float l[LT_ROWS][8];
+#pragma unroll
+      for (int rr = 0; rr < LT_ROWS; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[rr][e] = 0.f;
       for (int j = 0; j < r; ++j) {
-        const u16x2 b = *reinterpret_cast<const u16x2*>(bt + (size_t)j * ld);
-        l0 = __builtin_fmaf(tt[j], bf2f(b[0]), l0);
-        l1 = __builtin_fmaf(tt[j], bf2f(b[1]), l1);
+        const u16x8 b = *reinterpret_cast<const u16x8*>(bt + (size_t)j * ld);
+#pragma unroll
+        for (int rr = 0; rr < LT_ROWS; ++rr) {
+          const float tj = ts[rr][toff + j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) l[rr][e] = __builtin_fmaf(tj, bf2f(b[e]), l[rr][e]);
+        }
       }
-      v0 = bf2f(f2bf(v0 + bf2f(f2bf(bf2f(f2bf(l0)) * scaling))));
-      v1 = bf2f(f2bf(v1 + bf2f(f2bf(bf2f(f2bf(l1)) * scaling))));
+#pragma unroll
+      for (int rr = 0; rr < LT_ROWS; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[rr][e] = bf2f(f2bf(v[rr][e] + bf2f(f2bf(bf2f(f2bf(l[rr][e])) * scaling))));
     }
-    if (c < qcols + kcols) {  // pair (x1_i, x2_i) of one head: rotate-half convention in the packed layout
-      const int i = (c % hd) >> 1;
-      const float co = cs[2 * i], si = cs[2 * i + 1];
-      const float o0 = v0 * co - v1 * si, o1 = v1 * co + v0 * si;
-      v0 = o0;
-      v1 = o1;
+    const int i0 = (c % hd) >> 1;
+#pragma unroll
+    for (int rr = 0; rr < LT_ROWS; ++rr) {
+      if (rr >= nrows) continue;
+      if (!isv) {  // pairs (x1_i, x2_i) of one head: rotate-half convention in the packed layout
+        const float* cs = rope_cs + ((size_t)pos[rr] * half + i0) * 2;
+        const float4 c01 = *reinterpret_cast<const float4*>(cs), c23 = *reinterpret_cast<const float4*>(cs + 4);
+        const float co[4] = {c01.x, c01.z, c23.x, c23.z}, si[4] = {c01.y, c01.w, c23.y, c23.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float a0 = v[rr][2 * q], a1 = v[rr][2 * q + 1];
+          v[rr][2 * q] = a0 * co[q] - a1 * si[q];
+          v[rr][2 * q + 1] = a1 * co[q] + a0 * si[q];
+        }
+      }
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[rr][e]);
+      *reinterpret_cast<u16x8*>(qkv + (size_t)(row0 + rr) * qw + c) = o;
     }
-    u16x2 o;
-    o[0] = f2bf(v0);
-    o[1] = f2bf(v1);
-    *reinterpret_cast<u16x2*>(x + c) = o;
   }
 }
 int lr_launch_lora_rope_fwd(u16* qkv, int n, int qw, int qcols, int kcols, int hd, const u16* t, const u16* bq_t,
                             const u16* bv_t, int r, float scaling, const int32_t* tok_pos, const float* rope_cs,
                             hipStream_t st) {
   if (n < 1) return LR_OK;
-  hipLaunchKernelGGL(lt_lora_rope_fwd_kernel, dim3(n), dim3(256), 0, st, qkv, qw, qcols, kcols, hd, t, bq_t, bv_t, r,
-                     scaling, tok_pos, rope_cs);
+  if (hd % 8 != 0 || qcols % 8 != 0 || kcols % 8 != 0 || qw % 8 != 0)
+    LR_FAIL(LR_EUNSUPPORTED, "lora + rotary sweep: head_dim and projection widths must be multiples of 8");
+  hipLaunchKernelGGL(lt_lora_rope_fwd_kernel, dim3((n + LT_ROWS - 1) / LT_ROWS), dim3(256), 0, st, qkv, n, qw, qcols,
+                     kcols, hd, t, bq_t, bv_t, r, scaling, tok_pos, rope_cs);
   LR_CHECK_LAUNCH("lt_lora_rope_fwd_kernel");
   return LR_OK;
 }
 
 // =============================================================================================
-// backward of the same: d qkv (post-rotation) -> pre-rotation in place; d B_q, d B_v accumulated
+// backward of the rotary embedding (generic attention path only; the MFMA passes rotate in their epilogues)
 // =============================================================================================
-// A thread owns one column pair and walks a chunk of rows: the inverse rotation is pair-local, and
-// d B[c][j] = scaling * sum_rows dq_pre[row][c] t[row][j] is a per-column running sum -- one atomic per (c, j)
-// and row chunk. t rows are wave-uniform (scalar loads).
-__global__ __launch_bounds__(256) void lt_rope_bwd_db_kernel(u16* dqkv, int n, int qw, int qcols, int kcols, int hd,
-                                                             const u16* t, int r, float scaling,
-                                                             const int32_t* tok_pos, const float* rope_cs, float* dbq,
-                                                             float* dbv, int rows_per_wg) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int c = 2 * p;
-  if (c >= qw) return;
-  const int r0 = blockIdx.y * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
+__global__ __launch_bounds__(256) void lt_rope_bwd_kernel(u16* dqkv, int n, int qw, int rot_cols, int hd,
+                                                          const int32_t* tok_pos, const float* rope_cs) {
+  const int per_row = rot_cols / 8;
   const int half = hd >> 1;
-  const bool isq = c < qcols, isk = !isq && c < qcols + kcols;
-  const int i = (c % hd) >> 1;
-  float a0[LT_RP], a1[LT_RP];
-#pragma unroll
-  for (int j = 0; j < LT_RP; ++j) a0[j] = a1[j] = 0.f;
-  for (int row = r0; row < r1; ++row) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * per_row; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / per_row), c = (int)(i % per_row) * 8;
     u16* x = dqkv + (size_t)row * qw + c;
-    const u16x2 in = *reinterpret_cast<const u16x2*>(x);
-    float v0 = bf2f(in[0]), v1 = bf2f(in[1]);
-    if (isq || isk) {
-      const float* cs = rope_cs + ((size_t)tok_pos[row] * half + i) * 2;
-      const float co = cs[0], si = cs[1];
-      const float o0 = v0 * co + v1 * si, o1 = v1 * co - v0 * si;  // transpose of the rotation
-      u16x2 o;
-      o[0] = f2bf(o0);
-      o[1] = f2bf(o1);
-      *reinterpret_cast<u16x2*>(x) = o;
-      v0 = bf2f(o[0]);
-      v1 = bf2f(o[1]);
-    }
-    if (!isk) {
-      const u16* tr = t + (size_t)row * 2 * LT_RP + (isq ? 0 : LT_RP);
+    const u16x8 in = *reinterpret_cast<const u16x8*>(x);
+    const float* cs = rope_cs + ((size_t)tok_pos[row] * half + ((c % hd) >> 1)) * 2;
+    u16x8 o;
 #pragma unroll
-      for (int j = 0; j < LT_RP; ++j) {
-        const float tj = bf2f(tr[j]);
-        a0[j] = __builtin_fmaf(v0, tj, a0[j]);
-        a1[j] = __builtin_fmaf(v1, tj, a1[j]);
-      }
+    for (int q = 0; q < 4; ++q) {
+      const float v0 = bf2f(in[2 * q]), v1 = bf2f(in[2 * q + 1]), co = cs[2 * q], si = cs[2 * q + 1];
+      o[2 * q] = f2bf(v0 * co + v1 * si);  // transpose of the rotation
+      o[2 * q + 1] = f2bf(v1 * co - v0 * si);
     }
-  }
-  if (isk) return;
-  if (isq) {
-    const int head = c / hd, within = c % hd;  // packed pair (2i, 2i+1) = original columns (i, half + i)
-    const int o0 = head * hd + (within >> 1), o1 = o0 + half;
-    for (int j = 0; j < r; ++j) {
-      atomicAdd(dbq + (size_t)o0 * r + j, a0[j] * scaling);
-      atomicAdd(dbq + (size_t)o1 * r + j, a1[j] * scaling);
-    }
-  } else {
-    const int cv = c - qcols - kcols;
-    for (int j = 0; j < r; ++j) {
-      atomicAdd(dbv + (size_t)cv * r + j, a0[j] * scaling);
-      atomicAdd(dbv + (size_t)(cv + 1) * r + j, a1[j] * scaling);
-    }
+    *reinterpret_cast<u16x8*>(x) = o;
   }
 }
-int lr_launch_rope_bwd_db(u16* dqkv, int n, int qw, int qcols, int kcols, int hd, const u16* t, int r, float scaling,
-                          const int32_t* tok_pos, const float* rope_cs, float* dbq, float* dbv, hipStream_t st) {
+int lr_launch_rope_bwd(u16* dqkv, int n, int qw, int rot_cols, int hd, const int32_t* tok_pos, const float* rope_cs,
+                       hipStream_t st) {
   if (n < 1) return LR_OK;
-  const int rows_per_wg = n >= 16384 ? 512 : (n >= 2048 ? 128 : 32);
-  const dim3 grid((qw / 2 + 255) / 256, (n + rows_per_wg - 1) / rows_per_wg);
-  hipLaunchKernelGGL(lt_rope_bwd_db_kernel, grid, dim3(256), 0, st, dqkv, n, qw, qcols, kcols, hd, t, r, scaling,
-                     tok_pos, rope_cs, dbq, dbv, rows_per_wg);
-  LR_CHECK_LAUNCH("lt_rope_bwd_db_kernel");
+  const size_t total = (size_t)n * (rot_cols / 8);
+  hipLaunchKernelGGL(lt_rope_bwd_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, st, dqkv,
+                     n, qw, rot_cols, hd, tok_pos, rope_cs);
+  LR_CHECK_LAUNCH("lt_rope_bwd_kernel");
   return LR_OK;
 }
 
-// d A_q[j][c], d A_v[j][c] += sum_rows dt[row][j (+LT_RP)] * drop(xn)[row][c]   (dt already carries `scaling`)
-__global__ __launch_bounds__(256) void lt_da_kernel(const u16* xn, int n, int d, const u16* dt, int r,
-                                                    uint32_t drop_stream, uint32_t drop_thresh, float drop_scale,
-                                                    float* daq, float* dav, int rows_per_wg) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d) return;
-  const int r0 = blockIdx.y * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
-  float a[2 * LT_RP];
+// =============================================================================================
+// token reductions: out[j][c] += scale * sum_tok T[tok][tcol + j] * drop(X)[tok][c]      (d B, d A)
+// =============================================================================================
+// M = the adapter's rank (one or two 16-row tiles of T's columns), N = activation columns, K = tokens: both operands
+// are indexed k-major in memory, so a lane gathers its 8 tokens with 2-byte loads (16 lanes = 32 contiguous bytes;
+// T is a few hundred KB and stays in L2, X is read exactly once). A wave owns 64 columns (4 tiles sharing the T
+// fragment), a workgroup 256, and walks one chunk of tokens; partial sums leave with one fp32 atomic per (j, c).
+//   layout 0: out_t[j * cols + c]                          (d A: [r][hidden], tile t -> out0 / out1)
+//   layout 1: out0[c * r + j]                              (d B_v: [cols][r])
+//   layout 2: out0[orig(c) * r + j], packed -> HF column   (d B_q)
+template <int NJ>
+__global__ __launch_bounds__(256) void lt_tn_kernel(const u16* __restrict__ T, int ldt, int tcol,
+                                                    const u16* __restrict__ X, int ldx, int n, int cols, int chunk,
+                                                    float scale, float* out0, float* out1, int r, int layout, int hd,
+                                                    uint32_t drop_stream, uint32_t drop_thresh, float drop_scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.x * 256 + wave * 64;
+  if (c0 >= cols) return;
+  const int t0 = blockIdx.y * chunk, t1 = min(n, t0 + chunk);
+  floatx4 acc[NJ][4];
 #pragma unroll
-  for (int j = 0; j < 2 * LT_RP; ++j) a[j] = 0.f;
-  for (int row = r0; row < r1; ++row) {
-    float x = bf2f(xn[(size_t)row * d + c]);
-    if (drop_thresh) x = lt_keep(drop_stream, row, c, drop_thresh) ? bf2f(f2bf(x * drop_scale)) : 0.f;
-    const u16* tr = dt + (size_t)row * 2 * LT_RP;
+  for (int a = 0; a < NJ; ++a)
 #pragma unroll
-    for (int j = 0; j < 2 * LT_RP; ++j) a[j] = __builtin_fmaf(bf2f(tr[j]), x, a[j]);
+    for (int ct = 0; ct < 4; ++ct) acc[a][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = t0; k0 < t1; k0 += 32) {
+    u16x8 tf[NJ], xf[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int tok = k0 + g * 8 + e;
+      const bool ok = tok < t1;
+      const size_t tr = (size_t)min(tok, n - 1);
+#pragma unroll
+      for (int a = 0; a < NJ; ++a) tf[a][e] = ok ? T[tr * ldt + tcol + a * 16 + li] : (u16)0;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int c = c0 + ct * 16 + li;
+        u16 v = X[tr * ldx + c];
+        if (drop_thresh) v = lt_keep(drop_stream, (uint32_t)tr, c, drop_thresh) ? f2bf(bf2f(v) * drop_scale) : (u16)0;
+        xf[ct][e] = v;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NJ; ++a)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[a][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, tf[a]),
+                                                             __builtin_bit_cast(bf16x8, xf[ct]), acc[a][ct], 0, 0, 0);
   }
-  for (int j = 0; j < r; ++j) {
-    atomicAdd(daq + (size_t)j * d + c, a[j]);
-    atomicAdd(dav + (size_t)j * d + c, a[LT_RP + j]);
+  // accumulator: column = activation column li of the tile, rows j = 4g + i
+  const int half = hd >> 1;
+#pragma unroll
+  for (int a = 0; a < NJ; ++a) {
+    float* out = a == 0 ? out0 : out1;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int c = c0 + ct * 16 + li;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = g * 4 + i;
+        if (j >= r) continue;
+        size_t at;
+        if (layout == 0) {
+          at = (size_t)j * cols + c;
+        } else if (layout == 1) {
+          at = (size_t)c * r + j;
+        } else {
+          const int head = c / hd, within = c % hd;
+          at = (size_t)(head * hd + (within & 1) * half + (within >> 1)) * r + j;
+        }
+        atomicAdd(out + at, acc[a][ct][i] * scale);
+      }
+    }
   }
 }
+static int lt_tn_chunk(int n) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("LR_TN_CHUNK");  // tuning knob: tokens per workgroup (multiple of 32)
+    forced = e ? atoi(e) / 32 * 32 : 0;
+  }
+  if (forced > 0) return forced;
+  return n >= 4096 ? 256 : (n >= 512 ? 128 : 32);  // 7 k tokens: 128-256 measured best (512: too few workgroups)
+}
+static int launch_tn(int nj, const u16* T, int ldt, int tcol, const u16* X, int ldx, int n, int cols, float scale,
+                     float* out0, float* out1, int r, int layout, int hd, uint32_t drop_stream, float drop_p,
+                     hipStream_t st) {
+  if (n < 1) return LR_OK;
+  if (cols % 64 != 0) LR_FAIL(LR_EUNSUPPORTED, "token reduction: %d columns (must be a multiple of 64)", cols);
+  const int chunk = lt_tn_chunk(n);
+  const dim3 grid((cols + 255) / 256, (n + chunk - 1) / chunk);
+  const uint32_t th = lt_drop_thresh(drop_p);
+  const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  if (nj == 1)
+    hipLaunchKernelGGL(lt_tn_kernel<1>, grid, dim3(256), 0, st, T, ldt, tcol, X, ldx, n, cols, chunk, scale, out0, out1, r,
+                       layout, hd, drop_stream, th, ds);
+  else
+    hipLaunchKernelGGL(lt_tn_kernel<2>, grid, dim3(256), 0, st, T, ldt, tcol, X, ldx, n, cols, chunk, scale, out0, out1, r,
+                       layout, hd, drop_stream, th, ds);
+  LR_CHECK_LAUNCH("lt_tn_kernel");
+  return LR_OK;
+}
+// d B_q += scaling * dq_pre^T t_q,  d B_v += scaling * dv^T t_v      (dqkv: gradient w.r.t. the UNROTATED q, k, v)
+int lr_launch_lora_db(const u16* dqkv, int n, int qw, int qcols, int kcols, int hd, const u16* t, int r, float scaling,
+                      float* dbq, float* dbv, hipStream_t st) {
+  int rc = launch_tn(1, t, 2 * LT_RP, 0, dqkv, qw, n, qcols, scaling, dbq, nullptr, r, 2, hd, 0, 0.f, st);
+  if (rc) return rc;
+  return launch_tn(1, t, 2 * LT_RP, LT_RP, dqkv + qcols + kcols, qw, n, qw - qcols - kcols, scaling, dbv, nullptr, r, 1,
+                   hd, 0, 0.f, st);
+}
+// d A_q[j][c], d A_v[j][c] += sum_rows dt[row][j (+LT_RP)] * drop(xn)[row][c]   (dt already carries `scaling`)
 int lr_launch_lora_da(const u16* xn, int n, int d, const u16* dt, int r, uint32_t drop_stream, float drop_p, float* daq,
                       float* dav, hipStream_t st) {
-  if (n < 1) return LR_OK;
-  const int rows_per_wg = n >= 16384 ? 512 : (n >= 2048 ? 128 : 32);
-  const dim3 grid((d + 255) / 256, (n + rows_per_wg - 1) / rows_per_wg);
-  hipLaunchKernelGGL(lt_da_kernel, grid, dim3(256), 0, st, xn, n, d, dt, r, drop_stream, lt_drop_thresh(drop_p),
-                     drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, daq, dav, rows_per_wg);
-  LR_CHECK_LAUNCH("lt_da_kernel");
-  return LR_OK;
+  return launch_tn(2, dt, 2 * LT_RP, 0, xn, d, n, d, 1.0f, daq, dav, r, 0, 0, drop_stream, drop_p, st);
 }
 
 // =============================================================================================
 // SwiGLU on the interleaved gate/up layout of the packed wgu GEMM (16 gate columns, 16 up columns, ...)
 // =============================================================================================
-__global__ __launch_bounds__(256) void lt_swiglu_fwd_kernel(const u16* gu, u16* h, size_t total /* n*f */, int f) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t row = i / f;
-    const int c = (int)(i % f);
+// a thread owns 8 consecutive h columns = 16 bytes of gate, 16 of up, 16 of h
+__global__ __launch_bounds__(256) void lt_swiglu_fwd_kernel(const u16* gu, u16* h, size_t total8 /* n*f/8 */, int f) {
+  const int per_row = f >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / per_row;
+    const int c = (int)(i % per_row) * 8;
     const u16* p = gu + row * 2 * f + (c >> 4) * 32 + (c & 15);
-    h[i] = swiglu_bf16(bf2f(p[0]), bf2f(p[16]));
+    const u16x8 g = *reinterpret_cast<const u16x8*>(p), u = *reinterpret_cast<const u16x8*>(p + 16);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = swiglu_bf16(bf2f(g[e]), bf2f(u[e]));
+    *reinterpret_cast<u16x8*>(h + row * f + c) = o;
   }
 }
 // in place: (gate, up) -> (d gate, d up) given d h
-__global__ __launch_bounds__(256) void lt_swiglu_bwd_kernel(u16* gu, const u16* dh, size_t total, int f) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t row = i / f;
-    const int c = (int)(i % f);
+__global__ __launch_bounds__(256) void lt_swiglu_bwd_kernel(u16* gu, const u16* dh, size_t total8, int f) {
+  const int per_row = f >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / per_row;
+    const int c = (int)(i % per_row) * 8;
     u16* p = gu + row * 2 * f + (c >> 4) * 32 + (c & 15);
-    const float g = bf2f(p[0]), u = bf2f(p[16]), dy = bf2f(dh[i]);
-    const float sg = 1.0f / (1.0f + __expf(-g));
-    const float silu = g * sg;
-    p[0] = f2bf(dy * u * (sg * (1.0f + g * (1.0f - sg))));
-    p[16] = f2bf(dy * silu);
+    const u16x8 gv = *reinterpret_cast<const u16x8*>(p), uv = *reinterpret_cast<const u16x8*>(p + 16);
+    const u16x8 dv = *reinterpret_cast<const u16x8*>(dh + row * f + c);
+    u16x8 og, ou;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float g = bf2f(gv[e]), u = bf2f(uv[e]), dy = bf2f(dv[e]);
+      const float sg = 1.0f / (1.0f + __expf(-g));
+      og[e] = f2bf(dy * u * (sg * (1.0f + g * (1.0f - sg))));
+      ou[e] = f2bf(dy * (g * sg));
+    }
+    *reinterpret_cast<u16x8*>(p) = og;
+    *reinterpret_cast<u16x8*>(p + 16) = ou;
   }
 }
 int lr_launch_swiglu_fwd(const u16* gu, u16* h, int n, int f, hipStream_t st) {
   if (n < 1) return LR_OK;
-  const size_t total = (size_t)n * f;
-  hipLaunchKernelGGL(lt_swiglu_fwd_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, st, gu,
+  if (f % 16 != 0) LR_FAIL(LR_EUNSUPPORTED, "swiglu: intermediate size %d", f);
+  const size_t total = (size_t)n * f / 8;
+  hipLaunchKernelGGL(lt_swiglu_fwd_kernel, dim3((unsigned)min((size_t)16384, (total + 255) / 256)), dim3(256), 0, st, gu,
                      h, total, f);
   LR_CHECK_LAUNCH("lt_swiglu_fwd_kernel");
   return LR_OK;
 }
 int lr_launch_swiglu_bwd(u16* gu, const u16* dh, int n, int f, hipStream_t st) {
   if (n < 1) return LR_OK;
-  const size_t total = (size_t)n * f;
-  hipLaunchKernelGGL(lt_swiglu_bwd_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, st, gu,
+  if (f % 16 != 0) LR_FAIL(LR_EUNSUPPORTED, "swiglu: intermediate size %d", f);
+  const size_t total = (size_t)n * f / 8;
+  hipLaunchKernelGGL(lt_swiglu_bwd_kernel, dim3((unsigned)min((size_t)16384, (total + 255) / 256)), dim3(256), 0, st, gu,
                      dh, total, f);
   LR_CHECK_LAUNCH("lt_swiglu_bwd_kernel");
   return LR_OK;
@@ -391,53 +493,116 @@ int lr_launch_swiglu_bwd(u16* gu, const u16* dh, int n, int f, hipStream_t st) {
 // y = w * x * rstd. With g = w .* dy:  dx = rstd * g - x * rstd^3 * mean(x .* g).
 // out[out_row] = (res ? res[row] : 0) + dx.   dy may get the LoRA term first:
 //   dy[c] += keep(row, c) * drop_scale * sum_j dt[row][j] * a_cat[j][c]     (j over both projections)
-#define LT_NORM_MAX_PER_THREAD 32
+// A workgroup sweeps ROWS rows; a thread owns 8 consecutive columns (16-byte accesses) of up to LT_NORM_CHUNKS chunks
+// of every row, kept in registers between the statistics pass and the output pass. With the LoRA term ROWS = 4
+// (hidden <= 4096), so the 2r rows of A_cat a chunk needs come from L2 once per four activation rows.
+#define LT_NORM_CHUNKS 4  // hidden <= 256 * 8 * 4 = 8192
+template <int ROWS, int CHUNKS, bool LORA>
 __global__ __launch_bounds__(256) void lt_rmsnorm_bwd_kernel(const u16* dy, const u16* x, const u16* w, const u16* res,
-                                                             u16* out, int d, float eps, const int32_t* out_rows,
+                                                             u16* out, int n, int d, float eps, const int32_t* out_rows,
                                                              const u16* dt, const u16* a_cat, int r,
                                                              uint32_t drop_stream, uint32_t drop_thresh,
                                                              float drop_scale) {
-  __shared__ float sh[4];
-  __shared__ float ts[2 * LT_RP];
-  const int row = blockIdx.x;
-  const int orow = out_rows ? out_rows[row] : row;
-  if (dt) {
-    if (threadIdx.x < 2 * LT_RP) ts[threadIdx.x] = bf2f(dt[(size_t)row * 2 * LT_RP + threadIdx.x]);
+  __shared__ float sh[4][2 * ROWS];
+  __shared__ float ts[ROWS][2 * LT_RP];
+  const int row0 = blockIdx.x * ROWS;
+  const int nrows = min(ROWS, n - row0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (LORA) {
+    if (threadIdx.x < ROWS * 2 * LT_RP) {
+      const int rr = threadIdx.x / (2 * LT_RP), j = threadIdx.x % (2 * LT_RP);
+      ts[rr][j] = rr < nrows ? bf2f(dt[(size_t)(row0 + rr) * 2 * LT_RP + j]) : 0.f;
+    }
     __syncthreads();
   }
-  float xv[LT_NORM_MAX_PER_THREAD], gv[LT_NORM_MAX_PER_THREAD];
-  float ss = 0.f, dot = 0.f;
+  u16x8 xv[ROWS][CHUNKS];
+  float gv[ROWS][CHUNKS][8];
+  float ss[ROWS], dot[ROWS];
 #pragma unroll
-  for (int i = 0; i < LT_NORM_MAX_PER_THREAD; ++i) {
-    const int c = threadIdx.x + i * 256;
-    xv[i] = gv[i] = 0.f;
-    if (c < d) {
-      xv[i] = bf2f(x[(size_t)row * d + c]);
-      float g = bf2f(dy[(size_t)row * d + c]);
-      if (dt && (!drop_thresh || lt_keep(drop_stream, row, c, drop_thresh))) {
-        float l = 0.f;
-        for (int j = 0; j < r; ++j) {
-          l = __builtin_fmaf(ts[j], bf2f(a_cat[(size_t)j * d + c]), l);
-          l = __builtin_fmaf(ts[LT_RP + j], bf2f(a_cat[(size_t)(LT_RP + j) * d + c]), l);
+  for (int rr = 0; rr < ROWS; ++rr) ss[rr] = dot[rr] = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < CHUNKS; ++ch) {
+    const int c = (threadIdx.x + ch * 256) * 8;
+    if (c >= d) continue;
+    const u16x8 wv = *reinterpret_cast<const u16x8*>(w + c);
+    float g[ROWS][8];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const size_t at = (size_t)(row0 + min(rr, nrows - 1)) * d + c;
+      xv[rr][ch] = *reinterpret_cast<const u16x8*>(x + at);
+      const u16x8 dv = *reinterpret_cast<const u16x8*>(dy + at);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[rr][e] = bf2f(dv[e]);
+    }
+    if (LORA) {
+      float l[ROWS][8];
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[rr][e] = 0.f;
+      for (int j = 0; j < r; ++j) {
+        const u16x8 a0 = *reinterpret_cast<const u16x8*>(a_cat + (size_t)j * d + c);
+        const u16x8 a1 = *reinterpret_cast<const u16x8*>(a_cat + (size_t)(LT_RP + j) * d + c);
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+          const float t0 = ts[rr][j], t1 = ts[rr][LT_RP + j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            l[rr][e] = __builtin_fmaf(t1, bf2f(a1[e]), __builtin_fmaf(t0, bf2f(a0[e]), l[rr][e]));
         }
-        g = bf2f(f2bf(g + bf2f(f2bf(l * drop_scale))));
       }
-      gv[i] = g * bf2f(w[c]);
-      ss += xv[i] * xv[i];
-      dot += xv[i] * gv[i];
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!drop_thresh || lt_keep(drop_stream, row0 + min(rr, nrows - 1), c + e, drop_thresh))
+            g[rr][e] = bf2f(f2bf(g[rr][e] + bf2f(f2bf(l[rr][e] * drop_scale))));
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xe = bf2f(xv[rr][ch][e]);
+        gv[rr][ch][e] = g[rr][e] * bf2f(wv[e]);
+        ss[rr] += xe * xe;
+        dot[rr] += xe * gv[rr][ch][e];
+      }
+  }
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+#pragma unroll
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) {
+      ss[rr] += __shfl_xor(ss[rr], s_, 64);
+      dot[rr] += __shfl_xor(dot[rr], s_, 64);
+    }
+    if (lane == 0) {
+      sh[wave][2 * rr] = ss[rr];
+      sh[wave][2 * rr + 1] = dot[rr];
     }
   }
-  ss = lt_block_sum(ss, sh);
-  dot = lt_block_sum(dot, sh);
-  const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
-  const float coef = dot / (float)d * rstd * rstd * rstd;
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < LT_NORM_MAX_PER_THREAD; ++i) {
-    const int c = threadIdx.x + i * 256;
-    if (c < d) {
-      float v = rstd * gv[i] - xv[i] * coef;
-      if (res) v = bf2f(f2bf(v)) + bf2f(res[(size_t)row * d + c]);
-      out[(size_t)orow * d + c] = f2bf(v);
+  for (int rr = 0; rr < ROWS; ++rr) {
+    if (rr >= nrows) continue;
+    const float s2 = sh[0][2 * rr] + sh[1][2 * rr] + sh[2][2 * rr] + sh[3][2 * rr];
+    const float dt_ = sh[0][2 * rr + 1] + sh[1][2 * rr + 1] + sh[2][2 * rr + 1] + sh[3][2 * rr + 1];
+    const float rstd = 1.0f / sqrtf(s2 / (float)d + eps);
+    const float coef = dt_ / (float)d * rstd * rstd * rstd;
+    const int orow = out_rows ? out_rows[row0 + rr] : row0 + rr;
+#pragma unroll
+    for (int ch = 0; ch < CHUNKS; ++ch) {
+      const int c = (threadIdx.x + ch * 256) * 8;
+      if (c >= d) continue;
+      u16x8 rv;
+      if (res) rv = *reinterpret_cast<const u16x8*>(res + (size_t)(row0 + rr) * d + c);
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = rstd * gv[rr][ch][e] - bf2f(xv[rr][ch][e]) * coef;
+        if (res) v = bf2f(f2bf(v)) + bf2f(rv[e]);
+        o[e] = f2bf(v);
+      }
+      *reinterpret_cast<u16x8*>(out + (size_t)orow * d + c) = o;
     }
   }
 }
@@ -445,10 +610,24 @@ int lr_launch_rmsnorm_bwd(const u16* dy, const u16* x, const u16* w, const u16* 
                           const int32_t* out_rows, const u16* dt, const u16* a_cat, int r, uint32_t drop_stream,
                           float drop_p, hipStream_t st) {
   if (rows < 1) return LR_OK;
-  if (d > 256 * LT_NORM_MAX_PER_THREAD) LR_FAIL(LR_EUNSUPPORTED, "rmsnorm backward: hidden_size %d > %d", d,
-                                                256 * LT_NORM_MAX_PER_THREAD);
-  hipLaunchKernelGGL(lt_rmsnorm_bwd_kernel, dim3(rows), dim3(256), 0, st, dy, x, w, res, out, d, eps, out_rows, dt,
-                     a_cat, r, drop_stream, lt_drop_thresh(drop_p), drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f);
+  if (d % 8 != 0 || d > 256 * 8 * LT_NORM_CHUNKS)
+    LR_FAIL(LR_EUNSUPPORTED, "rmsnorm backward: hidden_size %d (multiple of 8, <= %d)", d, 256 * 8 * LT_NORM_CHUNKS);
+  const uint32_t th = lt_drop_thresh(drop_p);
+  const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#define LT_NORM_LAUNCH(ROWS, CH, LORA)                                                                              \
+  hipLaunchKernelGGL((lt_rmsnorm_bwd_kernel<ROWS, CH, LORA>), dim3((rows + ROWS - 1) / ROWS), dim3(256), 0, st, dy, x, w, \
+                     res, out, rows, d, eps, out_rows, dt, a_cat, r, drop_stream, th, ds)
+  const int chunks = (d + 2047) / 2048;
+  if (dt) {
+    if (chunks <= 1) LT_NORM_LAUNCH(4, 1, true);
+    else if (chunks == 2) LT_NORM_LAUNCH(4, 2, true);
+    else LT_NORM_LAUNCH(2, 4, true);
+  } else {
+    if (chunks <= 1) LT_NORM_LAUNCH(1, 1, false);
+    else if (chunks == 2) LT_NORM_LAUNCH(1, 2, false);
+    else LT_NORM_LAUNCH(1, 4, false);
+  }
+#undef LT_NORM_LAUNCH
   LR_CHECK_LAUNCH("lt_rmsnorm_bwd_kernel");
   return LR_OK;
 }
@@ -506,17 +685,25 @@ int lr_launch_finish_loss(const float* scal, int m, float* out, hipStream_t st) 
 // D[row][h] = sum_d dO[row][h][d] * O[row][h][d]   (softmax backward's row term)
 __global__ __launch_bounds__(256) void lt_rowdot_kernel(const u16* o, const u16* d_o, int n_items /* n*nh */, int hd,
                                                         float* out) {
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (item >= n_items) return;
+  // 16 lanes x 8 elements cover up to 128 dims per step: 4 (token, head) items per wave
+  const int lane = threadIdx.x & 63, sub = lane >> 4, l16 = lane & 15;
+  const int item = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;
   float s = 0.f;
-  for (int c = lane; c < hd; c += 64) s += bf2f(o[(size_t)item * hd + c]) * bf2f(d_o[(size_t)item * hd + c]);
+  if (item < n_items)
+    for (int c = l16 * 8; c < hd; c += 128) {
+      const u16x8 a = *reinterpret_cast<const u16x8*>(o + (size_t)item * hd + c);
+      const u16x8 b = *reinterpret_cast<const u16x8*>(d_o + (size_t)item * hd + c);
 #pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
-  if (lane == 0) out[item] = s;
+      for (int e = 0; e < 8; ++e) s = __builtin_fmaf(bf2f(a[e]), bf2f(b[e]), s);
+    }
+#pragma unroll
+  for (int sft = 8; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
+  if (l16 == 0 && item < n_items) out[item] = s;
 }
 int lr_launch_rowdot(const u16* o, const u16* d_o, int n, int nh, int hd, float* out, hipStream_t st) {
   if (n < 1) return LR_OK;
-  hipLaunchKernelGGL(lt_rowdot_kernel, dim3((n * nh + 3) / 4), dim3(256), 0, st, o, d_o, n * nh, hd, out);
+  if (hd % 8 != 0) LR_FAIL(LR_EUNSUPPORTED, "rowdot: head_dim %d", hd);
+  hipLaunchKernelGGL(lt_rowdot_kernel, dim3((n * nh + 15) / 16), dim3(256), 0, st, o, d_o, n * nh, hd, out);
   LR_CHECK_LAUNCH("lt_rowdot_kernel");
   return LR_OK;
 }
