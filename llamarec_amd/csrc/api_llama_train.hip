@@ -28,7 +28,27 @@ struct lr_llama_lora {
   int* ctr;                        // [4]: 0 optimizer steps
   uint32_t pass;                   // host-side pass counter (dropout streams)
   int qcols, kcols, vcols;
+  // The adapter-only kernels (rank-r products, dA / dB reductions: ~5 % of a step, a few hundred workgroups each) run
+  // on a low-priority side stream next to the big GEMM they are independent of, and fill the CUs its last, partly
+  // empty round of tiles leaves idle (7 k tokens: 448 tiles on 256 CUs). LR_LORA_OVERLAP=0 keeps everything in order.
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
 };
+
+static int fork_side(lr_llama_lora* h, hipStream_t main, hipStream_t* work) {
+  *work = main;
+  if (!h->side) return LR_OK;
+  LR_CHECK_HIP(hipEventRecord(h->ev_fork, main));
+  LR_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  *work = h->side;
+  return LR_OK;
+}
+static int join_side(lr_llama_lora* h, hipStream_t main) {
+  if (!h->side) return LR_OK;
+  LR_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
+  LR_CHECK_HIP(hipStreamWaitEvent(main, h->ev_join, 0));
+  return LR_OK;
+}
 
 struct LoraStateLayout {
   size_t params, grads, m, v, work, scratch, ctr, total;
@@ -105,6 +125,18 @@ extern "C" int lr_llama_lora_create(lr_llama_t* base, const LrLlamaWeightsTDesc*
   h->per_layer = 2 * (size_t)cfg->r * c.hidden_size + (size_t)cfg->r * (h->qcols + h->vcols);
   h->n_params = (size_t)c.num_layers * h->per_layer;
   h->work_per_layer = 2 * (size_t)LT_RP * c.hidden_size + (size_t)LT_RP * (h->qcols + h->vcols);
+  const char* ov = getenv("LR_LORA_OVERLAP");
+  if (!ov || ov[0] != '0') {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+      free(h->layers_t);
+      free(h);
+      LR_FAIL(LR_EHIP, "lr_llama_lora_create: side stream / events");
+    }
+  }
   // parameters are the caller's to fill (lr_llama_lora_buffers); gradients, moments and counters start at zero
   hipStream_t st = (hipStream_t)hip_stream;
   if (hipMemsetAsync(b + s.grads, 0, s.total - s.grads, st) != hipSuccess) {
@@ -118,6 +150,12 @@ extern "C" int lr_llama_lora_create(lr_llama_t* base, const LrLlamaWeightsTDesc*
 
 extern "C" void lr_llama_lora_destroy(lr_llama_lora_t* h) {
   if (!h) return;
+  if (h->side) {
+    (void)hipStreamSynchronize(h->side);
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->side);
+  }
   free(h->layers_t);
   free(h);
 }
@@ -306,8 +344,11 @@ static int forward(lr_llama_lora* h, const int32_t* ids, const int32_t* cu, cons
     const u16 *a_cat = wk, *bq_t = wk + 2 * LT_RP * (size_t)d, *bv_t = bq_t + LT_RP * (size_t)h->qcols;
     const uint32_t stream = lr_lora_drop_stream(h->cfg.seed, h->pass, (uint32_t)l);
     RUN(lr_launch_rmsnorm(s.x, w.input_norm, s.xn, n, d, c.rms_eps, nullptr, st));
+    hipStream_t sd;
+    RUN(fork_side(h, st, &sd));  // t = drop(xn) A^T next to the QKV GEMM: both only read xn
+    RUN(lr_launch_skinny(s.xn, d, n, d, a_cat, 2, s.t, 2 * LT_RP, 0, 1.0f, stream, drop_p, sd));
     RUN(lr_launch_gemm(s.xn, w.wqkv, s.qkv, nullptr, n, qw, d, LR_EPI_STORE, gv, st));
-    RUN(lr_launch_skinny(s.xn, d, n, d, a_cat, 2, s.t, 2 * LT_RP, 0, 1.0f, stream, drop_p, st));
+    RUN(join_side(h, st));
     RUN(lr_launch_lora_rope_fwd(s.qkv, n, qw, h->qcols, h->kcols, hd, s.t, bq_t, bv_t, h->cfg.r, scaling, ws.tok_pos,
                                 ws.rope, st));
     RUN(lr_launch_attention_lse(s.qkv, s.att, s.lse, cu, cu_host, B, n, nh, nkv, hd, h->base->attn_variant, st));
@@ -378,13 +419,17 @@ extern "C" int lr_llama_lora_loss_grad(lr_llama_lora_t* h, const int32_t* packed
     // ... down to the gradient of the UNROTATED q, k, v (the inverse rotation rides in the attention passes)
     RUN(lr_launch_attention_bwd(s.qkv, s.att, ws.datt, s.lse, ws.dqkv, ws.dsum, ws.dkv32, cu_seqlens, cu_seqlens_host, B,
                                 n, nh, nkv, hd, h->base->attn_variant, st, ws.tok_pos, ws.rope));
-    RUN(lr_launch_lora_db(ws.dqkv, n, qw, h->qcols, h->kcols, hd, s.t, r, scaling, dbq, dbv, st));
-    // d t = scaling * (d q B_q | d v B_v), then d A and the adapters' share of d xn
-    RUN(lr_launch_skinny(ws.dqkv, qw, n, h->qcols, bq_t, 1, ws.dt, 2 * LT_RP, 0, scaling, 0, 0.f, st));
+    // adapters (side stream, next to the qkv data-gradient GEMM; both only read dqkv):
+    // d B, d t = scaling * (d q B_q | d v B_v), d A
+    hipStream_t sd;
+    RUN(fork_side(h, st, &sd));
+    RUN(lr_launch_lora_db(ws.dqkv, n, qw, h->qcols, h->kcols, hd, s.t, r, scaling, dbq, dbv, sd));
+    RUN(lr_launch_skinny(ws.dqkv, qw, n, h->qcols, bq_t, 1, ws.dt, 2 * LT_RP, 0, scaling, 0, 0.f, sd));
     RUN(lr_launch_skinny(ws.dqkv + h->qcols + h->kcols, qw, n, h->vcols, bv_t, 1, ws.dt, 2 * LT_RP, LT_RP, scaling, 0,
-                         0.f, st));
-    RUN(lr_launch_lora_da(s.xn, n, d, ws.dt, r, stream, drop_p, daq, dav, st));
+                         0.f, sd));
+    RUN(lr_launch_lora_da(s.xn, n, d, ws.dt, r, stream, drop_p, daq, dav, sd));
     RUN(lr_launch_gemm(ws.dqkv, wt.wqkv_t, ws.dxn, nullptr, n, d, qw, LR_EPI_STORE, gv, st));
+    RUN(join_side(h, st));
     RUN(lr_launch_rmsnorm_bwd(ws.dxn, s.x, w.input_norm, ws.dx, ws.dx, n, d, c.rms_eps, nullptr, ws.dt, a_cat, r, stream,
                               drop_p, st));
   }
