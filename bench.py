@@ -252,6 +252,35 @@ def main():
             out["beauty_shape"] = {"users_per_s": 4 * wb["rerank_batch"] / tb, "steps": 4, "users_per_step": wb["rerank_batch"],
                                    "mean_prompt_tokens_per_step": float(np.mean([b[4][-1] for b in bb[2:]])),
                                    "ms_per_step": tb / 4 * 1e3}
+            # SURVEY.md 8(f) #4, the ranker's LoRA fine-tuning step on the same weights (reference micro-batch: 16
+            # prompts, config.py:90-97; 4 of this workload's prompt batches halved): reported, never the metric
+            from llamarec_amd.rank_train import LoraTrainEngine
+
+            eng = LoraTrainEngine(ranker, dropout=0.05, seed=1)
+            mb = []
+            for b in range(min(3, nb)):
+                cu = batches[b][4]
+                ids = batches[b][2].cpu().numpy()
+                seqs = [ids[cu[i]:cu[i + 1]].copy() for i in range(min(16, len(cu) - 1))]
+                for sq in seqs:
+                    sq[-1] = 2                                    # EOS closes a training sample
+                labs = [np.where(np.arange(len(sq)) >= len(sq) - 2, sq, -100) for sq in seqs]
+                mb.append((seqs, labs))
+            eng.loss_and_grads(*mb[0])
+            eng.apply(2e-4, 1.0)
+            torch.cuda.synchronize()
+            tt = time.perf_counter()
+            for seqs, labs in mb:
+                eng.loss_and_grads(seqs, labs)
+                eng.apply(2e-4, 1.0)
+            torch.cuda.synchronize()
+            tt = time.perf_counter() - tt
+            ntok = sum(len(sq) for seqs, _ in mb for sq in seqs)
+            out["lora_train_shape"] = {"micro_batch_prompts": len(mb[0][0]), "optimizer_steps": len(mb),
+                                       "ms_per_step": tt / len(mb) * 1e3, "tokens_per_s": ntok / tt,
+                                       "samples_per_s": sum(len(sq) for sq, _ in mb) / tt,
+                                       "loss_finite": bool(np.isfinite(float(eng._out[0])))}
+            del eng
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, hist, T[:4], lru_sd)
         print(json.dumps(out))
