@@ -5,6 +5,7 @@
 # 2. three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; MFMA busy + clock)        -> profiles/<tag>_pmc_summary.json
 # 3. kernel stats of the retriever training step (Beauty shape)          -> profiles/<tag>_train_beauty_kernel_stats.csv
 # 4. the same for the stage-1 roofline point (synth-1M item GEMM + top-K) -> profiles/<tag>_stage1_*.csv
+# 5. kernel stats of the ranker LoRA training step (Llama-2-7b shapes)    -> profiles/<tag>_rank_train_kernel_stats.csv
 # The program sits directly after `--` (no env/bash hop) and --pmc is never combined with a trace domain.
 set -e
 TAG=${1:-r01}
@@ -34,12 +35,16 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 
 echo "[profile] retriever training step kernel trace (Beauty shape)"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_train" -- python3 "$ROOT/tools/bench_train.py" --only beauty --graph 0 > "$OUT/train_kt.log" 2>&1
+echo "[profile] ranker LoRA training step kernel trace (Llama-2-7b shapes, 16 prompts)"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_rank_train" -- python3 "$ROOT/tools/bench_rank_train.py" --layers 32 --steps 3 > "$OUT/rank_train_kt.log" 2>&1
 
 cd "$ROOT"
 f() { find "$1" -name "$2" | head -1; }
 cp "$(f $OUT/kt '*kernel_stats.csv')" profiles/${TAG}_bench_steps5_kernel_stats.csv
 cp "$(f $OUT/kt_s1 '*kernel_stats.csv')" profiles/${TAG}_stage1_kernel_stats.csv
 cp "$(f $OUT/kt_train '*kernel_stats.csv')" profiles/${TAG}_train_beauty_kernel_stats.csv
+cp "$(f $OUT/kt_rank_train '*kernel_stats.csv')" profiles/${TAG}_rank_train_kernel_stats.csv
+{ python3 tools/kstats.py profiles/${TAG}_rank_train_kernel_stats.csv 24 4; echo "# tools/bench_rank_train.py --layers 32 --steps 3 (1 warm-up + 3 timed passes; lt_transpose_kernel and the at::native initialisers are setup)"; grep "^layers=" "$OUT/rank_train_kt.log"; } > profiles/${TAG}_rank_train_summary.txt
 python3 tools/summarize_pmc.py profiles/${TAG}_pmc_summary.json a=$(f $OUT/pmc_fetch '*counter_collection.csv') b=$(f $OUT/pmc_write '*counter_collection.csv') c=$(f $OUT/pmc_sq '*counter_collection.csv') > "$OUT/pmc_summary.txt"
 python3 tools/summarize_pmc.py profiles/${TAG}_stage1_pmc_summary.json a=$(f $OUT/pmc_s1_fetch '*counter_collection.csv') b=$(f $OUT/pmc_s1_write '*counter_collection.csv') c=$(f $OUT/pmc_s1_sq '*counter_collection.csv') > "$OUT/pmc_s1_summary.txt"
 cp profiles/${TAG}_*.csv profiles/${TAG}_*.json "$OUT/"
