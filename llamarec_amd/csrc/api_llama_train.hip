@@ -428,10 +428,12 @@ extern "C" int lr_llama_lora_loss_grad(lr_llama_lora_t* h, const int32_t* packed
     RUN(lr_launch_skinny(ws.dqkv + h->qcols + h->kcols, qw, n, h->vcols, bv_t, 1, ws.dt, 2 * LT_RP, LT_RP, scaling, 0,
                          0.f, sd));
     RUN(lr_launch_lora_da(s.xn, n, d, ws.dt, r, stream, drop_p, daq, dav, sd));
-    RUN(lr_launch_gemm(ws.dqkv, wt.wqkv_t, ws.dxn, nullptr, n, d, qw, LR_EPI_STORE, gv, st));
+    if (l > 0)  // below layer 0 only the frozen embedding is left: its input gradient has no reader
+      RUN(lr_launch_gemm(ws.dqkv, wt.wqkv_t, ws.dxn, nullptr, n, d, qw, LR_EPI_STORE, gv, st));
     RUN(join_side(h, st));
-    RUN(lr_launch_rmsnorm_bwd(ws.dxn, s.x, w.input_norm, ws.dx, ws.dx, n, d, c.rms_eps, nullptr, ws.dt, a_cat, r, stream,
-                              drop_p, st));
+    if (l > 0)
+      RUN(lr_launch_rmsnorm_bwd(ws.dxn, s.x, w.input_norm, ws.dx, ws.dx, n, d, c.rms_eps, nullptr, ws.dt, a_cat, r,
+                                stream, drop_p, st));
   }
   return LR_OK;
 }
