@@ -296,3 +296,49 @@ def test_full_size_llama2_7b_properties():
     loss_p = float(eng.loss_and_grads([seqs[i] for i in perm], [labels[i] for i in perm]))
     assert abs(loss_p - loss) < 2e-3
     assert torch.allclose(eng.grads, g1, rtol=5e-2, atol=5e-3 * float(g1.abs().max()))
+
+
+@pytest.mark.parametrize("r,lens", [(4, [300, 150, 33]), (16, [129, 260])])
+def test_other_ranks_and_long_prompts_match_float64_oracle(golden_dir, r, lens):
+    """LoRA ranks other than the reference's 8 (padding rows of the 16-wide MFMA tile must stay inert) and prompts that
+    span several attention blocks (128 query rows / 64 keys per block), against the float64 oracle."""
+    from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.rank_train import LoraTrainEngine
+    from llamarec_amd.synth import bf16_round, hash_uniform
+    from oracle import llama_train_oracle as LO
+
+    z, cfg, sd, _ = _load(golden_dir, "tiny_hd128")
+    cfg = dict(cfg, max_position_embeddings=512)
+    eng = LoraTrainEngine(LlamaRanker.from_state_dict(sd, cfg), r=r, alpha=2 * r, dropout=0.0)
+    init = {}
+    for i, (k, v) in enumerate(sorted(eng.named().items())):
+        init[k] = bf16_round(hash_uniform(900 + i, tuple(v.shape), 0.05))
+    eng.load(init)
+    rng = np.random.default_rng(r)
+    seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], size=n - 2), [2]]).astype(np.int32) for n in lens]
+    labels = [np.where(np.arange(len(s)) >= len(s) - 2, s, -100) for s in seqs]
+    loss = float(eng.loss_and_grads(seqs, labels))
+    ol, og = LO.loss_and_grads(sd, cfg, init, [s.tolist() for s in seqs], [l.tolist() for l in labels], r, 2 * r)
+    assert abs(loss - ol) < 1e-2
+    got = eng.named(eng.grads)
+    for n in sorted(init):
+        assert _rel(got[n].cpu().numpy(), og[n]) < 4e-2, (n, _rel(got[n].cpu().numpy(), og[n]))
+    allg = np.concatenate([got[n].cpu().numpy().ravel() for n in sorted(init)])
+    allr = np.concatenate([og[n].ravel() for n in sorted(init)])
+    assert _rel(allg, allr) < 2e-2
+
+
+def test_workspace_and_position_limits_are_checked(golden_dir):
+    from llamarec_amd._lib import LlamaRecError, check, lib, stream_ptr
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd16")
+    eng = _engine(z, cfg, sd, names)
+    too_long = [np.concatenate([[1], np.full(cfg["max_position_embeddings"], 5), [2]]).astype(np.int32)]
+    with pytest.raises(LlamaRecError, match="max_positions"):
+        eng.loss_and_grads(too_long, [np.where(np.arange(len(too_long[0])) >= len(too_long[0]) - 2, too_long[0], -100)])
+    # a workspace sized for 8 tokens cannot take 131
+    seqs, labels = _unpack(z, 0)
+    eng._ws = torch.empty(lib().lr_llama_lora_workspace_bytes(eng._h, 8, 1, 2), dtype=torch.uint8, device=eng.device)
+    eng._workspace = lambda n, B, m: eng._ws
+    with pytest.raises(LlamaRecError, match="workspace"):
+        eng.loss_and_grads(seqs, labels)
