@@ -393,7 +393,9 @@ class LoraRankerTrainer:
                     lo = s0 + (k * self.world + self.rank) * self.micro
                     batch = [self.samples[int(i)] for i in order[lo:lo + self.micro]]
                     seqs, labels = P.train_pack(batch, getattr(a, "llm_max_text_len", P.LLM_MAX_TEXT_LEN), eos)
-                    losses.append(eng.loss_and_grads(seqs, labels, grad_scale=1.0 / self.accum, accumulate=k > 0))
+                    # the engine returns a view of its output scalar: copy it (on the stream, no host sync)
+                    losses.append(eng.loss_and_grads(seqs, labels, grad_scale=1.0 / self.accum,
+                                                     accumulate=k > 0).clone())
                 average_gradients_(eng.grads)
                 eng.apply(a.lora_lr * self.schedule(step), self.MAX_GRAD_NORM)
                 step += 1
