@@ -207,6 +207,34 @@ def train_dataset_golden():
                              "samples": [{k: [int(x) for x in s[k]] for k in ("input_ids", "attention_mask", "labels")}
                                          for s in samples],
                              "collate_max_length": 48, "collate_first4": {k: v.tolist() for k, v in coll.items()}})
+    # G12: LLMValidDataset / LLMTestDataset (dataloader/llm.py:286-387) on a hand-made dataset + retrieved dict
+    train = {1: [5, 6, 7, 8], 2: [9, 10, 11], 3: list(range(12, 40)), 4: [1, 2]}
+    val = {1: [20], 2: [21], 3: [3], 4: [30]}
+    test = {1: [25], 2: [26], 3: [4], 4: [31]}
+    val_users, test_users = [1, 3, 4], [2, 3]
+    rs = np.random.RandomState(11)
+    def cands(answer):
+        c = [int(x) for x in rs.permutation(np.arange(1, 41))[:6] if int(x) != answer][:5]
+        c.insert(int(rs.randint(0, 6)), answer)
+        return c
+    val_c = [cands(val[u][0]) for u in val_users]
+    test_c = [cands(test[u][0]) for u in test_users]
+    ev = {"train": {str(k): v for k, v in train.items()}, "val": {str(k): v for k, v in val.items()},
+          "test": {str(k): v for k, v in test.items()}, "val_users": val_users, "val_candidates": val_c,
+          "test_users": test_users, "test_candidates": test_c, "cases": []}
+    for max_hist, title_len in ((20, 32), (3, 2)):
+        args = SimpleNamespace(num_items=40, llm_max_title_len=title_len, llm_max_text_len=1536,
+                               llm_system_template=ref_args.llm_system_template,
+                               llm_input_template=ref_args.llm_input_template)
+        vd = DL.LLMValidDataset(args, train, val, max_hist, np.random, titles, FakeTokenizer(), prompter, val_users, val_c)
+        td = DL.LLMTestDataset(args, train, val, test, max_hist, np.random, titles, FakeTokenizer(), prompter, test_users,
+                               test_c)
+        def items(ds):
+            return [{k: ([int(x) for x in s[k]] if isinstance(s[k], (list, tuple)) else int(s[k]))
+                     for k in ("input_ids", "attention_mask", "labels")} for s in (ds[i] for i in range(len(ds)))]
+        ev["cases"].append({"llm_max_history": max_hist, "llm_max_title_len": title_len, "val": items(vd),
+                            "test": items(td)})
+    out["eval_datasets"] = ev
     path = os.path.join(OUT, "llm_train_dataset.json")
     json.dump(out, open(path, "w"))
     print("wrote", path, os.path.getsize(path), "bytes")

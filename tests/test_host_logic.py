@@ -187,3 +187,27 @@ def test_linear_schedule_is_hf_linear_with_warmup():
             assert abs(sch.lr_lambdas[0](step) - f(step)) < 1e-12
     except ImportError:
         pass
+
+
+def test_llm_valid_and_test_datasets_match_reference(golden_dir):
+    """LLMValidDataset / LLMTestDataset (dataloader/llm.py:286-387): history = train[-H:] (validation) or
+    (train + val)[-H:] (test), the retriever's candidates in their order, eval tokenisation."""
+    from types import SimpleNamespace
+
+    from llamarec_amd.rerank import build_test_items, build_val_items
+
+    g = json.load(open(os.path.join(golden_dir, "llm_train_dataset.json")))
+    ev = g["eval_datasets"]
+    titles = {int(k): v for k, v in g["titles"].items()}
+    dataset = {"train": {int(k): v for k, v in ev["train"].items()}, "val": {int(k): v for k, v in ev["val"].items()},
+               "test": {int(k): v for k, v in ev["test"].items()}, "meta": titles}
+    retrieved = {k: ev[k] for k in ("val_users", "val_candidates", "test_users", "test_candidates")}
+    for c in ev["cases"]:
+        args = SimpleNamespace(llm_max_history=c["llm_max_history"], llm_max_title_len=c["llm_max_title_len"],
+                               llm_max_text_len=1536, llm_system_template=None, llm_input_template=None)
+        for got, ref in ((build_val_items(dataset, retrieved, FakeTokenizer(), args), c["val"]),
+                         (build_test_items(dataset, retrieved, FakeTokenizer(), args), c["test"])):
+            assert len(got) == len(ref)
+            for a, b in zip(got, ref):
+                assert a["input_ids"] == b["input_ids"] and a["attention_mask"] == b["attention_mask"]
+                assert a["labels"] == b["labels"]
