@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import argparse
 
+from .prompt import DEFAULT_INPUT_TEMPLATE, DEFAULT_SYSTEM_TEMPLATE
+
 EXPERIMENT_ROOT = "experiments"   # config.py:5-9
 STATE_DICT_KEY = "model_state_dict"
 RAW_DATASET_ROOT_FOLDER = "data"
@@ -34,8 +36,8 @@ def build_parser():
     p.add_argument("--llm_max_text_len", type=int, default=1536)
     p.add_argument("--llm_max_history", type=int, default=20)
     p.add_argument("--llm_negative_sample_size", type=int, default=19)
-    p.add_argument("--llm_system_template", type=str, default=None)
-    p.add_argument("--llm_input_template", type=str, default=None)
+    p.add_argument("--llm_system_template", type=str, default=DEFAULT_SYSTEM_TEMPLATE)   # config.py:242-249
+    p.add_argument("--llm_input_template", type=str, default=DEFAULT_INPUT_TEMPLATE)
     p.add_argument("--llm_retrieved_path", type=str, default=None)
     p.add_argument("--lora_r", type=int, default=8)
     p.add_argument("--lora_alpha", type=int, default=32)
@@ -67,7 +69,7 @@ def build_parser():
     p.add_argument("--enable_lr_schedule", action="store_true")
     p.add_argument("--enable_lr_warmup", action="store_true")
     p.add_argument("--warmup_steps", type=int, default=None)
-    p.add_argument("--decay_step", type=int, default=10000)
+    p.add_argument("--decay_step", type=int, default=None)
     p.add_argument("--gamma", type=float, default=1.0)
     p.add_argument("--val_strategy", type=str, default=None, choices=["epoch", "iteration"])
     p.add_argument("--val_iterations", type=int, default=500)

@@ -181,7 +181,8 @@ def lr_lambda_from_args(args, num_training_steps=None):
     if getattr(args, "enable_lr_warmup", False):
         w, n = args.warmup_steps, max(int(num_training_steps or 0), args.warmup_steps + 1)
         return lambda it: it / max(1, w) if it < w else max(0.0, (n - it) / max(1, n - w))
-    return lambda it: args.gamma ** (it // args.decay_step)
+    step = args.decay_step or 10000   # the reference leaves --decay_step unset (config.py); StepLR needs a period
+    return lambda it: args.gamma ** (it // step)
 
 
 class LRUTrainer:

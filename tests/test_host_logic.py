@@ -211,3 +211,20 @@ def test_llm_valid_and_test_datasets_match_reference(golden_dir):
             for a, b in zip(got, ref):
                 assert a["input_ids"] == b["input_ids"] and a["attention_mask"] == b["attention_mask"]
                 assert a["labels"] == b["labels"]
+
+
+def test_flag_defaults_match_reference_config(golden_dir):
+    """Every flag this implementation shares with the reference's parser has the reference's value after
+    `set_template` (config.py:12-148), for each dataset / model code of BASELINE.json's configs."""
+    from llamarec_amd import config as cfg
+
+    g = json.load(open(os.path.join(golden_dir, "config_defaults.json")))
+    shared = 0
+    for key, ref in g.items():
+        mc, ds = key.split("/")
+        mine = vars(cfg.parse(["--dataset_code", ds], model_code=mc))
+        for k, v in ref.items():
+            if k in mine:
+                shared += 1
+                assert mine[k] == v, (key, k, mine[k], v)
+    assert shared >= 6 * 40
