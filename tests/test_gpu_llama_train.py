@@ -342,3 +342,26 @@ def test_workspace_and_position_limits_are_checked(golden_dir):
     eng._workspace = lambda n, B, m: eng._ws
     with pytest.raises(LlamaRecError, match="workspace"):
         eng.loss_and_grads(seqs, labels)
+
+
+@pytest.mark.parametrize("name", ["tiny_hd128", "tiny_gqa"])
+def test_minimal_and_ragged_micro_batches_match_oracle(golden_dir, name):
+    """The shortest sample the reference's collate accepts (3 tokens: labels[-3] == -100), alone and packed with
+    neighbours of very different length."""
+    from oracle import llama_train_oracle as LO
+
+    z, cfg, sd, names = _load(golden_dir, name)
+    init = {n: z["init/" + n] for n in names}
+    rng = np.random.default_rng(4)
+    for lens in ([3], [3, 70, 4, 129]):
+        eng = _engine(z, cfg, sd, names)
+        seqs = [np.concatenate([[1], rng.integers(3, cfg["vocab_size"], size=n - 2), [2]]).astype(np.int32) for n in lens]
+        labels = [np.where(np.arange(len(s)) >= len(s) - 2, s, -100) for s in seqs]
+        loss = float(eng.loss_and_grads(seqs, labels))
+        ol, og = LO.loss_and_grads(sd, cfg, init, [s.tolist() for s in seqs], [l.tolist() for l in labels],
+                                   int(z["lora_r"]), int(z["lora_alpha"]))
+        assert abs(loss - ol) < 1.5e-2, (lens, loss, ol)
+        got = eng.named(eng.grads)
+        allg = np.concatenate([got[n].cpu().numpy().ravel() for n in names])
+        allr = np.concatenate([og[n].ravel() for n in names])
+        assert _rel(allg, allr) < 3e-2, (lens, _rel(allg, allr))
