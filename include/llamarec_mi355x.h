@@ -246,6 +246,18 @@ int lr_llama_pack_qkv(const uint16_t* q, const uint16_t* k, const uint16_t* v, i
 int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,
                           uint16_t* out);
 
+/* Load-time NF4 round trip  W -> dequant(quant(W))  of a frozen bf16 weight matrix (DEVICE pointers, n elements,
+ * row-major blocks of 64): what the reference's forward effectively multiplies by, since it quantises every Linear
+ * of the base model with BitsAndBytesConfig(load_in_4bit, nf4, double quant, bf16 compute) (train_ranker.py:49-56,
+ * setup_demo.py:67-74; bitsandbytes 0.43.1 is absent here, its published algorithm is restated -- parity with it is
+ * unpinned). double_quant != 0 also quantises the per-block absmax (8-bit dynamic code, blocks of 256, mean offset).
+ * out may alias w. Synchronises the stream once when double_quant is set (load-time call).
+ * lr_nf4_dynamic_map: the 256 sorted levels of that 8-bit code (HOST float[256]). */
+size_t lr_nf4_scratch_bytes(size_t n);
+int lr_nf4_roundtrip_bf16(const uint16_t* w, size_t n, int32_t double_quant, uint16_t* out, void* scratch,
+                          size_t scratch_bytes, void* hip_stream);
+int lr_nf4_dynamic_map(float* out256);
+
 /* Stand-alone bf16 GEMM used by the prefill (exposed for parity tests and roofline runs):
  * C[M][N] = A[M][K] * B[N][K]^T, bf16 in, fp32 accumulate, bf16 out; all DEVICE pointers,
  * row-major, leading dimensions = K, K, N. variant: 0 = auto, 1 = generic (any shape),

@@ -70,6 +70,10 @@ PROTOTYPES = {
                                      C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_attention_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lr_nf4_scratch_bytes": (C.c_size_t, [C.c_size_t]),
+    "lr_nf4_roundtrip_bf16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "lr_nf4_dynamic_map": (C.c_int, [C.POINTER(C.c_float)]),
     "lr_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "lr_llama_lora_state_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(A.LrLoraTrainConfig)]),
     "lr_llama_lora_create": (C.c_int, [C.c_void_p, C.POINTER(A.LrLlamaWeightsTDesc), C.POINTER(A.LrLoraTrainConfig),

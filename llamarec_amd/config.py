@@ -39,6 +39,8 @@ def build_parser():
     p.add_argument("--llm_system_template", type=str, default=DEFAULT_SYSTEM_TEMPLATE)   # config.py:242-249
     p.add_argument("--llm_input_template", type=str, default=DEFAULT_INPUT_TEMPLATE)
     p.add_argument("--llm_retrieved_path", type=str, default=None)
+    # config.py:250 (the reference's `type=bool` makes any non-empty string True; here "false" / "0" / "no" turn it off)
+    p.add_argument("--llm_load_in_4bit", type=lambda v: str(v).lower() not in ("false", "0", "no", ""), default=True)
     p.add_argument("--lora_r", type=int, default=8)
     p.add_argument("--lora_alpha", type=int, default=32)
     # ranker LoRA fine-tuning (config.py:203,236-241,257-269; defaults filled in set_template like config.py:81-102)

@@ -95,11 +95,25 @@ class LlamaRanker:
 
     # -- construction ------------------------------------------------------------------------
     @classmethod
-    def from_state_dict(cls, state_dict, config, device="cuda:0", lora=None):
+    def from_state_dict(cls, state_dict, config, device="cuda:0", lora=None, nf4=False):
         """state_dict: HF LlamaForCausalLM names -> torch tensors / numpy arrays (any float dtype).
-        lora: optional dict(r=8, alpha=32, weights={"...q_proj.lora_A.weight": A, "...lora_B.weight": B})."""
+        lora: optional dict(r=8, alpha=32, weights={"...q_proj.lora_A.weight": A, "...lora_B.weight": B}).
+        nf4: pass every Linear of the base through the NF4 + double-quantisation round trip first, like the
+        reference's BitsAndBytesConfig (train_ranker.py:49-56; lm_head, embeddings and norms stay as they are --
+        bitsandbytes skips lm_head); the adapter is merged AFTER it, as peft adds it to the dequantised output."""
         self = cls(config, device)
         dev = self.device
+        scratch = {}
+
+        def nf4_roundtrip(w):
+            w = w.to(torch.bfloat16).contiguous()
+            need = lib().lr_nf4_scratch_bytes(w.numel())
+            if scratch.get("n", 0) < need:
+                scratch["buf"], scratch["n"] = torch.empty(need, dtype=torch.uint8, device=dev), need
+            with torch.cuda.device(dev):
+                check(lib().lr_nf4_roundtrip_bf16(w.data_ptr(), w.numel(), 1, w.data_ptr(), scratch["buf"].data_ptr(),
+                                                  scratch["n"], stream_ptr()), "lr_nf4_roundtrip_bf16")
+            return w
 
         def t(name):
             w = state_dict[name]
@@ -107,8 +121,11 @@ class LlamaRanker:
                 w = torch.from_numpy(np.ascontiguousarray(w))
             return w.to(dev)
 
+        def linear(name):
+            return nf4_roundtrip(t(name)) if nf4 else t(name)
+
         def merged(name):
-            w = t(name).float()
+            w = linear(name).float()
             if lora is not None:
                 base = name[: -len(".weight")]
                 ka, kb = base + ".lora_A.weight", base + ".lora_B.weight"
@@ -128,9 +145,9 @@ class LlamaRanker:
             q, k, v = (merged(p + f"self_attn.{n}_proj.weight") for n in "qkv")
             T[f"{i}.wqkv"] = torch.cat([self._interleave_rope_rows(q), self._interleave_rope_rows(k), v],
                                        0).to(torch.bfloat16).contiguous()
-            T[f"{i}.wo"] = t(p + "self_attn.o_proj.weight").to(torch.bfloat16).contiguous()
-            T[f"{i}.wgu"] = self._interleave_gate_up(t(p + "mlp.gate_proj.weight"), t(p + "mlp.up_proj.weight"))
-            T[f"{i}.wdown"] = t(p + "mlp.down_proj.weight").to(torch.bfloat16).contiguous()
+            T[f"{i}.wo"] = linear(p + "self_attn.o_proj.weight").to(torch.bfloat16).contiguous()
+            T[f"{i}.wgu"] = self._interleave_gate_up(linear(p + "mlp.gate_proj.weight"), linear(p + "mlp.up_proj.weight"))
+            T[f"{i}.wdown"] = linear(p + "mlp.down_proj.weight").to(torch.bfloat16).contiguous()
             T[f"{i}.input_norm"] = t(p + "input_layernorm.weight").to(torch.bfloat16).contiguous()
             T[f"{i}.post_norm"] = t(p + "post_attention_layernorm.weight").to(torch.bfloat16).contiguous()
         self._create()
@@ -165,9 +182,10 @@ class LlamaRanker:
         return self
 
     @classmethod
-    def from_pretrained(cls, path, device="cuda:0", adapter_path=None):
+    def from_pretrained(cls, path, device="cuda:0", adapter_path=None, load_in_4bit=False):
         """Local HF directory (config.json + *.safetensors), optionally a PEFT LoRA adapter directory
-        (adapter_config.json + adapter_model.safetensors) merged at load. No network access."""
+        (adapter_config.json + adapter_model.safetensors) merged at load. load_in_4bit: the reference's NF4 round trip
+        of the base Linears (see from_state_dict). No network access."""
         from safetensors import safe_open
 
         cfg = json.load(open(os.path.join(path, "config.json")))
@@ -177,7 +195,8 @@ class LlamaRanker:
                 with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
                     for k in f.keys():
                         sd[k] = f.get_tensor(k)
-        return cls.from_state_dict(sd, cfg, device, load_peft_adapter(adapter_path) if adapter_path else None)
+        return cls.from_state_dict(sd, cfg, device, load_peft_adapter(adapter_path) if adapter_path else None,
+                                   nf4=load_in_4bit)
 
     def _interleave_rope_rows(self, w):
         """Rows of every head reordered to (0, hd/2, 1, hd/2+1, ...): rotation pairs become adjacent

@@ -53,7 +53,7 @@ def main(argv=None, export_root=None):
 
         model = LlamaRanker.from_state_dict(synth_llama_state(c, args.seed), c,
                                             lora=load_peft_adapter(args.llm_adapter_path) if args.llm_adapter_path
-                                            else None)
+                                            else None, nf4=args.llm_load_in_4bit)
     else:
         from transformers import AutoTokenizer
 
@@ -65,7 +65,8 @@ def main(argv=None, export_root=None):
         tokenizer.padding_side = "left"
         tokenizer.truncation_side = "left"
         tokenizer.clean_up_tokenization_spaces = True
-        model = LlamaRanker.from_pretrained(args.llm_base_model, adapter_path=args.llm_adapter_path)
+        model = LlamaRanker.from_pretrained(args.llm_base_model, adapter_path=args.llm_adapter_path,
+                                            load_in_4bit=args.llm_load_in_4bit)
     ncls = args.llm_negative_sample_size + 1
     args.num_items = len(dataset["smap"])
     verbalizer = ManualVerbalizer(tokenizer=tokenizer, prefix="", post_log_softmax=False, classes=list(range(ncls)),
