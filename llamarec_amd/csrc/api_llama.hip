@@ -146,12 +146,26 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     if (l == c.num_layers - 1 && h->prune_last) {
       // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
       // last layer needs K/V for every token but attention output, o_proj, and the MLP for B rows only.
-      RUN(lr_launch_attention_rows(ws.qkv, ws.att_last, cu, B, ws.last_rows, B, nh, nkv, hd, st));
+      if (hd == 128 && h->attn_variant != 1) {
+        // the MFMA kernel over ALL rows (188 us for 14.8 k tokens, 16 us for one prompt) beats the scalar kernel over the
+        // B last rows (459 / 295 us): attend everything, keep the last rows
+        RUN(lr_launch_attention(ws.qkv, ws.att, cu, cu_host, ws.tok_pos, ws.tok_seq, B, n, nh, nkv, hd, h->attn_variant,
+                                nullptr, st));
+        RUN(lr_launch_gather_rows(ws.att, ws.last_rows, B, nh * hd, ws.att_last, st));
+      } else {
+        RUN(lr_launch_attention_rows(ws.qkv, ws.att_last, cu, B, ws.last_rows, B, nh, nkv, hd, st));
+      }
       RUN(lr_launch_gather_rows(ws.x, ws.last_rows, B, d, ws.x_last, st));
-      RUN(lr_launch_gemm(ws.att_last, w.wo, ws.x_last, ws.x_last, B, d, nh * hd, LR_EPI_RESIDUAL, 1, st));
+      // B-row products: the generic kernel, or -- latency mode -- split-K over the 256-column tiles (weight streaming
+      // spread over 64-128 CUs instead of N / 64 workgroups of the small-tile kernel)
+      const int pv = h->gemm_variant == 5 ? 5 : 1;
+      RUN(lr_launch_gemm(ws.att_last, w.wo, ws.x_last, ws.x_last, B, d, nh * hd, LR_EPI_RESIDUAL, pv, st, nullptr, nullptr,
+                         0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
       RUN(lr_launch_rmsnorm(ws.x_last, w.post_norm, ws.xn_last, B, d, c.rms_eps, nullptr, st));
-      RUN(lr_launch_gemm(ws.xn_last, w.wgu, ws.h_last, nullptr, B, 2 * f, d, LR_EPI_SWIGLU, 1, st));
-      RUN(lr_launch_gemm(ws.h_last, w.wdown, ws.x_last, ws.x_last, B, d, f, LR_EPI_RESIDUAL, 1, st));
+      RUN(lr_launch_gemm(ws.xn_last, w.wgu, ws.h_last, nullptr, B, 2 * f, d, LR_EPI_SWIGLU, pv, st, nullptr, nullptr, 0, 0,
+                         ws.splitk, LR_SPLITK_WS_BYTES));
+      RUN(lr_launch_gemm(ws.h_last, w.wdown, ws.x_last, ws.x_last, B, d, f, LR_EPI_RESIDUAL, pv, st, nullptr, nullptr, 0, 0,
+                         ws.splitk, LR_SPLITK_WS_BYTES));
       ws.compact = true;
       break;
     }

@@ -890,7 +890,7 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
   if (variant == 0) variant = (fast_ok && M >= 128) ? 4 : 1;
-  if (variant == 5 && !(fast_ok && M >= 128)) variant = 1;  // latency mode falls back like auto does
+  if (variant == 5 && !fast_ok) variant = 1;  // latency mode: any row count (B last-token rows too), shapes as auto
   if (variant >= 2 && !fast_ok)
     LR_FAIL(LR_EUNSUPPORTED, "gemm variants 2..5 need N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
