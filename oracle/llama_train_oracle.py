@@ -30,15 +30,18 @@ def _rope(x, cos, sin):
     return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)
 
 
-def loss_and_grads(sd, cfg, lora, seqs, labels, r=8, alpha=32, dtype=torch.float64):
+def loss_and_grads(sd, cfg, lora, seqs, labels, r=8, alpha=32, dtype=torch.float64, drop_masks=None):
     """sd: HF-named float arrays of the frozen base; lora: {"layers.{l}.{q,v}_proj.lora_{A,B}": array};
-    seqs / labels: lists of int lists (labels -100 = ignored). Returns (loss, {name: grad array})."""
+    seqs / labels: lists of int lists (labels -100 = ignored). Returns (loss, {name: grad array}).
+    drop_masks: optional list (one per layer) of [total_tokens, hidden] arrays holding 0 or 1 / (1 - p): the adapters'
+    input dropout (peft: lora_dropout on x before lora_A), rows in packed order."""
     d, nh, nkv = cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
     hd, eps, theta = d // nh, cfg["rms_norm_eps"], cfg["rope_theta"]
     W = {k: torch.from_numpy(np.asarray(v, np.float64)).to(dtype) for k, v in sd.items()}
     P = {k: torch.from_numpy(np.asarray(v, np.float64)).to(dtype).requires_grad_(True) for k, v in lora.items()}
     scaling = alpha / r
     total, count = torch.zeros((), dtype=dtype), 0
+    row0 = 0
     for ids, lab in zip(seqs, labels):
         T = len(ids)
         inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float64) / hd))
@@ -49,11 +52,14 @@ def loss_and_grads(sd, cfg, lora, seqs, labels, r=8, alpha=32, dtype=torch.float
         for i in range(cfg["num_hidden_layers"]):
             p = f"model.layers.{i}."
             xn = _rms(x, W[p + "input_layernorm.weight"], eps)
+            xd = xn
+            if drop_masks is not None:
+                xd = xn * torch.from_numpy(np.asarray(drop_masks[i][row0:row0 + T], np.float64)).to(dtype)
             q = xn @ W[p + "self_attn.q_proj.weight"].T
-            q = q + scaling * ((xn @ P[f"layers.{i}.q_proj.lora_A"].T) @ P[f"layers.{i}.q_proj.lora_B"].T)
+            q = q + scaling * ((xd @ P[f"layers.{i}.q_proj.lora_A"].T) @ P[f"layers.{i}.q_proj.lora_B"].T)
             k = xn @ W[p + "self_attn.k_proj.weight"].T
             v = xn @ W[p + "self_attn.v_proj.weight"].T
-            v = v + scaling * ((xn @ P[f"layers.{i}.v_proj.lora_A"].T) @ P[f"layers.{i}.v_proj.lora_B"].T)
+            v = v + scaling * ((xd @ P[f"layers.{i}.v_proj.lora_A"].T) @ P[f"layers.{i}.v_proj.lora_B"].T)
             q, k, v = q.reshape(T, nh, hd), k.reshape(T, nkv, hd), v.reshape(T, nkv, hd)
             q, k = _rope(q, cos, sin), _rope(k, cos, sin)
             rep = nh // nkv
@@ -73,6 +79,7 @@ def loss_and_grads(sd, cfg, lora, seqs, labels, r=8, alpha=32, dtype=torch.float
             lp = torch.log_softmax(logits[:-1][keep], dim=-1)
             total = total - lp[torch.arange(int(keep.sum())), tgt[keep]].sum()
             count += int(keep.sum())
+        row0 += T
     loss = total / max(count, 1)
     loss.backward()
     return float(loss.detach()), {k: (v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape))
@@ -93,3 +100,34 @@ def clip_and_adamw(params, grads, m, v, step, lr, max_grad_norm, beta1=0.9, beta
         vh = v[k] / (1 - beta2 ** step)
         params[k] -= lr * mh / (np.sqrt(vh) + eps)
     return norm
+
+
+# ---- the HIP step's counter-based dropout stream (csrc/llama_train.hip: lt_keep / lr_lora_drop_stream), restated so
+# ---- that a test can hand the oracle the very mask the kernels use (torch's own masks are not reproducible)
+def _mix32(h):
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    h = (h * np.uint32(0x85EBCA6B)).astype(np.uint32)
+    h ^= h >> np.uint32(13)
+    h = (h * np.uint32(0xC2B2AE35)).astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def drop_stream(seed, pass_no, layer):
+    m = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * ((pass_no * 131 + layer + 1) & m)) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return (z ^ (z >> 31)) & 0xFFFFFFFF
+
+
+def drop_mask(seed, pass_no, layer, n_rows, d, p):
+    """[n_rows, d] float64: 1 / (1 - p) where the element is kept, 0 where it is dropped."""
+    thresh = min(int(p * 4294967296.0), 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        rows = np.arange(n_rows, dtype=np.uint32)[:, None]
+        cols = np.arange(d, dtype=np.uint32)[None, :]
+        stream = np.uint32(drop_stream(seed, pass_no, layer))
+        h = _mix32(_mix32(stream ^ (rows * np.uint32(0x9E3779B9))) + cols * np.uint32(0x7F4A7C15))
+    return np.where(h >= np.uint32(thresh), 1.0 / (1.0 - p), 0.0)

@@ -365,3 +365,31 @@ def test_minimal_and_ragged_micro_batches_match_oracle(golden_dir, name):
         allg = np.concatenate([got[n].cpu().numpy().ravel() for n in names])
         allr = np.concatenate([og[n].ravel() for n in names])
         assert _rel(allg, allr) < 3e-2, (lens, _rel(allg, allr))
+
+
+def test_gradients_with_dropout_match_the_oracle_under_the_same_mask(golden_dir):
+    """The adapters' input dropout (config.py:259, p = 0.05; here 0.3 so that it matters): the oracle is handed the
+    mask of the kernels' counter-based stream (restated in oracle/llama_train_oracle.py), so forward AND backward must
+    have used that same mask in every layer for the gradients to agree."""
+    from oracle import llama_train_oracle as LO
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd128")
+    p, seed = 0.3, 21
+    eng = _engine(z, cfg, sd, names, dropout=p, seed=seed)
+    seqs, labels = _unpack(z, 0)
+    n = sum(len(s) for s in seqs)
+    for pass_no in (1, 2):                                  # the stream moves on with every micro-batch
+        loss = float(eng.loss_and_grads(seqs, labels))
+        masks = [LO.drop_mask(seed, pass_no, l, n, cfg["hidden_size"], p) for l in range(cfg["num_hidden_layers"])]
+        assert 0.25 < 1.0 - (masks[0] > 0).mean() < 0.35
+        ol, og = LO.loss_and_grads(sd, cfg, {k: z["init/" + k] for k in names}, [s.tolist() for s in seqs],
+                                   [l.tolist() for l in labels], int(z["lora_r"]), int(z["lora_alpha"]), drop_masks=masks)
+        assert abs(loss - ol) < 1e-2, (pass_no, loss, ol)
+        got = eng.named(eng.grads)
+        allg = np.concatenate([got[k].cpu().numpy().ravel() for k in names])
+        allr = np.concatenate([og[k].ravel() for k in names])
+        assert _rel(allg, allr) < 2e-2, (pass_no, _rel(allg, allr))
+        # and the mask matters: without it the oracle's gradient is far from the engine's
+        _, og0 = LO.loss_and_grads(sd, cfg, {k: z["init/" + k] for k in names}, [s.tolist() for s in seqs],
+                                   [l.tolist() for l in labels], int(z["lora_r"]), int(z["lora_alpha"]))
+        assert _rel(allg, np.concatenate([og0[k].ravel() for k in names])) > 0.1
