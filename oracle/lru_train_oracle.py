@@ -68,8 +68,31 @@ def num_blocks(state):
     return n
 
 
-def loss_and_grads(state, tokens, labels):
-    """-> (loss, grads dict with the state's names/shapes). tokens/labels: int [B, L]."""
+def drop_scale(seed, site, n, p):
+    """The HIP step's counter-based dropout (csrc/lru_train.hip: tr_drop_scale), restated: float64 [n] of 0 or
+    1 / (1 - p) for flat element indices 0..n-1 of dropout site `site` under 64-bit `seed`."""
+    C1, C2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xD6E8FEB86659FD93)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) ^ (C1 * np.uint64(site + 1)) ^ (np.arange(n, dtype=np.uint64) * C2)
+        for _ in range(2):
+            x ^= x >> np.uint64(32)
+            x = x * C2
+        x ^= x >> np.uint64(32)
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u < np.float32(p), 0.0, 1.0 / (1.0 - float(np.float32(p))))
+
+
+def pass_seed(cfg_seed, pass_no):
+    """Dropout seed of forward pass `pass_no` (0-based) of an engine created with `seed=cfg_seed` (tr_begin_pass)."""
+    m = (1 << 64) - 1
+    return ((cfg_seed * 0x9E3779B97F4A7C15) + pass_no * 0xA24BAED4963EE407) & m
+
+
+def loss_and_grads(state, tokens, labels, dropout=None):
+    """-> (loss, grads dict with the state's names/shapes). tokens/labels: int [B, L].
+    dropout: optional (seed64, p, p_attn): apply the masks of the HIP step's stream at the reference's four dropout
+    sites (model/lru.py: embedding, LRU-layer output, FFN activation, FFN output) -- torch's masks are not reproducible,
+    the positions and the 1 / (1 - p) scaling are the reference's."""
     P = {k: np.asarray(v, dtype=np.float64) for k, v in state.items()}
     tokens = np.asarray(tokens)
     labels = np.asarray(labels)
@@ -79,8 +102,15 @@ def loss_and_grads(state, tokens, labels):
     nb = num_blocks(state)
     G = {k: np.zeros_like(v) for k, v in P.items()}
 
+    def mask(site, shape, p):
+        if dropout is None or p <= 0:
+            return 1.0
+        return drop_scale(dropout[0], site, int(np.prod(shape)), p).reshape(shape)
+
+    pd, pa = (dropout[1], dropout[2]) if dropout is not None else (0.0, 0.0)
     # ---- forward
-    x, ln0 = _ln_fwd(E[tokens], P["embedding.layer_norm.weight"], P["embedding.layer_norm.bias"])
+    M0 = mask(0, (B, L, 64), pd)
+    x, ln0 = _ln_fwd(E[tokens] * M0, P["embedding.layer_norm.weight"], P["embedding.layer_norm.bias"])
     caches = []
     for b in range(nb):
         pre = f"model.lru_blocks.{b}."
@@ -93,13 +123,15 @@ def loss_and_grads(state, tokens, labels):
         h = np.zeros_like(u)
         for t in range(L):
             h[:, t] = u[:, t] + (lam * h[:, t - 1] * m[:, t - 1, None] if t > 0 else 0.0)
-        o = (h @ Wout.T + bout).real                              # :160
+        Mo, Mg, Mz = mask(10 + 4 * b, (B, L, 64), pa), mask(11 + 4 * b, (B, L, 256), pd), mask(12 + 4 * b, (B, L, 64), pd)
+        o = (h @ Wout.T + bout).real * Mo                         # :160, dropout
         y, ln1 = _ln_fwd(o + x, P[pre + "lru_layer.layer_norm.weight"], P[pre + "lru_layer.layer_norm.bias"])
         a = y @ P[pre + "feed_forward.w_1.weight"].T + P[pre + "feed_forward.w_1.bias"]
-        g = _gelu(a)
-        z0 = g @ P[pre + "feed_forward.w_2.weight"].T + P[pre + "feed_forward.w_2.bias"] + y
+        g = _gelu(a) * Mg
+        z0 = (g @ P[pre + "feed_forward.w_2.weight"].T + P[pre + "feed_forward.w_2.bias"]) * Mz + y
         xn, ln2 = _ln_fwd(z0, P[pre + "feed_forward.layer_norm.weight"], P[pre + "feed_forward.layer_norm.bias"])
-        caches.append(dict(x=x, p=p, h=h, lam=lam, nu=nu, th=th, ga=ga, Win=Win, Wout=Wout, ln1=ln1, y=y, a=a, g=g, ln2=ln2))
+        caches.append(dict(x=x, p=p, h=h, lam=lam, nu=nu, th=th, ga=ga, Win=Win, Wout=Wout, ln1=ln1, y=y, a=a, g=g, ln2=ln2,
+                           Mo=Mo, Mg=Mg, Mz=Mz))
         x = xn
     scores = x @ E.T + P["model.bias"]                            # model/lru.py:85
     valid = labels != 0                                           # CrossEntropyLoss(ignore_index=0)
@@ -123,9 +155,10 @@ def loss_and_grads(state, tokens, labels):
         dz0, G[pre + "feed_forward.layer_norm.weight"], G[pre + "feed_forward.layer_norm.bias"] = _ln_bwd(
             dx, c["ln2"], P[pre + "feed_forward.layer_norm.weight"])
         W1, W2 = P[pre + "feed_forward.w_1.weight"], P[pre + "feed_forward.w_2.weight"]
-        G[pre + "feed_forward.w_2.weight"] = dz0.reshape(-1, 64).T @ c["g"].reshape(-1, 256)
-        G[pre + "feed_forward.w_2.bias"] = dz0.reshape(-1, 64).sum(0)
-        da = (dz0 @ W2) * _gelu_grad(c["a"])
+        dzw = dz0 * c["Mz"]                                        # the W2 branch sits behind a dropout
+        G[pre + "feed_forward.w_2.weight"] = dzw.reshape(-1, 64).T @ c["g"].reshape(-1, 256)
+        G[pre + "feed_forward.w_2.bias"] = dzw.reshape(-1, 64).sum(0)
+        da = (dzw @ W2) * c["Mg"] * _gelu_grad(c["a"])
         G[pre + "feed_forward.w_1.weight"] = da.reshape(-1, 256).T @ c["y"].reshape(-1, 64)
         G[pre + "feed_forward.w_1.bias"] = da.reshape(-1, 256).sum(0)
         dy = dz0 + da @ W1
@@ -133,6 +166,8 @@ def loss_and_grads(state, tokens, labels):
             dy, c["ln1"], P[pre + "lru_layer.layer_norm.weight"])
         # o = Re(W h + b): gradient pairs (d/dRe + i d/dIm)
         Wout, h = c["Wout"], c["h"]
+        dres = dy0                                                # the residual branch is not dropped
+        dy0 = dy0 * c["Mo"]
         do = dy0.reshape(-1, 64)
         hf = h.reshape(-1, 128)
         G[pre + "lru_layer.out_proj.weight"] = _pair(do.T @ hf.real - 1j * (do.T @ hf.imag))
@@ -156,9 +191,9 @@ def loss_and_grads(state, tokens, labels):
         G[pre + "lru_layer.in_proj.weight"] = _pair(dp.real.T @ xf + 1j * (dp.imag.T @ xf))
         G[pre + "lru_layer.in_proj.bias"] = _pair(dp.sum(0))
         Win = c["Win"]
-        dx = dy0 + (dp.real @ Win.real + dp.imag @ Win.imag).reshape(B, L, 64)
+        dx = dres + (dp.real @ Win.real + dp.imag @ Win.imag).reshape(B, L, 64)
     de, G["embedding.layer_norm.weight"], G["embedding.layer_norm.bias"] = _ln_bwd(dx, ln0, P["embedding.layer_norm.weight"])
-    np.add.at(G["embedding.token.weight"], tokens.reshape(-1), de.reshape(-1, 64))
+    np.add.at(G["embedding.token.weight"], tokens.reshape(-1), (de * M0).reshape(-1, 64))
     return loss, G
 
 

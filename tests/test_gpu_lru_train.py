@@ -149,3 +149,25 @@ def test_loss_decreases_and_dropout_is_deterministic(golden_dir):
     c = LRUTrainEngine(init, dropout=0.2, attn_dropout=0.2, seed=6)
     assert abs(float(c.train_step(z["tokens"], z["labels"])) - la[0]) > 1e-3   # another seed, other masks
     assert all(np.isfinite(la))
+
+
+def test_gradients_with_dropout_match_the_oracle_under_the_same_masks(golden_dir):
+    """Dropout at the reference's four sites (embedding, LRU-layer output, FFN activation, FFN output; config.py
+    bert_dropout / bert_attn_dropout 0.2) with the kernels' counter-based stream restated in the oracle: forward and
+    backward of every site must have used the same mask for the gradients to agree -- on two consecutive passes."""
+    from oracle import lru_train_oracle as TO
+    from llamarec_amd.train import LRUTrainEngine
+
+    z, names = load(golden_dir)
+    init = {n: z["init/" + n] for n in names}
+    pd, pa, seed = 0.2, 0.3, 17
+    eng = LRUTrainEngine(init, dropout=pd, attn_dropout=pa, seed=seed)
+    for pass_no in range(2):
+        loss = float(eng.loss_and_grads(z["tokens"], z["labels"]))
+        o_loss, o_grads = TO.loss_and_grads(init, z["tokens"], z["labels"],
+                                            dropout=(TO.pass_seed(seed, pass_no), pd, pa))
+        assert abs(loss - o_loss) < 5e-5, (pass_no, loss, o_loss)
+        got = eng.grad_dict()
+        for n in names:
+            assert rel_err(as_pairs(got[n]), o_grads[n]) < 5e-4, (pass_no, n, rel_err(as_pairs(got[n]), o_grads[n]))
+    assert abs(o_loss - float(z["step0/loss"])) > 1e-3            # the masks matter
