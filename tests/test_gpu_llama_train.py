@@ -393,3 +393,26 @@ def test_gradients_with_dropout_match_the_oracle_under_the_same_mask(golden_dir)
         _, og0 = LO.loss_and_grads(sd, cfg, {k: z["init/" + k] for k in names}, [s.tolist() for s in seqs],
                                    [l.tolist() for l in labels], int(z["lora_r"]), int(z["lora_alpha"]))
         assert _rel(allg, np.concatenate([og0[k].ravel() for k in names])) > 0.1
+
+
+def test_eight_step_loss_trajectory_follows_the_oracle(golden_dir):
+    """Eight clipped AdamW steps at a learning rate large enough to move the loss by > 1: the bf16 HIP engine stays on
+    the float64 oracle's loss curve (optimizer state, bias corrections, clipping and the adapter refresh every step)."""
+    from oracle import llama_train_oracle as LO
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd128")
+    eng = _engine(z, cfg, sd, names)
+    seqs, labels = _unpack(z, 0)
+    sl, ll = [s.tolist() for s in seqs], [l.tolist() for l in labels]
+    params = {n: z["init/" + n].astype(np.float64) for n in names}
+    m = {n: np.zeros_like(params[n]) for n in names}
+    v = {n: np.zeros_like(params[n]) for n in names}
+    lr, got, ref = 2e-3, [], []
+    for step in range(8):
+        got.append(float(eng.loss_and_grads(seqs, labels)))
+        eng.apply(lr, 1.0)
+        ol, og = LO.loss_and_grads(sd, cfg, params, sl, ll, int(z["lora_r"]), int(z["lora_alpha"]))
+        LO.clip_and_adamw(params, og, m, v, step + 1, lr, 1.0)
+        ref.append(ol)
+    assert ref[0] - ref[-1] > 1.0, ref
+    assert max(abs(a - b) for a, b in zip(got, ref)) < 3e-2, (got, ref)
