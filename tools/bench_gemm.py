@@ -7,6 +7,7 @@ from llamarec_amd._lib import check, lib, stream_ptr
 def run(variants, M=14800, rounds=5, check_equal=True):
     shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
     g = torch.Generator(device="cuda"); g.manual_seed(0)
+    ws = torch.empty((64 << 20) + 4096, dtype=torch.uint8, device="cuda")   # split-K planes / stream-K slots + flags
     for name, N, K in shapes:
         A = (torch.randn(M, K, generator=g, device="cuda") ).to(torch.bfloat16)
         B = (torch.randn(N, K, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
@@ -19,7 +20,8 @@ def run(variants, M=14800, rounds=5, check_equal=True):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    check(lib().lr_gemm_bf16_nt(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, v, stream_ptr()), "gemm")
+                    check(lib().lr_gemm_bf16_nt_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, v, ws.data_ptr(),
+                                                   ws.numel(), stream_ptr()), "gemm")
                 e1.record(); torch.cuda.synchronize()
                 if r: times[v].append(e0.elapsed_time(e1) / 3)
                 outs[v] = C
@@ -36,7 +38,7 @@ def run(variants, M=14800, rounds=5, check_equal=True):
 
 if __name__ == "__main__":
     vs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 3]
-    run(vs)
+    run(vs, M=int(sys.argv[2]) if len(sys.argv) > 2 else 14800)
 
 
 def yardstick(M=14800, rounds=5):
