@@ -44,14 +44,25 @@ class LLMEvaluator:
         self.max_text_len = getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN)
 
     def predict(self):
+        """Under torch.distributed every rank scores its contiguous share of the items and the int64 rank histograms
+        are summed with ONE all-reduce; the reference gathers [N, 32000] fp32 logits instead
+        (trainer/llm.py:122,127)."""
+        from . import dist as D
+
         t0 = time.time()
         ncls = self.verbalizer.num_classes
         hist = torch.zeros(ncls + 1, dtype=torch.int64, device=self.model.device)
-        for i in range(0, len(self.items), self.batch_size):
-            seqs, labels = P.eval_pack(self.items[i:i + self.batch_size], self.max_text_len)
+        rank, world, _ = D.env_world()
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            rank, world = 0, 1
+        lo, hi = D.shard_range(len(self.items), rank, world)
+        mine = self.items[lo:hi]
+        for i in range(0, len(mine), self.batch_size):
+            seqs, labels = P.eval_pack(mine[i:i + self.batch_size], self.max_text_len)
             scores = self.model.prefill_verbalize(seqs, self.verbalizer.label_token_ids)
             ranked = M.rank_classes(scores)
             M.rank_histogram(ranked, torch.from_numpy(labels).to(self.model.device), hist)
+        D.all_reduce_sum_(hist)
         m = M.metrics_from_histogram(hist, self.ks) if len(self.items) else {}
         out = {"test_" + k: v for k, v in m.items()}
         out["test_loss"] = -1.0  # model/llm.py:128-129: eval loss is the constant -1
@@ -62,7 +73,9 @@ class LLMEvaluator:
     def test(self, test_retrieval):
         average_metrics = self.predict()
         overall = merge_overall_metrics(average_metrics, test_retrieval)
-        if self.export_root:
+        from . import dist as D
+
+        if self.export_root and D.env_world()[0] == 0:            # every rank holds the same sums: rank 0 writes
             os.makedirs(self.export_root, exist_ok=True)
             with open(os.path.join(self.export_root, "subset_metrics.json"), "w") as f:
                 json.dump(average_metrics, f, indent=4)
