@@ -214,16 +214,36 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 
   // ---- DMA staging: 16 pieces per tile (4 rows each); wave w moves pieces 4w..4w+3 of K and of V
   const int prow = lane >> 4, ppos = lane & 15;
+  // per-lane byte offsets of this wave's 4 K pieces and 4 V pieces inside a key block (row and swizzled chunk are
+  // block-invariant): a full block then costs one 64-bit add per DMA, and only the sequence's last, ragged block
+  // pays the per-row clamp to T - 1 (a wave-uniform branch: as selects inside one loop hipcc predicates every block)
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 4 + prow;
+    koff[i] = (unsigned)(row * stride + (ppos ^ (row & 15)) * 8) * 2u;
+    voff[i] = (unsigned)(row * stride + (ppos ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 8) * 2u;
+  }
   auto stage = [&](int kb, int buf) {
     char* base = smem + buf * FA_STAGE_BYTES + wave * 4096;
+    if ((kb + 1) * FA_KB <= T) {
+      const char* kblk = reinterpret_cast<const char*>(kbase) + (size_t)kb * FA_KB * stride * 2;
+      const char* vblk = reinterpret_cast<const char*>(vbase) + (size_t)kb * FA_KB * stride * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 4 + prow;
-      const int key = min(kb * FA_KB + row, T - 1);
-      const int kchunk = ppos ^ (row & 15);
-      const int vchunk = ppos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-      attn_glds16(kbase + (size_t)key * stride + kchunk * 8, base + i * 1024);
-      attn_glds16(vbase + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
+      for (int i = 0; i < 4; ++i) {
+        attn_glds16(kblk + koff[i], base + i * 1024);
+        attn_glds16(vblk + voff[i], base + FA_TILE_BYTES + i * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + prow;
+        const int key = min(kb * FA_KB + row, T - 1);
+        const int kchunk = ppos ^ (row & 15);
+        const int vchunk = ppos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        attn_glds16(kbase + (size_t)key * stride + kchunk * 8, base + i * 1024);
+        attn_glds16(vbase + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
+      }
     }
   };
 
