@@ -2,30 +2,40 @@
 """bench.py -- users/sec through the two-stage retrieve+rerank scoring path on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W
+      N = 1: runs in this process. N > 1 without torchrun's environment: this process starts N ranks itself
+      (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`)
+      BEFORE it touches the GPU, relays rank 0's JSON line and exits with the children's code; it fails loudly
+      when the node has fewer than N GPUs. Nothing is exec-replaced.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+      --master-port P bench.py --gpus N --steps K --warmup W          (the driver's own launch; same ranks)
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): ML-100k shape --
-LRURec (V=3650, L=200, D=64, 2 blocks) retrieve top-50 with history masking, then ONE Llama-2-7b
-(32 layers, bf16, random weights) prefill over the templated prompts of the same users and the
-verbalizer gather over the 20 candidate letters. Synthetic data per BASELINE.md section 3.
-A step = one pass of the hot path over one batch of 32 users (the reference's ranker eval batch,
-config.py:98). Inputs (history ids, labels, prompt token ids) are resident in HBM before the
-timed region. One process per GPU; users are sharded, weights replicated; the only collective is
-the final all-reduce of the int64 rank histograms (inside the timed region).
+Workload = BASELINE.json north_star's "synthetic sequences of the Beauty shape" (configs[2]): LRURec (V = 12 086,
+L = 50, D = 64, 2 blocks) retrieve top-50 with history masking, then ONE Llama-2-7b (32 layers, bf16, random
+weights) prefill over the templated prompts of the same users and the verbalizer gather over the 20 candidate
+letters. Synthetic data per BASELINE.md section 3. A step = one pass of the hot path over one batch of users; the
+batch is the reference's eval loop re-batched by TOKEN budget (llamarec_amd/packing.py: 16 384 prompt tokens,
+about 22 Beauty users, instead of 16 prompts of whatever length -- eval order is free, dataloader/llm.py:196-202,
+and a prompt's scores do not depend on its batch). Inputs (history ids, labels, prompt token ids) are resident in
+HBM before the timed region. One process per GPU over RCCL; users are sharded, weights replicated; the only
+collective is the final all-reduce of the int64 rank histograms (inside the timed region).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (256x256x64 bf16 MFMA GEMM): algorithmic FLOPs per launch over
-                  its measured duration (HIP events recorded by the library on the launch stream)
-  cpu_baseline -- the CPU oracle (a port of the reference algorithm) timed on the host cores on a
-                  bounded sample of the same workload (N = 1 only)
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline     -- the dominant kernel (256x256x64 bf16 MFMA GEMM): algorithmic FLOPs per launch over its measured
+                  duration (HIP events recorded by the library on the launch stream)
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm) timed on the host cores on a bounded sample
+                  of the same workload (N = 1 only)
+  parity       -- GPU vs that oracle on the same sample, outside the timed region (N = 1 only)
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +45,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+STAGE2_TOL = 3e-2          # |GPU - oracle| bound on the O(1) verbalizer scores (bf16 path), as in tests/
+# SURVEY.md section 6 / BASELINE.md section 2: the REFERENCE code's own stage-1 CPU path (model/lru.py + masking +
+# top-20 of trainer/lru.py), torch 2.10 CPU, 8 cores, measured in the survey container (not on the GPU box)
+REFERENCE_CODE_STAGE1_USERS_PER_S = {"ml-100k": 242.0, "beauty": 554.0, "games": 1706.0}
 
 
 def parse():
@@ -42,10 +56,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ml-100k")
+    ap.add_argument("--workload", default="beauty")
+    ap.add_argument("--token-budget", type=int, default=None, help="prompt tokens per step (default: packing.TOKEN_BUDGET)")
+    ap.add_argument("--users-per-step", type=int, default=0, help="> 0: the reference's fixed-size batches "
+                    "(config.py:98: 16, ML-100k 32) instead of token-budget batches")
+    ap.add_argument("--no-shared-prefix", action="store_true", help="do not compute the prompts' common template prefix once per step")
     ap.add_argument("--layers", type=int, default=32, help="Llama layers (32 = Llama-2-7b; other values are for profiling only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-shapes", action="store_true", help="skip the short Beauty-shape side measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that reuses it)")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the short ML-100k-shape and LoRA-step side measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to "
                     "rehearse several ranks on one GPU)")
@@ -53,53 +71,191 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(workload, hist_ids, T_sample, lru_sd):
-    """Oracle ("port") timed on the host: stage 1 over the shard's users; stage 2 on 4 users x 2 of
-    the 32 Llama-2-7b layers, extrapolated x16 (a full 7B prefill is ~5 TFLOP per user)."""
+def spawn_ranks(args) -> int:
+    """Parent of an N-rank run: no HIP call is made here (torch.cuda.device_count() does not initialise the GPU)."""
+    import torch
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.share_gpu:
+        print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s); refusing to report a "
+              f"{n_dev}-GPU number as n_gpus={args.gpus}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(p.stdout)
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+    return p.returncode if p.returncode else (0 if lines else 1)
+
+
+def stage2_sample(T_sample, layers=2, vocab=2048, seed=0):
+    """A 2-layer slice of Llama-2-7b at full width (d 4096, d_ff 11008, 32 x 128) with random bf16-valued weights
+    and prompts of the given lengths: what the CPU oracle can finish in seconds."""
+    from llamarec_amd.synth import bf16_round, llama_param_shapes
+
+    cfg = dict(vocab_size=vocab, hidden_size=4096, intermediate_size=11008, num_hidden_layers=layers,
+               num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=4096,
+               rms_norm_eps=1e-5, rope_theta=10000.0)
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, shape in llama_param_shapes(cfg):
+        sd[name] = np.ones(shape, np.float32) if len(shape) == 1 else \
+            bf16_round(rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02))
+    seqs = [np.concatenate([[1], rng.integers(3, vocab, size=int(t) - 1)]).astype(np.int32) for t in T_sample]
+    return cfg, sd, seqs, list(range(100, 120))
+
+
+def ndcg_at_10(ranked, labels):
+    """mean NDCG@10 of one relevant item per row (trainer/utils.py:43-90 with one answer: 1 / log2(rank + 2))."""
+    ranked, labels = np.asarray(ranked)[:, :10], np.asarray(labels).reshape(-1, 1)
+    hit = ranked == labels
+    return float((hit / np.log2(np.arange(2, ranked.shape[1] + 2))[None, :]).sum(1).mean())
+
+
+def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retriever, dev):
+    """Oracle ("port") timed on the host: stage 1 over the resident users; stage 2 on 4 users x 2 of the 32
+    Llama-2-7b layers, extrapolated x16 (a full 7B prefill is ~10 TFLOP per Beauty user). The same oracle outputs
+    are then compared with the HIP path on the same inputs (never inside the timed region)."""
+    import torch
+
+    from llamarec_amd.llm import LlamaRanker
     from oracle import llama_oracle as LO
     from oracle import lru_oracle as O
 
     cores = len(os.sched_getaffinity(0))
+    blas_threads = None
     try:  # threads the numpy BLAS actually uses for the stage-2 GEMMs (the dominant part)
         from threadpoolctl import threadpool_info
 
         blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
-        if blas:
-            cores = min(cores, max(blas))
+        blas_threads = max(blas) if blas else None
     except Exception:
         pass
     omp_threads = O.num_threads()
     orc = O.LruOracle(lru_sd)
     t0 = time.perf_counter()
-    orc.retrieve_topk(hist_ids, 50, True)
+    o_top, _ = orc.retrieve_topk(hist_ids, 50, True)
     t1 = time.perf_counter() - t0
     s1_per_user = t1 / len(hist_ids)
 
-    cfg = dict(vocab_size=2048, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
-               num_attention_heads=32, num_key_value_heads=32, rms_norm_eps=1e-5, rope_theta=10000.0)
-    rng = np.random.default_rng(0)
-    from llamarec_amd.synth import llama_param_shapes
-
-    sd = {}
-    for name, shape in llama_param_shapes(cfg):
-        sd[name] = np.ones(shape, np.float32) if len(shape) == 1 else \
-            rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
-    seqs = [np.concatenate([[1], rng.integers(3, 2048, size=int(t) - 1)]) for t in T_sample]
+    cfg, sd, seqs, label_ids = stage2_sample(T_sample)
     t0 = time.perf_counter()
-    LO.prefill_verbalize(sd, cfg, seqs, list(range(100, 120)), mode="bf16")
+    o_scores = LO.prefill_verbalize(sd, cfg, seqs, label_ids, mode="bf16")
     t2 = time.perf_counter() - t0
-    s2_per_user = t2 / len(seqs) * (32 / 2)
-    return {
-        "value": 1.0 / (s1_per_user + s2_per_user), "unit": "users/s", "cores": cores, "kind": "port",
-        "sample": (f"stage 1: C oracle ({omp_threads} OpenMP threads) over {len(hist_ids)} {workload} users = {t1:.2f} s; stage 2: numpy "
-                   f"oracle, {len(seqs)} users (T={[int(t) for t in T_sample]}) x 2 of 32 Llama-2-7b layers "
-                   f"= {t2:.2f} s, extrapolated x16"),
+    s2_per_user = t2 / len(seqs) * (32 / cfg["num_hidden_layers"])
+    base = {
+        "value": 1.0 / (s1_per_user + s2_per_user), "unit": "users/s", "kind": "port",
+        "cores": min(cores, blas_threads) if blas_threads else cores, "host_cores": cores,
+        "omp_threads": omp_threads, "blas_threads": blas_threads,
+        "sample": (f"stage 1: C oracle ({omp_threads} OpenMP threads) over {len(hist_ids)} {workload} users = {t1:.2f} s; "
+                   f"stage 2: numpy oracle ({blas_threads} BLAS threads), {len(seqs)} users (T={[int(t) for t in T_sample]}) x "
+                   f"{cfg['num_hidden_layers']} of 32 Llama-2-7b layers at full width = {t2:.2f} s, extrapolated x"
+                   f"{32 // cfg['num_hidden_layers']}"),
         "stage1_users_per_s": 1.0 / s1_per_user, "stage2_users_per_s_extrapolated": 1.0 / s2_per_user,
+        "reference_code_stage1_users_per_s": REFERENCE_CODE_STAGE1_USERS_PER_S.get(workload),
+        "reference_code_note": "the reference's own torch CPU path (stage 1 only), 8 cores, measured in the build "
+                               "container (SURVEY.md section 6); not measured on this host",
     }
+
+    g_top, _ = retriever.retrieve_topk(torch.from_numpy(hist_ids).to(dev), 50, True)
+    g_top = g_top.cpu().numpy()
+    small = LlamaRanker.from_state_dict(sd, cfg, device=dev)
+    g_scores = small.prefill_verbalize(seqs, label_ids).cpu().numpy()
+    del small
+    err = float(np.abs(g_scores - o_scores).max())
+    # ordering of the 20 candidate scores: every pair the oracle separates by more than 2 x tolerance must agree
+    d_o = o_scores[:, :, None] - o_scores[:, None, :]
+    d_g = g_scores[:, :, None] - g_scores[:, None, :]
+    decided = np.abs(d_o) > 2 * STAGE2_TOL
+    agree = float((np.sign(d_o[decided]) == np.sign(d_g[decided])).mean()) if decided.any() else 1.0
+    lab2 = np.arange(len(seqs)) % 20  # stand-in answer letters for an NDCG@10 of the two rankings
+    parity = {
+        "stage1_users": int(len(hist_ids)), "stage1_top50_equal": bool(np.array_equal(g_top, o_top)),
+        "stage1_ndcg10_gpu": ndcg_at_10(g_top, labels), "stage1_ndcg10_oracle": ndcg_at_10(o_top, labels),
+        "stage2_prompts": len(seqs), "stage2_layers": cfg["num_hidden_layers"], "stage2_width": cfg["hidden_size"],
+        "stage2_max_abs_err": err, "stage2_tolerance": STAGE2_TOL, "stage2_rank_agree": agree,
+        "stage2_pairs_decided": int(decided.sum() // 2),
+        "stage2_ndcg10_gpu": ndcg_at_10(np.argsort(-g_scores, axis=1, kind="stable"), lab2),
+        "stage2_ndcg10_oracle": ndcg_at_10(np.argsort(-o_scores, axis=1, kind="stable"), lab2),
+    }
+    parity["ok"] = bool(parity["stage1_top50_equal"] and err <= STAGE2_TOL and agree == 1.0)
+    return base, parity
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 PMC summary
+    (profiles/r*_pmc_summary.json, made by tools/summarize_pmc.py from separate --pmc passes of this command on a
+    2-layer slice: FETCH_SIZE x 2 + WRITE_SIZE). (None, None) if no summary is present."""
+    def round_no(p):
+        m = re.search(r"r(\d+)[a-z]?_pmc_summary\.json$", p)
+        return int(m.group(1)) if m else -1
+
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")), key=round_no)
+    paths = [p for p in paths if "stage1" not in os.path.basename(p)]
+    if not paths:
+        return None, None
+    path = paths[-1]
+    d = json.load(open(path))
+    num = den = 0.0
+    for k, e in d.items():
+        if k.startswith("gemm256") and "hbm_bytes_per_launch" in e:
+            num += e["hbm_bytes_per_launch"] * e["launches_profiled"]
+            den += e["launches_profiled"]
+    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on a 2-layer slice; not collected by this run)"
+    return (num / den if den else None), src
+
+
+def build_steps(workload, rank, n_steps, budget, users_per_step, dev, shared_prefix):
+    """Resident inputs of `n_steps` steps for this rank: synthetic users of the rank's own block, grouped into steps."""
+    import torch
+
+    from llamarec_amd.llm import common_prefix_len
+    from llamarec_amd.packing import token_budget_steps
+    from llamarec_amd.synth import WORKLOADS, synth_prompt_tokens, synth_users
+
+    w = WORKLOADS[workload]
+    if users_per_step > 0:
+        n_users = n_steps * users_per_step
+    else:
+        probe = synth_users(workload, 256, first_user=rank * w["U"])[3]
+        n_users = int(np.ceil((n_steps + 1.5) * budget / float(probe.mean())))
+    n_users = min(max(n_users, 1), w["U"])
+    hist, labels, _, T = synth_users(workload, n_users, first_user=rank * w["U"])
+    if users_per_step > 0:
+        groups = [np.arange(i, min(i + users_per_step, n_users)) for i in range(0, n_users, users_per_step)]
+    else:
+        groups = token_budget_steps(T, budget)
+    groups = groups[:n_steps] if len(groups) >= n_steps else groups
+    steps = []
+    for b, g in enumerate(groups):
+        pids, cu = synth_prompt_tokens(T[g], seed=1000 * (rank + 1) + b, shared_prefix=shared_prefix)
+        steps.append(dict(hist=torch.from_numpy(hist[g]).to(dev), labels=torch.from_numpy(labels[g]).to(dev),
+                          ids=torch.from_numpy(pids).to(dev), cu_dev=torch.from_numpy(cu).to(dev), cu=cu, users=len(g),
+                          prefix=common_prefix_len(pids, cu) if shared_prefix else 0))
+    used = np.concatenate(groups)
+    return steps, hist[used], labels[used], T[used]
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}. Launch exactly N ranks: python -m "
+              f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P "
+              f"bench.py --gpus {args.gpus} ... (or plain `python bench.py --gpus {args.gpus}`, which does that itself)",
+              file=sys.stderr)
+        sys.exit(2)
+
     import torch
 
     from llamarec_amd import dist as D
@@ -107,52 +263,52 @@ def main():
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = D.init_from_env(args.dist_backend)
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    D.all_reduce_sum_(ones)                    # over RCCL when world > 1: the driver can see N ranks took part
+    ranks_seen = int(ones.item())
+    if ranks_seen != world:
+        raise SystemExit(f"bench.py: all-reduce saw {ranks_seen} ranks, expected {world}")
 
     from llamarec_amd import _lib
     from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
     from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.packing import TOKEN_BUDGET
     from llamarec_amd.pipeline import TwoStagePipeline
-    from llamarec_amd.synth import WORKLOADS, synth_prompt_tokens, synth_users
+    from llamarec_amd.synth import WORKLOADS
 
     w = WORKLOADS[args.workload]
-    bsz = w["rerank_batch"]
-    n_shard = min(w["U"], max(bsz, args.steps * bsz))  # users this rank needs resident
-    hist, labels, n_hist, T = synth_users(args.workload, n_shard, first_user=rank * w["U"])
-    nb = max(1, len(hist) // bsz)
-    batches = []
-    for b in range(nb):
-        sl = slice(b * bsz, (b + 1) * bsz)
-        pids, cu = synth_prompt_tokens(T[sl], seed=1000 * (rank + 1) + b)
-        batches.append((torch.from_numpy(hist[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev),
-                        torch.from_numpy(pids).to(dev), torch.from_numpy(cu).to(dev), cu))
+    budget = args.token_budget or TOKEN_BUDGET
+    shared = not args.no_shared_prefix
+    steps, hist, labels, T = build_steps(args.workload, rank, max(args.steps, 1), budget, args.users_per_step, dev, shared)
+    nb = len(steps)
 
     lru_sd = init_lru_state_dict(w["V"], seed=42)
     retriever = LRURec.from_state_dict(lru_sd, device=dev)
     cfg = dict(LLAMA2_7B, num_hidden_layers=args.layers)
     ranker = LlamaRanker.random_init(cfg, seed=42, device=dev)
     label_ids = list(range(319, 339))  # stand-in ids of "A".."T" (taken from the tokenizer at run time in real use)
-    pipe = TwoStagePipeline(retriever, ranker, label_ids, device=dev)
+    pipe = TwoStagePipeline(retriever, ranker, label_ids, device=dev, shared_prefix=shared)
+
+    def run(s):
+        return pipe.step(s["hist"], s["labels"], s["ids"], s["cu_dev"], s["cu"], s["prefix"])
 
     for i in range(args.warmup):
-        pipe.step(*batches[i % nb])
+        run(steps[i % nb])
     pipe.reset()
     torch.cuda.synchronize()
 
     lib = _lib.lib()
     if not args.no_profile:
-        _lib.check(lib.lr_profile_start(args.steps * (args.layers * 6 + 16)), "lr_profile_start")
+        _lib.check(lib.lr_profile_start(args.steps * (args.layers * 8 + 24)), "lr_profile_start")
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        pipe.step(*batches[i % nb])
+        run(steps[i % nb])
     retr, rer, total_users = pipe.finish()
     torch.cuda.synchronize()
     D.barrier()
@@ -160,28 +316,15 @@ def main():
     lib.lr_profile_stop()
     elapsed = D.all_reduce_max_float(elapsed, device=dev)
 
-    users = args.steps * bsz * world
-    tok_per_step = float(np.mean([b[4][-1] for b in batches]))
+    users_rank = sum(steps[i % nb]["users"] for i in range(args.steps))
+    tok_rank = sum(int(steps[i % nb]["cu"][-1]) for i in range(args.steps))
+    users = total_users                      # all-reduced count of users scored in the timed region
+    assert world > 1 or users == users_rank
 
     def collect(kind):
         ms, work, n = C.c_double(), C.c_double(), C.c_int64()
         lib.lr_profile_collect(kind, C.byref(ms), C.byref(work), C.byref(n))
         return ms.value, work.value, n.value
-
-    def pmc_traffic():
-        """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
-        this same command (profiles/r01_pmc_summary.json, made by tools/summarize_pmc.py: FETCH_SIZE x2
-        + WRITE_SIZE, separate passes). None if the summary is absent."""
-        path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
-        if not os.path.exists(path):
-            return None
-        d = json.load(open(path))
-        num = den = 0.0
-        for k, e in d.items():
-            if k.startswith("gemm256") and "hbm_bytes_per_launch" in e:
-                num += e["hbm_bytes_per_launch"] * e["launches_profiled"]
-                den += e["launches_profiled"]
-        return num / den if den else None
 
     roofline = None
     extra = {}
@@ -192,16 +335,17 @@ def main():
         k_ms, k_fl, k_n = collect(5)
         if g_n:
             ach = g_fl / (g_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic()
             roofline = {"bound": "mfma", "kernel": "gemm256rb_kernel (bf16 256x256x64 MFMA tile, ping-pong pipeline; QKV+RoPE/O/gate-up+SwiGLU/down)",
                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                        "traffic": pmc_traffic(), "launches": g_n, "avg_launch_ms": g_ms / g_n,
+                        "traffic": traffic, "traffic_source": traffic_src, "launches": g_n, "avg_launch_ms": g_ms / g_n,
                         "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed}
         extra = {"attention_tflops": (a_fl / (a_ms * 1e-3) / 1e12) if a_n else None,
                  "attention_share_of_step_time": a_ms * 1e-3 / elapsed if a_n else None,
                  "stage1_ms_per_step": (e_ms + k_ms) / max(1, args.steps),
                  "item_topk_tflops_f32": (k_fl / (k_ms * 1e-3) / 1e12) if k_n else None}
 
-    # stage-1-only throughput over the whole resident shard (one call; reported, not the metric)
+    # stage-1-only throughput over this rank's resident users (one call; reported, not the metric)
     all_hist = torch.from_numpy(hist).to(dev)
     retriever.retrieve_topk(all_hist, 50, True)
     torch.cuda.synchronize()
@@ -211,80 +355,98 @@ def main():
     stage1_users_per_s = len(hist) / (time.perf_counter() - t1)
 
     if rank == 0:
+        # algorithmic prefill work of the timed region (T * 1.2952e10 + T^2 * 2.62e5 per user), whatever
+        # the kernels executed (shared prefix, last-layer pruning)
+        T_timed = np.concatenate([np.diff(steps[i % nb]["cu"]) for i in range(args.steps)]).astype(np.float64)
+        alg_flops = float((T_timed * 1.2952e10 + T_timed ** 2 * 2.62e5).sum()) * (args.layers / 32.0)
         out = {
             "metric": "users/sec through retrieve+rerank", "value": users / elapsed, "unit": "users/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{args.workload} two-stage: LRURec(V={w['V']}, L={w['L']}, D=64, 2 blocks) top-50 with "
                                     f"history mask -> Llama-2-7b ({args.layers} layers, bf16, random init) single prefill "
                                     f"-> verbalizer over 20 candidates"),
-                       "users_per_step": bsz, "mean_prompt_tokens_per_step": tok_per_step,
-                       "llama_layers": args.layers, "parallelism": f"dp{world}"},
+                       "batching": (f"{args.users_per_step} users per step (reference batch)" if args.users_per_step > 0 else
+                                    f"token budget {budget} per step (llamarec_amd/packing.py)"),
+                       "shared_prompt_prefix_tokens": float(np.mean([steps[i % nb]["prefix"] for i in range(args.steps)])),
+                       "users_per_step": users_rank / args.steps, "mean_prompt_tokens_per_step": tok_rank / args.steps,
+                       "llama_layers": args.layers, "parallelism": f"dp{world}", "collective_backend": args.dist_backend or "nccl"},
             "roofline": roofline, "stage1_only_users_per_s": stage1_users_per_s,
+            "prefill_algorithmic_tflops_per_gpu": alg_flops / elapsed / 1e12,
             "metrics": {"retrieve_NDCG@10": retr["NDCG@10"], "rerank_overall_NDCG@10": rer["NDCG@10"],
                         "users_counted": total_users},
         }
         out.update(extra)
-        if world == 1 and not args.no_other_shapes and args.workload != "beauty" and args.layers == LLAMA2_7B["num_hidden_layers"]:
-            # north_star also names the Beauty shape (configs[2], the item-GEMM roofline point): a short side
-            # measurement with the same ranker weights -- reported, never the metric
-            wb = WORKLOADS["beauty"]
-            hb, lb, _, Tb = synth_users("beauty", 6 * wb["rerank_batch"])
-            rb = LRURec.from_state_dict(init_lru_state_dict(wb["V"], seed=42), device=dev)
-            pb = TwoStagePipeline(rb, ranker, label_ids, device=dev)
-            bb = []
-            for b in range(6):
-                sl = slice(b * wb["rerank_batch"], (b + 1) * wb["rerank_batch"])
-                pids, cu = synth_prompt_tokens(Tb[sl], seed=77 + b)
-                bb.append((torch.from_numpy(hb[sl]).to(dev), torch.from_numpy(lb[sl]).to(dev), torch.from_numpy(pids).to(dev),
-                           torch.from_numpy(cu).to(dev), cu))
-            for i in range(2):
-                pb.step(*bb[i])
-            pb.reset()
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for i in range(2, 6):
-                pb.step(*bb[i])
-            pb.finish()
-            torch.cuda.synchronize()
-            tb = time.perf_counter() - tb
-            out["beauty_shape"] = {"users_per_s": 4 * wb["rerank_batch"] / tb, "steps": 4, "users_per_step": wb["rerank_batch"],
-                                   "mean_prompt_tokens_per_step": float(np.mean([b[4][-1] for b in bb[2:]])),
-                                   "ms_per_step": tb / 4 * 1e3}
-            # SURVEY.md 8(f) #4, the ranker's LoRA fine-tuning step on the same weights (reference micro-batch: 16
-            # prompts, config.py:90-97; 4 of this workload's prompt batches halved): reported, never the metric
-            from llamarec_amd.rank_train import LoraTrainEngine
-
-            eng = LoraTrainEngine(ranker, dropout=0.05, seed=1)
-            mb = []
-            for b in range(min(3, nb)):
-                cu = batches[b][4]
-                ids = batches[b][2].cpu().numpy()
-                seqs = [ids[cu[i]:cu[i + 1]].copy() for i in range(min(16, len(cu) - 1))]
-                for sq in seqs:
-                    sq[-1] = 2                                    # EOS closes a training sample
-                labs = [np.where(np.arange(len(sq)) >= len(sq) - 2, sq, -100) for sq in seqs]
-                mb.append((seqs, labs))
-            eng.loss_and_grads(*mb[0])
-            eng.apply(2e-4, 1.0)
-            torch.cuda.synchronize()
-            tt = time.perf_counter()
-            for seqs, labs in mb:
-                eng.loss_and_grads(seqs, labs)
-                eng.apply(2e-4, 1.0)
-            torch.cuda.synchronize()
-            tt = time.perf_counter() - tt
-            ntok = sum(len(sq) for seqs, _ in mb for sq in seqs)
-            out["lora_train_shape"] = {"micro_batch_prompts": len(mb[0][0]), "optimizer_steps": len(mb),
-                                       "ms_per_step": tt / len(mb) * 1e3, "tokens_per_s": ntok / tt,
-                                       "samples_per_s": sum(len(sq) for sq, _ in mb) / tt,
-                                       "loss_finite": bool(np.isfinite(float(eng._out[0])))}
-            del eng
+        if world == 1 and not args.no_other_shapes and args.layers == LLAMA2_7B["num_hidden_layers"]:
+            out.update(side_measurements(args, ranker, label_ids, dev, steps, shared))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, hist, T[:4], lru_sd)
-        print(json.dumps(out))
+            n1 = min(len(hist), 512)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(args.workload, hist[:n1], labels[:n1], T[:4], lru_sd,
+                                                                         retriever, dev)
+        print(json.dumps(out), flush=True)
     D.barrier()
+
+
+def side_measurements(args, ranker, label_ids, dev, steps, shared):
+    """Reported, never the metric: (1) BASELINE.json configs[1] (ML-100k shape) through the same pipeline, 4 steps;
+    (2) SURVEY.md 8(f) #4, three optimizer steps of the ranker's LoRA fine-tuning on the same weights."""
+    import torch
+
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.pipeline import TwoStagePipeline
+    from llamarec_amd.synth import WORKLOADS
+
+    out = {}
+    other = "ml-100k" if args.workload != "ml-100k" else "beauty"
+    wo = WORKLOADS[other]
+    so, _, _, _ = build_steps(other, 0, 6, args.token_budget or 16384, args.users_per_step, dev, shared)
+    ro = LRURec.from_state_dict(init_lru_state_dict(wo["V"], seed=42), device=dev)
+    po = TwoStagePipeline(ro, ranker, label_ids, device=dev, shared_prefix=shared)
+    for s in so[:2]:
+        po.step(s["hist"], s["labels"], s["ids"], s["cu_dev"], s["cu"], s["prefix"])
+    po.reset()
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    timed = so[2:6]
+    for s in timed:
+        po.step(s["hist"], s["labels"], s["ids"], s["cu_dev"], s["cu"], s["prefix"])
+    po.finish()
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - tb
+    nu = sum(s["users"] for s in timed)
+    out[other.replace("-", "") + "_shape"] = {"users_per_s": nu / tb, "steps": len(timed), "users_per_step": nu / len(timed),
+                                              "mean_prompt_tokens_per_step": float(np.mean([s["cu"][-1] for s in timed])),
+                                              "ms_per_step": tb / len(timed) * 1e3}
+    # the ranker's LoRA fine-tuning step (reference micro-batch: 16 prompts, config.py:90-97)
+    from llamarec_amd.rank_train import LoraTrainEngine
+
+    eng = LoraTrainEngine(ranker, dropout=0.05, seed=1)
+    mb = []
+    for s in steps[: min(3, len(steps))]:
+        cu = s["cu"]
+        ids = s["ids"].cpu().numpy()
+        seqs = [ids[cu[i]:cu[i + 1]].copy() for i in range(min(16, len(cu) - 1))]
+        for sq in seqs:
+            sq[-1] = 2                                    # EOS closes a training sample
+        labs = [np.where(np.arange(len(sq)) >= len(sq) - 2, sq, -100) for sq in seqs]
+        mb.append((seqs, labs))
+    eng.loss_and_grads(*mb[0])
+    eng.apply(2e-4, 1.0)
+    torch.cuda.synchronize()
+    tt = time.perf_counter()
+    for seqs, labs in mb:
+        eng.loss_and_grads(seqs, labs)
+        eng.apply(2e-4, 1.0)
+    torch.cuda.synchronize()
+    tt = time.perf_counter() - tt
+    ntok = sum(len(sq) for seqs, _ in mb for sq in seqs)
+    out["lora_train_shape"] = {"micro_batch_prompts": len(mb[0][0]), "optimizer_steps": len(mb),
+                               "ms_per_step": tt / len(mb) * 1e3, "tokens_per_s": ntok / tt,
+                               "samples_per_s": sum(len(sq) for sq, _ in mb) / tt,
+                               "loss_finite": bool(np.isfinite(float(eng._out[0])))}
+    del eng
+    return out
 
 
 if __name__ == "__main__":

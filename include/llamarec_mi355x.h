@@ -198,10 +198,10 @@ typedef struct lr_llama lr_llama_t;
 int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDesc* w, lr_llama_t** out);
 void lr_llama_destroy(lr_llama_t* h);
 
-/* Kernel selection: 0 = auto (default), 1 = generic kernels, 2 = the MFMA 256x256x64 GEMM /
- * head_dim-128 flash attention (K/V by LDS-DMA, 128 query rows per workgroup), attention 3 = the same
- * arithmetic with register-staged K/V and 256 query rows on 8 waves (measured equal within 3 %, kept for
- * A/B runs), gemm 3 / 4 = ping-pong pipelined 256x256x64 GEMMs (an error if a shape does not fit). gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
+/* Kernel selection: 0 = auto (default), 1 = generic kernels (any shape; the in-library cross-check of the fast
+ * ones), attention 2 = head_dim-128 MFMA flash attention (K/V by LDS-DMA, 128 query rows per workgroup),
+ * gemm 4 = the ping-pong pipelined 256x256x64 MFMA GEMM (an error if a shape does not fit).
+ * gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
  * variant 4 plus split-K wherever the output tiles alone would leave most CUs idle (a 460-token prompt
  * gives o_proj / down_proj 32 tiles for 256 CUs); shapes that do not fit fall back as in auto. The
  * split-K summation order depends on the token count, so unlike the default a prompt's scores are
@@ -230,6 +230,21 @@ int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_ids, const i
                                const int32_t* cu_seqlens_host, int32_t B,
                                const int32_t* label_token_ids, int32_t C, float* out_scores,
                                void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* The same call when every prompt of the batch starts with the same prefix_len tokens -- the template text in front
+ * of the first history item (dataloader/utils.py:24-40, templates/alpaca_short.json:3; about 36 Llama-2 tokens) --
+ * which is then evaluated ONCE: internally the batch is laid out as [prefix][rest of prompt 0]...[rest of prompt B-1]
+ * and the attention kernel reads keys/values of positions < prefix_len from the prefix rows. Inputs are the caller's
+ * ordinary packed prompts (prefix included in each). Scores are BIT-IDENTICAL to lr_llama_prefill_verbalize.
+ * Preconditions: 0 <= prefix_len < the shortest prompt; ids[cu[b] + i] == ids[cu[0] + i] for all b, i < prefix_len
+ * (lr_common_prefix_len computes the largest such value from host copies). prefix_len = 0, B = 1, head_dim != 128
+ * or the generic attention variant run the plain path. */
+int lr_llama_prefill_verbalize_prefix(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                                      const int32_t* cu_seqlens_host, int32_t B, int32_t prefix_len,
+                                      const int32_t* label_token_ids, int32_t C, float* out_scores,
+                                      void* workspace, size_t workspace_bytes, void* hip_stream);
+/* Host helper (pure CPU): longest token prefix shared by all B prompts, capped at (shortest prompt - 1). */
+int32_t lr_common_prefix_len(const int32_t* packed_ids_host, const int32_t* cu_seqlens_host, int32_t B);
 
 /* Compatibility: full last-position logits fp32 [B][vocab] (model/llm.py:131). */
 int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
@@ -261,9 +276,8 @@ int lr_nf4_dynamic_map(float* out256);
 /* Stand-alone bf16 GEMM used by the prefill (exposed for parity tests and roofline runs):
  * C[M][N] = A[M][K] * B[N][K]^T, bf16 in, fp32 accumulate, bf16 out; all DEVICE pointers,
  * row-major, leading dimensions = K, K, N. variant: 0 = auto, 1 = generic (any shape),
- * 2 = 256x256x64 MFMA tile, double-buffered; 3 = the same tile with the ping-pong 4-phase
- * pipeline; 4 = ping-pong with balanced fragment reads and region-recycling DMA prefetch (default for
- * N%256==0, K%64==0, M>=128; any M: rows are bounds-checked). */
+ * 4 = 256x256x64 MFMA tile, ping-pong pipeline with balanced fragment reads and region-recycling DMA prefetch
+ * (default for N%256==0, K%64==0, M>=128; any M: rows are bounds-checked). */
 int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
                     int32_t K, int32_t variant, void* hip_stream);
 /* The same with a device workspace for variant 5 (split-K, see lr_llama_set_variants): fp32 partial

@@ -59,6 +59,10 @@ PROTOTYPES = {
     "lr_llama_prefill_verbalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                              C.c_void_p]),
+    "lr_llama_prefill_verbalize_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                    C.c_void_p]),
+    "lr_common_prefix_len": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "lr_llama_last_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_llama_pack_gate_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

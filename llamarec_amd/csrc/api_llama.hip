@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "llama_kernels.h"
 
 typedef unsigned short u16;
@@ -39,8 +41,9 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
 }
 
 extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
-  if (!h || gemm_variant < 0 || gemm_variant > 5 || attention_variant < 0 || attention_variant > 3)
-    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: bad argument");
+  if (!h || (gemm_variant != 0 && gemm_variant != 1 && gemm_variant != 4 && gemm_variant != 5) || attention_variant < 0 ||
+      attention_variant > 2)
+    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: gemm in {0, 1, 4, 5}, attention in {0, 1, 2}");
   h->gemm_variant = gemm_variant;
   h->attn_variant = attention_variant;
   return LR_OK;
@@ -59,7 +62,7 @@ extern "C" void lr_llama_destroy(lr_llama_t* h) {
 }
 
 struct LlamaWs {
-  int32_t *tok_pos, *tok_seq, *last_rows;
+  int32_t *tok_pos, *tok_src, *last_rows, *seg_start;
   float* rope;
   u16 *x, *xn, *qkv, *att, *hmid;
   u16 *x_last, *xn_last, *att_last, *h_last;  // compact [B][.] buffers of the pruned last layer
@@ -80,7 +83,7 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   const size_t n = (size_t)max_tokens;
   const size_t qkv_w = (size_t)(c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
   w.tok_pos = (int32_t*)take(n * 4);
-  w.tok_seq = (int32_t*)take(n * 4);
+  w.tok_src = (int32_t*)take(n * 4);
   w.rope = (float*)take((size_t)c.max_positions * (c.head_dim / 2) * 2 * sizeof(float));
   w.x = (u16*)take(n * c.hidden_size * 2);
   w.xn = (u16*)take(n * c.hidden_size * 2);
@@ -89,6 +92,7 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.hmid = (u16*)take(n * c.intermediate_size * 2);
   const size_t nb = (size_t)(max_seqs > 0 ? max_seqs : 1);
   w.last_rows = (int32_t*)take(nb * 4);
+  w.seg_start = (int32_t*)take((nb + 2) * 4);
   w.x_last = (u16*)take(nb * c.hidden_size * 2);
   w.xn_last = (u16*)take(nb * c.hidden_size * 2);
   w.att_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
@@ -105,26 +109,47 @@ extern "C" size_t lr_llama_workspace_bytes(const lr_llama_t* h, int32_t max_toke
   return carve(h->cfg, max_tokens, max_seqs, nullptr).total;
 }
 
-// Runs the transformer body; leaves the residual stream (before the final norm) in ws.x.
-static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const int32_t* cu_host, int B,
+// Runs the transformer body; leaves the residual stream (before the final norm) in ws.x (all internal rows) or,
+// after a pruned last layer, in ws.x_last (one row per prompt). prefix_len = P > 0: the first P tokens of every
+// prompt are the same (the caller's promise) and are run ONCE as segment 0 of the internal layout (llama_elem.hip,
+// token_meta_kernel); the other segments attend to its K/V rows. Every row then sees exactly the operands of the
+// unshared run, so the scores are bit-identical to prefix_len = 0.
+static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const int32_t* cu_host, int B, int P,
                     void* workspace, size_t workspace_bytes, hipStream_t st, LlamaWs* out_ws) {
   if (!h || !ids || !cu || !cu_host || !workspace) LR_FAIL(LR_EINVAL, "llama prefill: null argument");
   if (B < 1) LR_FAIL(LR_EINVAL, "llama prefill: B=%d", B);
   const LrLlamaConfig& c = h->cfg;
   if (cu_host[0] != 0) LR_FAIL(LR_EINVAL, "llama prefill: cu_seqlens[0] must be 0");
-  int maxT = 0;
+  int maxT = 0, minT = 0x7fffffff;
   for (int b = 0; b < B; ++b) {
     int t = cu_host[b + 1] - cu_host[b];
     if (t < 1) LR_FAIL(LR_EINVAL, "llama prefill: prompt %d is empty", b);
     if (t > maxT) maxT = t;
+    if (t < minT) minT = t;
   }
   if (maxT > c.max_positions)
     LR_FAIL(LR_EINVAL, "llama prefill: prompt of %d tokens exceeds max_positions %d", maxT, c.max_positions);
-  const int n = cu_host[B];
-  LlamaWs ws = carve(c, n, B, (char*)workspace);
+  if (P < 0 || (P > 0 && P >= minT))
+    LR_FAIL(LR_EINVAL, "llama prefill: shared prefix of %d tokens, shortest prompt has %d (every prompt keeps >= 1 own token)",
+            P, minT);
+  if (P > 0 && (c.head_dim != 128 || h->attn_variant == 1)) P = 0;  // only the MFMA attention kernel reads a shared prefix
+  if (B == 1) P = 0;
+  const int n_in = cu_host[B];
+  const int n = P > 0 ? n_in - (B - 1) * P : n_in;  // internal rows
+  const int S = P > 0 ? B + 1 : B;                   // segments
+  LlamaWs ws = carve(c, n_in, B, (char*)workspace);
   if (ws.total > workspace_bytes)
-    LR_FAIL(LR_EWORKSPACE, "llama prefill: workspace needs %zu bytes for %d tokens, have %zu", ws.total, n,
+    LR_FAIL(LR_EWORKSPACE, "llama prefill: workspace needs %zu bytes for %d tokens, have %zu", ws.total, n_in,
             workspace_bytes);
+  // host copy of the segment starts (launch geometry of the attention kernel)
+  std::vector<int32_t> seg_host_v((size_t)S + 1);
+  int32_t* seg_host = seg_host_v.data();
+  if (P > 0) {
+    seg_host[0] = 0;
+    for (int b = 0; b <= B; ++b) seg_host[b + 1] = P + cu_host[b] - b * P;
+  } else {
+    for (int b = 0; b <= B; ++b) seg_host[b] = cu_host[b];
+  }
   const int d = c.hidden_size, f = c.intermediate_size, nh = c.num_heads, nkv = c.num_kv_heads,
             hd = c.head_dim;
   const int qkv_w = (nh + 2 * nkv) * hd;
@@ -134,9 +159,9 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     rc = (x);               \
     if (rc) return rc;      \
   } while (0)
-  RUN(lr_launch_token_meta(cu, B, ws.tok_pos, ws.tok_seq, ws.last_rows, st));
+  RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
-  RUN(lr_launch_embed(ids, h->embed, c.vocab_size, d, ws.x, n, st));
+  RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->layers[l];
     RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
@@ -149,8 +174,8 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       if (hd == 128 && h->attn_variant != 1) {
         // the MFMA kernel over ALL rows (188 us for 14.8 k tokens, 16 us for one prompt) beats the scalar kernel over the
         // B last rows (459 / 295 us): attend everything, keep the last rows
-        RUN(lr_launch_attention(ws.qkv, ws.att, cu, cu_host, ws.tok_pos, ws.tok_seq, B, n, nh, nkv, hd, h->attn_variant,
-                                nullptr, st));
+        RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,
+                                h->attn_variant, nullptr, st, P));
         RUN(lr_launch_gather_rows(ws.att, ws.last_rows, B, nh * hd, ws.att_last, st));
       } else {
         RUN(lr_launch_attention_rows(ws.qkv, ws.att_last, cu, B, ws.last_rows, B, nh, nkv, hd, st));
@@ -169,8 +194,8 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       ws.compact = true;
       break;
     }
-    RUN(lr_launch_attention(ws.qkv, ws.att, cu, cu_host, ws.tok_pos, ws.tok_seq, B, n, nh, nkv, hd,
-                            h->attn_variant, nullptr, st));
+    RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,
+                            h->attn_variant, nullptr, st, P));
     RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0,
                        0, ws.splitk, LR_SPLITK_WS_BYTES));
     RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
@@ -184,29 +209,59 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   return LR_OK;
 }
 
+static int prefill_head(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens, const int32_t* cu_seqlens_host,
+                        int32_t B, int32_t prefix_len, const int32_t* class_ids, int32_t C, float* out, void* workspace,
+                        size_t workspace_bytes, hipStream_t st) {
+  LlamaWs ws;
+  int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, prefix_len, workspace, workspace_bytes, st, &ws);
+  if (rc) return rc;
+  return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : ws.last_rows, h->final_norm, h->lm_head,
+                        class_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out, h->cfg.vocab_size, st);
+}
+
 extern "C" int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
                                           const int32_t* cu_seqlens_host, int32_t B,
                                           const int32_t* label_token_ids, int32_t C, float* out_scores,
                                           void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!label_token_ids || !out_scores || C < 1) LR_FAIL(LR_EINVAL, "lr_llama_prefill_verbalize: bad label ids / output");
-  hipStream_t st = (hipStream_t)hip_stream;
-  LlamaWs ws;
-  int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
-  if (rc) return rc;
-  return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : cu_seqlens, h->final_norm, h->lm_head,
-                        label_token_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out_scores, h->cfg.vocab_size, st);
+  return prefill_head(h, packed_ids, cu_seqlens, cu_seqlens_host, B, 0, label_token_ids, C, out_scores, workspace,
+                      workspace_bytes, (hipStream_t)hip_stream);
+}
+
+extern "C" int lr_llama_prefill_verbalize_prefix(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
+                                                 const int32_t* cu_seqlens_host, int32_t B, int32_t prefix_len,
+                                                 const int32_t* label_token_ids, int32_t C, float* out_scores,
+                                                 void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!label_token_ids || !out_scores || C < 1)
+    LR_FAIL(LR_EINVAL, "lr_llama_prefill_verbalize_prefix: bad label ids / output");
+  return prefill_head(h, packed_ids, cu_seqlens, cu_seqlens_host, B, prefix_len, label_token_ids, C, out_scores, workspace,
+                      workspace_bytes, (hipStream_t)hip_stream);
 }
 
 extern "C" int lr_llama_last_logits(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
                                     const int32_t* cu_seqlens_host, int32_t B, float* out_logits,
                                     void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!out_logits) LR_FAIL(LR_EINVAL, "lr_llama_last_logits: null output");
-  hipStream_t st = (hipStream_t)hip_stream;
-  LlamaWs ws;
-  int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, workspace, workspace_bytes, st, &ws);
-  if (rc) return rc;
-  return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : cu_seqlens, h->final_norm, h->lm_head,
-                        nullptr, B, h->cfg.vocab_size, h->cfg.hidden_size, h->cfg.rms_eps, out_logits, h->cfg.vocab_size, st);
+  return prefill_head(h, packed_ids, cu_seqlens, cu_seqlens_host, B, 0, nullptr, h ? h->cfg.vocab_size : 0, out_logits,
+                      workspace, workspace_bytes, (hipStream_t)hip_stream);
+}
+
+extern "C" int32_t lr_common_prefix_len(const int32_t* packed_ids_host, const int32_t* cu_seqlens_host, int32_t B) {
+  if (!packed_ids_host || !cu_seqlens_host || B < 2) return 0;
+  int n = 0x7fffffff;
+  for (int b = 0; b < B; ++b) {
+    const int t = cu_seqlens_host[b + 1] - cu_seqlens_host[b];
+    if (t - 1 < n) n = t - 1;
+  }
+  if (n <= 0) return 0;
+  const int32_t* head = packed_ids_host + cu_seqlens_host[0];
+  for (int b = 1; b < B && n > 0; ++b) {
+    const int32_t* p = packed_ids_host + cu_seqlens_host[b];
+    int i = 0;
+    while (i < n && p[i] == head[i]) ++i;
+    n = i;
+  }
+  return n;
 }
 
 extern "C" int lr_llama_pack_gate_up(const uint16_t* gate, const uint16_t* up, int32_t inter, int32_t hidden,

@@ -333,9 +333,9 @@ static int forward(lr_llama_lora* h, const int32_t* ids, const int32_t* cu, cons
   const float scaling = h->cfg.alpha / (float)h->cfg.r;
   const int gv = h->base->gemm_variant == 5 ? 0 : h->base->gemm_variant;
   int rc;
-  RUN(lr_launch_token_meta(cu, B, ws.tok_pos, ws.tok_seq, ws.last_rows, st));
+  RUN(lr_launch_token_meta(cu, B, 0, nullptr, ws.tok_pos, nullptr, ws.last_rows, st));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
-  RUN(lr_launch_embed(ids, h->base->embed, c.vocab_size, d, slot(ws, 0).x, n, st));
+  RUN(lr_launch_embed(ids, nullptr, h->base->embed, c.vocab_size, d, slot(ws, 0).x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->base->layers[l];
     const LoraLayerSave s = slot(ws, save ? l : 0);
@@ -464,7 +464,7 @@ extern "C" int lr_llama_lora_prefill_verbalize(lr_llama_lora_t* h, const int32_t
             ws.total, n, workspace_bytes);
   RUN(prep_adapters(h, st));
   RUN(forward(h, packed_ids, cu_seqlens, cu_seqlens_host, B, n, maxT, ws, false, 0.f, st));
-  return lr_launch_head(ws.x_final, cu_seqlens, h->base->final_norm, h->base->lm_head, label_token_ids, B, C,
+  return lr_launch_head(ws.x_final, ws.last_rows, h->base->final_norm, h->base->lm_head, label_token_ids, B, C,
                         c.hidden_size, c.rms_eps, out_scores, c.vocab_size, st);
 }
 

@@ -17,6 +17,10 @@
 //    A workgroup = 4 wave64 = 128 query rows of one (prompt, head); each wave 32 rows, so every K/V
 //    fragment read from LDS feeds two MFMA column tiles. K tile XOR-swizzled by (row&15) for
 //    ds_read_b128; V tile by the dual-use swizzle (row reads + transposed reads).
+//    Shared prompt prefix (prefix_len = P > 0): segment 0 of the packed batch holds the P tokens every prompt
+//    starts with (the template text, dataloader/utils.py:24-40), segment s >= 1 the rest of prompt s-1 at
+//    positions P.. . Such a segment's keys [0, P) are read from segment 0's rows; query tiles and key blocks stay
+//    aligned to ABSOLUTE positions, so every row executes exactly the instruction sequence of the unshared run.
 #include <stdlib.h>
 
 #include "llama_kernels.h"
@@ -151,8 +155,9 @@ __device__ __forceinline__ float fa_sum_xor16_32(float v) {
 #define FA_TILE_BYTES (FA_KB * 256)        // one K or V tile: 64 keys x 128 dims bf16
 #define FA_STAGE_BYTES (2 * FA_TILE_BYTES)  // K tile + V tile
 
-// Diagnostic stamps (STAMP = true only under LR_ATTN_STAMPS=1, never in the product path): s_memtime deltas of
-// the key-block loop's segments summed over the loop, wave 0 of the first 64 workgroups.
+// Diagnostic stamps: STAMP = true is instantiated only in a -DLR_EXPERIMENTS build (make EXPERIMENTS=1, then
+// LR_ATTN_STAMPS=1 at run time; tools/attn_stamps.py); the product library holds no stamping code. s_memtime deltas
+// of the key-block loop's segments summed over the loop, wave 0 of the first 64 workgroups.
 __device__ unsigned long long g_attn_stamps[64 * 8];
 #define FA_STAMP(slot)                                                         \
   if (STAMP) {                                                                 \
@@ -166,7 +171,7 @@ __device__ unsigned long long g_attn_stamps[64 * 8];
 
 template <bool STAMP>
 __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
-                                                              const int32_t* cu, int nh, int nkv,
+                                                              const int32_t* cu, int prefix_len, int nh, int nkv,
                                                               int max_qblocks, float* lse) {
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
@@ -174,18 +179,22 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   // the XOR swizzles are applied to the SOURCE chunk: position p of row r holds chunk p ^ s(r).
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hd = 128;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int seg = blockIdx.z, h = blockIdx.y;
   const int qb = max_qblocks - 1 - (int)blockIdx.x;  // heavy (late) query blocks first
-  const int tok0 = cu[b];
-  const int T = cu[b + 1] - tok0;
-  if (qb * FA_QROWS >= T) return;
+  const int tok0 = cu[seg];
+  const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;  // keys [0, P) live in segment 0's rows [0, P)
+  const int T = P + cu[seg + 1] - tok0;                        // sequence length, prefix included
+  if (qb * FA_QROWS >= T || (qb + 1) * FA_QROWS <= P) return;  // no query row of this segment in the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int quad = lane >> 4, li = lane & 15;
   const int kvh = h / (nh / nkv);
   const int stride = (nh + 2 * nkv) * hd;
-  const u16* kbase = qkv + (size_t)tok0 * stride + (nh + kvh) * hd;
-  const u16* vbase = qkv + (size_t)tok0 * stride + (nh + nkv + kvh) * hd;
+  const int vtok0 = tok0 - P;  // the row of position p >= P is vtok0 + p (tok0 >= P: segment 0 precedes it)
+  const u16* kbase = qkv + (size_t)vtok0 * stride + (nh + kvh) * hd;
+  const u16* vbase = qkv + (size_t)vtok0 * stride + (nh + nkv + kvh) * hd;
+  const u16* pkbase = qkv + (nh + kvh) * hd;        // prefix rows start at packed row 0
+  const u16* pvbase = qkv + (nh + nkv + kvh) * hd;
 
   // ---- Q fragments (B operand of S^T = K Q^T): row q, d = 32*ks + 8*quad + 0..7
   bf16x8 qf[2][4];
@@ -193,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     qabs[qt] = qb * FA_QROWS + wave * 32 + qt * 16 + li;
-    const int qr = min(qabs[qt], T - 1);
-    const u16* qp = qkv + (size_t)(tok0 + qr) * stride + h * hd + quad * 8;
+    const int qr = min(max(qabs[qt], P), T - 1);
+    const u16* qp = qkv + (size_t)(vtok0 + qr) * stride + h * hd + quad * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
   }
@@ -216,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   const int prow = lane >> 4, ppos = lane & 15;
   // per-lane byte offsets of this wave's 4 K pieces and 4 V pieces inside a key block (row and swizzled chunk are
   // block-invariant): a full block then costs one 64-bit add per DMA, and only the sequence's last, ragged block
-  // pays the per-row clamp to T - 1 (a wave-uniform branch: as selects inside one loop hipcc predicates every block)
+  // (per-row clamp to T - 1) and the blocks that hold shared-prefix keys (rows < P come from segment 0) pay per-row
+  // addressing (a wave-uniform branch: as selects inside one loop hipcc predicates every block)
   unsigned koff[4], voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   }
   auto stage = [&](int kb, int buf) {
     char* base = smem + buf * FA_STAGE_BYTES + wave * 4096;
-    if ((kb + 1) * FA_KB <= T) {
+    if ((kb + 1) * FA_KB <= T && kb * FA_KB >= P) {
       const char* kblk = reinterpret_cast<const char*>(kbase) + (size_t)kb * FA_KB * stride * 2;
       const char* vblk = reinterpret_cast<const char*>(vbase) + (size_t)kb * FA_KB * stride * 2;
 #pragma unroll
@@ -241,8 +251,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
         const int key = min(kb * FA_KB + row, T - 1);
         const int kchunk = ppos ^ (row & 15);
         const int vchunk = ppos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        attn_glds16(kbase + (size_t)key * stride + kchunk * 8, base + i * 1024);
-        attn_glds16(vbase + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
+        const u16* kr = key < P ? pkbase : kbase;
+        const u16* vr = key < P ? pvbase : vbase;
+        attn_glds16(kr + (size_t)key * stride + kchunk * 8, base + i * 1024);
+        attn_glds16(vr + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
       }
     }
   };
@@ -263,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     if (kb < kb_last) stage(kb + 1, (kb + 1) & 1);
     FA_STAMP(1)  // DMA issue
 
-    if (kb * FA_KB <= wave_q_last) {  // otherwise every key of the block is masked for this wave
+    if (kb * FA_KB <= wave_q_last && wave_q_last >= P) {  // otherwise every key of the block is masked for this wave
+                                                          // (or all its rows belong to the prefix segment)
       // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
       floatx4 st[2][4];
 #pragma unroll
@@ -379,10 +392,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   for (int qt = 0; qt < 2; ++qt) {
     const float l = fa_sum_xor16_32(l_run[qt]);
     const float inv = 1.0f / l;
-    if (qabs[qt] < T) {
+    if (qabs[qt] < T && qabs[qt] >= P) {
       if (lse && quad == 0)  // natural-log log-sum-exp of the scaled scores, kept for the backward pass
-        lse[(size_t)(tok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
-      u16* op = out + (size_t)(tok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
+        lse[(size_t)(vtok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+      u16* op = out + (size_t)(vtok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         u16x4 o;
@@ -403,222 +416,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   }
 }
 
+#ifdef LR_EXPERIMENTS
 extern "C" int lr_debug_attn_stamps(unsigned long long* out, int n) {
   if (!out || n < 1 || n > 64 * 8) LR_FAIL(LR_EINVAL, "lr_debug_attn_stamps: bad arguments");
   LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), (size_t)n * sizeof(unsigned long long)));
   return LR_OK;
 }
-
-// =============================================================================================
-// MFMA, head_dim 128, register-staged K/V, 8 waves (variant 3)
-// =============================================================================================
-// Same per-wave arithmetic as attn_mfma128_kernel (32 query rows per wave, everything transposed), different
-// data movement: a workgroup is 8 waves = 256 query rows of one (prompt, head), and the next K/V tile is
-// fetched by ordinary global loads into registers right after S = K Q^T has been issued, rides through the
-// softmax and the P V product, and is written to the other LDS buffer (ds_write_b128, swizzles applied on the
-// write side) just before the block's single barrier. The stamps of the LDS-DMA kernel showed ~980 cycles of
-// DMA issue and ~1080 of barrier / DMA wait per 64-key block against ~1450 of MFMA work; here a block costs four
-// loads and four LDS writes per lane, the memory latency hides behind softmax + P V, and twice the query rows
-// share every staged tile.
-#define FB_QROWS 256
-
-__global__ __launch_bounds__(512, 1) void attn_mfma128_rs_kernel(const u16* __restrict__ qkv, u16* out,
-                                                                 const int32_t* cu, int nh, int nkv, int max_qblocks) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K 16 KiB | V 16 KiB]
-  const int hd = 128;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qb = max_qblocks - 1 - (int)blockIdx.x;  // heavy (late) query blocks first
-  const int tok0 = cu[b];
-  const int T = cu[b + 1] - tok0;
-  if (qb * FB_QROWS >= T) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int quad = lane >> 4, li = lane & 15;
-  const int kvh = h / (nh / nkv);
-  const int stride = (nh + 2 * nkv) * hd;
-  const u16* kbase = qkv + (size_t)tok0 * stride + (nh + kvh) * hd;
-  const u16* vbase = qkv + (size_t)tok0 * stride + (nh + nkv + kvh) * hd;
-
-  // ---- Q fragments (B operand of S^T = K Q^T): row q, d = 32*ks + 8*quad + 0..7
-  bf16x8 qf[2][4];
-  int qabs[2];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qabs[qt] = qb * FB_QROWS + wave * 32 + qt * 16 + li;
-    const int qr = min(qabs[qt], T - 1);
-    const u16* qp = qkv + (size_t)(tok0 + qr) * stride + h * hd + quad * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
-  }
-  floatx4 ot[2][8];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
-  float l_run[2] = {0.f, 0.f};
-
-  const int q_last = min(qb * FB_QROWS + FB_QROWS - 1, T - 1);
-  const int kb_last = q_last / FA_KB;
-  const int wave_q_first = qb * FB_QROWS + wave * 32;
-  const int wave_q_last = wave_q_first + 31;
-  const bool wave_live = wave_q_first < T;  // a wave whose rows are all past the prompt only helps with staging
-  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
-
-  // ---- staging: thread -> (row = tid>>4 [+32], 16-byte chunk = tid&15) of the 64 x 256-byte K and V tiles
-  const int srow = tid >> 4, schunk = tid & 15;
-  u16x8 kreg[2], vreg[2];
-  auto fetch = [&](int kb) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = min(kb * FA_KB + srow + 32 * i, T - 1);
-      kreg[i] = *reinterpret_cast<const u16x8*>(kbase + (size_t)key * stride + schunk * 8);
-      vreg[i] = *reinterpret_cast<const u16x8*>(vbase + (size_t)key * stride + schunk * 8);
-    }
-  };
-  auto commit = [&](int buf) {
-    char* Ks = smem + buf * FA_STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow + 32 * i;
-      *reinterpret_cast<u16x8*>(Ks + row * 256 + ((schunk ^ (row & 15)) << 4)) = kreg[i];
-      *reinterpret_cast<u16x8*>(Ks + FA_TILE_BYTES + v_off(row, schunk)) = vreg[i];
-    }
-  };
-  fetch(0);
-  commit(0);
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));  // Q resident before the loop
-  __syncthreads();
-
-  for (int kb = 0; kb <= kb_last; ++kb) {
-    const char* Ks = smem + (kb & 1) * FA_STAGE_BYTES;
-    const char* Vs = Ks + FA_TILE_BYTES;
-    const bool work = wave_live && kb * FA_KB <= wave_q_last;  // otherwise every key of the block is masked for this wave
-    floatx4 st[2][4];
-    if (work) {
-      // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-      bf16x8 kf[2][4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int row = nt * 16 + li;
-        kf[0][nt] = *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((quad ^ (row & 15)) << 4));
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int row = nt * 16 + li;
-            kf[(ks + 1) & 1][nt] =
-                *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((((ks + 1) * 4 + quad) ^ (row & 15)) << 4));
-          }
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
-            st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][nt], qf[qt][ks], st[qt][nt], 0, 0, 0);
-      }
-    }
-    // ---- next tile: global -> registers now, LDS after this block's P V
-    if (kb < kb_last) fetch(kb + 1);
-    if (work) {
-      // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
-      bf16x8 pa[2][2];
-      const bool diag = (kb * FA_KB + FA_KB - 1) > wave_q_first;  // block needs masking
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        float mx = -__builtin_inff();
-        if (diag) {  // a real (wave-uniform) branch: written as a select inside the loop below, hipcc predicates
-                     // all 32 scores of every block -- ~100 wasted VALU instructions on the off-diagonal blocks
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
-              st[qt][nt][r] = (key <= qabs[qt]) ? st[qt][nt][r] : -__builtin_inff();
-            }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][nt][r]);
-        mx = fa_max_xor16_32(mx);
-        const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
-        const bool grew = m_new > m_run[qt];
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-        m_run[qt] = m_new;
-        float ps = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][nt][r], sl2, -m_new));
-            ps += p;
-            pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
-          }
-        l_run[qt] = l_run[qt] * alpha + ps;
-        if (__any(grew)) {
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
-        }
-      }
-      // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
-      const int qp = li >> 2, p4 = li & 3;
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-          const int row0 = ks2 * 32 + quad * 4 + qp;
-          const int ch = dt * 2 + (p4 >> 1);
-          const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0, ch) + 8 * (p4 & 1)));
-          const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0 + 16, ch) + 8 * (p4 & 1)));
-          bf16x8 vf;
-          const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            vf[r] = b0[r];
-            vf[4 + r] = b1[r];
-          }
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
-            ot[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa[qt][ks2], ot[qt][dt], 0, 0, 0);
-        }
-      }
-    }
-    if (kb < kb_last) commit((kb + 1) & 1);  // buffer (kb+1)&1 was last read in block kb-1, before its barrier
-    __syncthreads();
-  }
-
-  // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const float l = fa_sum_xor16_32(l_run[qt]);
-    const float inv = 1.0f / l;
-    if (qabs[qt] < T) {
-      u16* op = out + (size_t)(tok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        u16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(ot[qt][dt][r] * inv);
-        *reinterpret_cast<u16x4*>(op + dt * 16) = o;
-      }
-    }
-  }
-}
+#endif
 
 // attention for a list of query tokens only (the last layer needs just each prompt's last token)
 int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B, const int32_t* q_rows,
@@ -633,59 +437,49 @@ int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B,
 }
 
 // =============================================================================================
+// cu / cu_host: segment starts [S + 1] in packed rows. prefix_len = P > 0: segment 0 is the shared prefix (P rows)
+// and segments 1.. continue it (see the kernel); only the MFMA kernel implements that.
 int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32_t* cu_host,
                         const int32_t* tok_pos, const int32_t* tok_seq, int B, int n_tok, int nh, int nkv,
-                        int hd, int variant, void* scratch, hipStream_t st) {
-  float* lse = (float*)scratch;  // optional [n_tok][nh] log-sum-exp output (variants 1 and 2)
+                        int hd, int variant, void* scratch, hipStream_t st, int prefix_len) {
+  float* lse = (float*)scratch;  // optional [n_tok][nh] log-sum-exp output
   (void)tok_pos;
   (void)tok_seq;
   if (n_tok <= 0 || B <= 0) return LR_OK;
   if (nh % nkv != 0) LR_FAIL(LR_EINVAL, "attention: num_heads %d not a multiple of num_kv_heads %d", nh, nkv);
   if (variant == 0) variant = (hd == 128) ? 2 : 1;
-  double work = 0;  // causal QK^T + PV flops
+  if (prefix_len < 0 || (prefix_len > 0 && (variant != 2 || cu_host[1] - cu_host[0] != prefix_len)))
+    LR_FAIL(LR_EINVAL, "attention: shared prefix of %d tokens needs the head_dim-128 MFMA kernel and segment 0 = the prefix",
+            prefix_len);
+  double work = 0;  // causal QK^T + PV flops of the rows each segment owns
+  int maxT = 0;
   for (int b = 0; b < B; ++b) {
-    double T = cu_host[b + 1] - cu_host[b];
-    work += 4.0 * nh * hd * (T * (T + 1) / 2);
+    const double P = (prefix_len > 0 && b > 0) ? prefix_len : 0;
+    const double T = P + cu_host[b + 1] - cu_host[b];
+    work += 4.0 * nh * hd * (T * (T + 1) / 2 - P * (P + 1) / 2);
+    maxT = max(maxT, (int)T);
   }
   LrProfScope prof(variant >= 2 ? LR_PROF_ATTN_MFMA : LR_PROF_ATTN_GENERIC, work, st);
-  if (variant == 3) {
-    if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 3 needs head_dim 128 (got %d)", hd);
-    if (lse) LR_FAIL(LR_EUNSUPPORTED, "attention variant 3 does not emit the softmax statistics");
-    int maxT = 0;
-    for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
-    const int mq = (maxT + FB_QROWS - 1) / FB_QROWS;
-    if (mq == 0) return LR_OK;
-    static bool attr_set3 = false;
-    if (!attr_set3) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_rs_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
-      attr_set3 = true;
-    }
-    hipLaunchKernelGGL(attn_mfma128_rs_kernel, dim3(mq, nh, B), dim3(512), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh, nkv,
-                       mq);
-    LR_CHECK_LAUNCH("attn_mfma128_rs_kernel");
-  } else if (variant == 2) {
+  if (variant == 2) {
     if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 2 needs head_dim 128 (got %d)", hd);
-    int maxT = 0;
-    for (int b = 0; b < B; ++b) maxT = max(maxT, cu_host[b + 1] - cu_host[b]);
     const int mq = (maxT + FA_QROWS - 1) / FA_QROWS;
     if (mq == 0) return LR_OK;
-    static bool attr_set = false, stamps = false;
-    if (!attr_set) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma128_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE_BYTES));
-      const char* e = getenv("LR_ATTN_STAMPS");
-      stamps = e && e[0] == '1';
-      attr_set = true;
-    }
-    if (stamps)
-      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
-                         nkv, mq, lse);
-    else
-      hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu, nh,
-                         nkv, mq, lse);
+    static bool lds_set[LR_MAX_DEVICES] = {};
+    if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<false>), 2 * FA_STAGE_BYTES, lds_set))
+      return rc;
+#ifdef LR_EXPERIMENTS
+    static bool lds_set_stamp[LR_MAX_DEVICES] = {};
+    const char* stamp_env = getenv("LR_ATTN_STAMPS");
+    if (stamp_env && stamp_env[0] == '1') {
+      if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<true>), 2 * FA_STAGE_BYTES,
+                                         lds_set_stamp))
+        return rc;
+      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
+                         prefix_len, nh, nkv, mq, lse);
+    } else
+#endif
+      hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
+                         prefix_len, nh, nkv, mq, lse);
     LR_CHECK_LAUNCH("attn_mfma128_kernel");
   } else if (variant == 1) {
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
@@ -694,7 +488,7 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
                        n_tok, nh, nkv, hd, (const int32_t*)nullptr, lse);
     LR_CHECK_LAUNCH("attn_generic_kernel");
   } else {
-    LR_FAIL(LR_EINVAL, "attention: unknown variant %d", variant);
+    LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA)", variant);
   }
   return LR_OK;
 }
@@ -703,6 +497,5 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
 int lr_launch_attention_lse(const u16* qkv, u16* out, float* lse, const int32_t* cu, const int32_t* cu_host, int B,
                             int n_tok, int nh, int nkv, int hd, int variant, hipStream_t st) {
   if (!lse) LR_FAIL(LR_EINVAL, "attention (training): null statistics buffer");
-  if (variant == 3) variant = 2;
-  return lr_launch_attention(qkv, out, cu, cu_host, nullptr, nullptr, B, n_tok, nh, nkv, hd, variant, lse, st);
+  return lr_launch_attention(qkv, out, cu, cu_host, nullptr, nullptr, B, n_tok, nh, nkv, hd, variant, lse, st, 0);
 }

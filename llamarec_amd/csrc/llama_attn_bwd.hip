@@ -468,15 +468,12 @@ int lr_launch_attention_bwd(const u16* qkv, const u16* out, const u16* d_out, co
   LrProfScope prof(variant >= 2 ? LR_PROF_ATTN_MFMA : LR_PROF_ATTN_GENERIC, work, st);
   if (variant == 2) {
     if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention backward variant 2 needs head_dim 128 (got %d)", hd);
-    static bool attr_set = false;
+    static bool lds_set_dq[LR_MAX_DEVICES] = {}, lds_set_dkv[LR_MAX_DEVICES] = {};
     const size_t dkv_lds = 2 * AB_STAGE_BYTES + 2 * 128 * sizeof(float);
-    if (!attr_set) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AB_STAGE_BYTES));
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dkv_lds));
-      attr_set = true;
-    }
+    if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel), 2 * AB_STAGE_BYTES, lds_set_dq))
+      return rc;
+    if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), (int)dkv_lds, lds_set_dkv))
+      return rc;
     const int mq = (maxT + AB_QROWS - 1) / AB_QROWS, mk = (maxT + AB_KB - 1) / AB_KB;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(mq, nh, B), dim3(256), 2 * AB_STAGE_BYTES, st, qkv, d_out, lse, dsum,
                        dqkv, cu, nh, nkv, mq, rope_cs);

@@ -24,23 +24,43 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// ---- token positions inside their prompt, and prompt index, for packed layouts ---------------
-__global__ void token_meta_kernel(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq,
-                                  int32_t* last_rows) {
-  int b = blockIdx.x;
-  int s = cu[b], e = cu[b + 1];
-  if (threadIdx.x == 0 && last_rows) last_rows[b] = e - 1;
-  for (int t = s + threadIdx.x; t < e; t += blockDim.x) {
-    tok_pos[t] = t - s;
-    tok_seq[t] = b;
+// ---- packed-layout metadata ---------------------------------------------------------------------
+// Without a shared prefix (P = 0) the internal rows are the caller's packed tokens: segment b = prompt b.
+// With P > 0 (every prompt starts with the same P tokens, run once): S = B + 1 segments,
+//   segment 0      rows [0, P)                                     = the prefix, taken from prompt 0
+//   segment b + 1  rows [P + cu[b] - b P, P + cu[b+1] - (b+1) P)   = prompt b's tokens at positions P..T_b-1
+// tok_pos = position inside the prompt (rotary embedding), tok_src = index into the caller's packed ids,
+// last_rows[b] = internal row of prompt b's last token, seg_start[0..S] = segment starts.
+__global__ void token_meta_kernel(const int32_t* cu, int B, int P, int32_t* seg_start, int32_t* tok_pos,
+                                  int32_t* tok_src, int32_t* last_rows) {
+  const int seg = blockIdx.x;
+  int start, len, pos0, src0;
+  if (P > 0 && seg == 0) {
+    start = 0, len = P, pos0 = 0, src0 = cu[0];
+  } else {
+    const int b = P > 0 ? seg - 1 : seg;
+    const int s = cu[b], e = cu[b + 1];
+    start = P > 0 ? P + s - b * P : s;
+    len = e - s - P;
+    pos0 = P;
+    src0 = s + P;
+    if (threadIdx.x == 0) {
+      if (last_rows) last_rows[b] = start + len - 1;
+      if (seg_start && seg == (int)gridDim.x - 1) seg_start[seg + 1] = start + len;
+    }
+  }
+  if (threadIdx.x == 0 && seg_start) seg_start[seg] = start;
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    tok_pos[start + i] = pos0 + i;
+    if (tok_src) tok_src[start + i] = src0 + i;
   }
 }
 
 // ---- embedding gather ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(const int32_t* ids, const u16* table, int vocab,
-                                                    int d, u16* out) {
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t* ids, const int32_t* tok_src, const u16* table,
+                                                    int vocab, int d, u16* out) {
   const int tok = blockIdx.x;
-  int id = ids[tok];
+  int id = ids[tok_src ? tok_src[tok] : tok];
   if (id < 0 || id >= vocab) id = 0;
   const u16x8* src = reinterpret_cast<const u16x8*>(table + (size_t)id * d);
   u16x8* dst = reinterpret_cast<u16x8*>(out + (size_t)tok * d);
@@ -89,14 +109,14 @@ __global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, flo
 
 // ---- final RMSNorm on each prompt's last token + dot with selected lm_head rows -------------
 // grid (B, ceil(C/32)); out[b][c] = float(bf16(sum_k xn[k] * W[row_c][k])), row_c = ids ? ids[c] : c
-__global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* cu, const u16* norm_w,
+__global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* rows, const u16* norm_w,
                                                    const u16* lm_head, const int32_t* class_ids, int C,
                                                    int d, float eps, float* out, int vocab) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   u16* xn = reinterpret_cast<u16*>(smem_raw);  // [d]
   __shared__ float red[4];
   const int b = blockIdx.x;
-  const int row = cu ? cu[b + 1] - 1 : b;  // cu == nullptr: x is already compact, one row per prompt
+  const int row = rows ? rows[b] : b;  // rows == nullptr: x is already compact, one row per prompt
   const u16* xr = x + (size_t)row * d;
   float ss = 0.f;
   for (int i = threadIdx.x; i < d; i += 256) {
@@ -146,15 +166,18 @@ int lr_launch_gather_rows(const u16* x, const int32_t* rows, int n_rows, int d, 
 }
 
 // ---------------------------------------------------------------------------------------------
-int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, int32_t* last_rows,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(token_meta_kernel, dim3(B), dim3(256), 0, st, cu, B, tok_pos, tok_seq, last_rows);
+int lr_launch_token_meta(const int32_t* cu, int B, int prefix_len, int32_t* seg_start, int32_t* tok_pos,
+                         int32_t* tok_src, int32_t* last_rows, hipStream_t st) {
+  const int S = prefix_len > 0 ? B + 1 : B;
+  hipLaunchKernelGGL(token_meta_kernel, dim3(S), dim3(256), 0, st, cu, B, prefix_len, seg_start, tok_pos, tok_src,
+                     last_rows);
   LR_CHECK_LAUNCH("token_meta_kernel");
   return LR_OK;
 }
 
-int lr_launch_embed(const int32_t* ids, const u16* table, int vocab, int d, u16* out, int n, hipStream_t st) {
-  hipLaunchKernelGGL(embed_kernel, dim3(n), dim3(256), 0, st, ids, table, vocab, d, out);
+int lr_launch_embed(const int32_t* ids, const int32_t* tok_src, const u16* table, int vocab, int d, u16* out, int n,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(embed_kernel, dim3(n), dim3(256), 0, st, ids, tok_src, table, vocab, d, out);
   LR_CHECK_LAUNCH("embed_kernel");
   return LR_OK;
 }
@@ -173,11 +196,11 @@ int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st) 
   return LR_OK;
 }
 
-int lr_launch_head(const u16* x, const int32_t* cu, const u16* norm_w, const u16* lm_head,
+int lr_launch_head(const u16* x, const int32_t* rows, const u16* norm_w, const u16* lm_head,
                    const int32_t* class_ids, int B, int C, int d, float eps, float* out, int vocab,
                    hipStream_t st) {
   dim3 grid(B, (C + 31) / 32);
-  hipLaunchKernelGGL(head_kernel, grid, dim3(256), (size_t)d * sizeof(u16), st, x, cu, norm_w, lm_head,
+  hipLaunchKernelGGL(head_kernel, grid, dim3(256), (size_t)d * sizeof(u16), st, x, rows, norm_w, lm_head,
                      class_ids, C, d, eps, out, vocab);
   LR_CHECK_LAUNCH("head_kernel");
   return LR_OK;

@@ -9,13 +9,13 @@
 // Two kernels:
 //  gemm_generic_kernel : 64x64x32 tile, any M/N/K (bounds-checked) -- tiny test models, odd shapes,
 //                        and the in-library reference for the fast kernel.
-//  gemm256_kernel      : 256x256x64 tile, 8 wave64 (2 x 4), each wave 128x64 = 8x4 MFMA tiles.
+//  gemm256rb_kernel    : 256x256x64 tile, 8 wave64 (2 x 4), each wave 128x64 = 8x4 MFMA tiles.
 //     * both operands stream global -> LDS with global_load_lds_dwordx4 (no VGPR staging): every
 //       wave-instruction moves 8 rows x 128 B = full cache lines; the LDS image is lane-linear
 //       (the DMA's constraint) and the 16-byte chunk a lane FETCHES is XOR-permuted
 //       (chunk ^ ((row>>1)&7)), so the ds_read_b128 fragment reads are bank-conflict free.
-//     * double-buffered K tiles (2 x 64 KiB LDS): the DMA of tile k+1 is in flight while tile k
-//       is multiplied.
+//     * two 64 KiB K-tile stages; a ping-pong schedule between the two wave groups of a workgroup
+//       (described at the kernel) keeps the DMA queue and the matrix pipe busy together.
 //     * MFMA operands are swapped (D = B_frag x A_frag) so each lane ends up with 4 CONSECUTIVE
 //       output columns -> 8-byte epilogue accesses, and gate/up of one SwiGLU output meet in a lane.
 //     * workgroup -> tile map: bijective XCD remap (each XCD's L2 sees a compact set of tiles)
@@ -192,138 +192,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
-                                                      const u16* __restrict__ B, u16* C,
-                                                      const u16* R, int M, int N, int K, RopeArgs rope) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  // ---- workgroup -> output tile
-  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
-  const int nwg = tilesM * tilesN;
-  int id;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int per_group = G2_GROUP_M * tilesN;
-    const int g = id / per_group, rem = id % per_group;
-    const int first_m = g * G2_GROUP_M;
-    const int gsz = min(G2_GROUP_M, tilesM - first_m);
-    tm = first_m + rem % gsz;
-    tn = rem / gsz;
-  }
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  // ---- staging addresses: wave w moves pieces 4w..4w+3 (8 rows x 128 B each) of A and of B
-  const int srow = lane >> 3;  // row inside a piece
-  const int spos = lane & 7;   // 16-byte slot inside the 128-byte LDS row
-  const char* asrc[4];
-  const char* bsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + srow;
-    const int chunk = spos ^ ((row >> 1) & 7);
-    const int arow = min(m0 + row, M - 1);
-    asrc[i] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
-    bsrc[i] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
-  }
-  auto stage = [&](int kt, int buf) {
-    char* lA = smem + buf * G2_STAGE_BYTES + wave * 4096;
-    char* lB = lA + 32768;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(asrc[i] + (size_t)kt * 128, lA + i * 1024);
-      glds16(bsrc[i] + (size_t)kt * 128, lB + i * 1024);
-    }
-  };
-
-  // ---- fragment read offsets: row r of a tile lives at r*128, chunk c at ((c ^ ((r>>1)&7)) * 16)
-  const int frow = lane & 15;
-  const int fsw = frow >> 1;
-  const int foff0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);        // k-step 0: chunk = lane>>4
-  const int foff1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);  // k-step 1: chunk = 4 + lane>>4
-  const int a_base = wm * 128 * 128;
-  const int b_base = 32768 + wn * 64 * 128;
-
-  floatx4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  auto compute = [&](int buf) {
-    const char* base = smem + buf * G2_STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int fo = ks ? foff1 : foff0;
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        bfr[nt] = *reinterpret_cast<const bf16x8*>(base + b_base + nt * 16 * 128 + fo);
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        bf16x8 afr = *reinterpret_cast<const bf16x8*>(base + a_base + mt * 16 * 128 + fo);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], afr, acc[mt][nt], 0, 0, 0);
-      }
-    }
-  };
-
-  const int nkt = K >> 6;
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane holds row m = lane&15 of each m-tile, 4 consecutive columns per n-tile
-  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
-    if (row < M) {
-      if (EPI == LR_EPI_SWIGLU) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col);
-        }
-      }
-    }
-  }
-}
-
-// =============================================================================================
-// 256 x 256 x 64 kernel, ping-pong pipeline (variant 3)
-// =============================================================================================
-// Same tile, LDS image and MFMA mapping as gemm256_kernel, different schedule. The K tile is
-// processed in 4 phases (one 64x32 quadrant of the wave's 128x64 output per phase, 16 MFMAs each):
-//     LOAD_p : ds_read the quadrant's new fragments + issue 2 global->LDS DMAs of the NEXT K tile
-//              + s_waitcnt vmcnt(4)            | s_barrier |
-//     MFMA_p : 16 x v_mfma_f32_16x16x32_bf16   | s_barrier |
-// The two wave groups (wm = 0 / 1; one wave of each per SIMD) run ONE BARRIER APART, so on every
-// SIMD one wave's MFMA segment overlaps the other wave's LOAD segment and the matrix pipe never
-// waits for LDS or DMA issue. DMAs are issued in the order their data is consumed next tile
-// (S0: phase-0 rows, 4 pieces; S1: phase-1 rows, 2; S2: phase-2 rows, 2), two per phase, and a
-// reader only needs "all but my newest 4" complete -- the DMA queue is never drained in the loop.
-// RAW: every wave's wait precedes a barrier that the reading wave passes before its LOAD_p;
-// WAR: a buffer region is overwritten a full K tile after its last read.
 #define PP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define PP_BARRIER()                        \
   do {                                      \
@@ -332,230 +200,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const u16* __restrict__ A,
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
 
-// Diagnostic stamps (STAMP = true, variant 9 only, never in the product path): per phase the
-// s_memtime deltas of [LOAD + DMA issue + vmcnt wait], [wait at barrier A], [MFMA issue],
-// [wait at barrier B], summed over the K loop, for waves 0 and 4 of the first 8 workgroups.
-__device__ unsigned long long g_gemm_stamps[8 * 2 * 24];
-
-#define PP_STAMP(slot)                                                                         \
-  if (STAMP) {                                                                                 \
-    unsigned long long t_;                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    stamp_acc[(slot)] += t_ - t_prev;                                                          \
-    t_prev = t_;                                                                               \
-  }
-
-template <int EPI, bool STAMP = false>
-__global__ __launch_bounds__(512) void gemm256pp_kernel(const u16* __restrict__ A,
-                                                        const u16* __restrict__ B, u16* C,
-                                                        const u16* R, int M, int N, int K, int group_m,
-                                                        RopeArgs rope) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tilesM = (M + 255) >> 8, tilesN = N >> 8;
-  const int nwg = tilesM * tilesN;
-  int id;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
-    const int per_group = group_m * tilesN;
-    const int g = id / per_group, rem = id % per_group;
-    const int first_m = g * group_m;
-    const int gsz = min(group_m, tilesM - first_m);
-    tm = first_m + rem % gsz;
-    tn = rem / gsz;
-  }
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  // ---- DMA pieces of this wave (8 rows x 128 B each), in issue order
-  //  j = 0,1: q = 2*wave + j in 0..15
-  //  S0A rows (q>>3)*128 + (q&7)*8         S0B rows (q>>2)*64 + (q&3)*8        (phase 0)
-  //  S1B rows (q>>2)*64 + 32 + (q&3)*8                                         (phase 1)
-  //  S2A rows (q>>3)*128 + 64 + (q&7)*8                                        (phase 2)
-  const int srow = lane >> 3, spos = lane & 7;
-  const char* src[8];
-  int ldsoff[8];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = 2 * wave + j;
-    const int r_s0a = (q >> 3) * 128 + (q & 7) * 8;
-    const int r_s0b = (q >> 2) * 64 + (q & 3) * 8;
-    const int rows[4] = {r_s0a, r_s0b, r_s0b + 32, r_s0a + 64};
-    const bool isA[4] = {true, false, false, true};
-    // issue order: phase0: S0A#0,S0B#0  phase1: S0A#1,S0B#1  phase2: S1B#0,S1B#1  phase3: S2A#0,S2A#1
-    const int slot[4] = {j * 2 + 0, j * 2 + 1, 4 + j, 6 + j};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = rows[t] + srow;
-      const int chunk = spos ^ ((row >> 1) & 7);
-      if (isA[t]) {
-        const int arow = min(m0 + row, M - 1);
-        src[slot[t]] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16;
-        ldsoff[slot[t]] = rows[t] * 128;
-      } else {
-        src[slot[t]] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
-        ldsoff[slot[t]] = 32768 + rows[t] * 128;
-      }
-    }
-  }
-
-  const int frow = lane & 15;
-  const int fsw = frow >> 1;
-  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
-  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
-  const int a_base = wm * 128 * 128;
-  const int b_base = 32768 + wn * 64 * 128;
-
-  floatx4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K >> 6;
-  // prologue: whole tile 0
-#pragma unroll
-  for (int i = 0; i < 8; ++i) glds16(src[i], smem + ldsoff[i]);
-  PP_WAIT_VM(0);
-  PP_BARRIER();
-  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
-
-  bf16x8 afr[8], b0[4], b1[4];
-  unsigned long long stamp_acc[24];
-  unsigned long long t_prev = 0;
-  if (STAMP) {
-#pragma unroll
-    for (int i = 0; i < 24; ++i) stamp_acc[i] = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-  }
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = smem + (kt & 1) * G2_STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * G2_STAGE_BYTES;
-    const bool more = kt + 1 < nkt;
-    const size_t koff = (size_t)(kt + 1) * 128;
-
-#define PP_LOAD_A(mh)                                                                                 \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                  \
-    afr[mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo0);       \
-    afr[4 + mt] = *reinterpret_cast<const bf16x8*>(cur + a_base + ((mh)*64 + mt * 16) * 128 + fo1);   \
-  }
-#define PP_LOAD_B(dst, nh)                                                                            \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                  \
-    dst[nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo0);       \
-    dst[2 + nt] = *reinterpret_cast<const bf16x8*>(cur + b_base + ((nh)*32 + nt * 16) * 128 + fo1);   \
-  }
-#define PP_STAGE(i0)                                          \
-  PP_STAMP(((i0) / 2) * 6 + 0) /* fragment reads landed */    \
-  if (more) {                                                 \
-    glds16(src[(i0)] + koff, nxt + ldsoff[(i0)]);             \
-    glds16(src[(i0) + 1] + koff, nxt + ldsoff[(i0) + 1]);     \
-    PP_STAMP(((i0) / 2) * 6 + 1) /* DMAs issued */            \
-    PP_WAIT_VM(4);                                            \
-  } else {                                                    \
-    PP_WAIT_VM(0);                                            \
-  }
-#define PP_MFMA(bfrag, mh, nh)                                                                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
-  __builtin_amdgcn_sched_barrier(0);                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                      \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
-    acc[(mh)*4 + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);                \
-  __builtin_amdgcn_s_setprio(0);
-
-    // ---- phase 0: quadrant (0,0)
-    PP_LOAD_A(0)
-    PP_LOAD_B(b0, 0)
-    PP_STAGE(0)
-    PP_STAMP(2)
-    PP_BARRIER();
-    PP_STAMP(3)
-    PP_MFMA(b0, 0, 0)
-    PP_STAMP(4)
-    PP_BARRIER();
-    PP_STAMP(5)
-    // ---- phase 1: quadrant (0,1)
-    PP_LOAD_B(b1, 1)
-    PP_STAGE(2)
-    PP_STAMP(8)
-    PP_BARRIER();
-    PP_STAMP(9)
-    PP_MFMA(b1, 0, 1)
-    PP_STAMP(10)
-    PP_BARRIER();
-    PP_STAMP(11)
-    // ---- phase 2: quadrant (1,1)
-    PP_LOAD_A(1)
-    PP_STAGE(4)
-    PP_STAMP(14)
-    PP_BARRIER();
-    PP_STAMP(15)
-    PP_MFMA(b1, 1, 1)
-    PP_STAMP(16)
-    PP_BARRIER();
-    PP_STAMP(17)
-    // ---- phase 3: quadrant (1,0)
-    PP_STAGE(6)
-    PP_STAMP(20)
-    PP_BARRIER();
-    PP_STAMP(21)
-    PP_MFMA(b0, 1, 0)
-    PP_STAMP(22)
-    PP_BARRIER();
-    PP_STAMP(23)
-#undef PP_LOAD_A
-#undef PP_LOAD_B
-#undef PP_STAGE
-#undef PP_MFMA
-  }
-  if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
-  if (STAMP) {
-    if (blockIdx.x < 8 && (wave == 0 || wave == 4) && lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 24; ++i) g_gemm_stamps[(blockIdx.x * 2 + (wave >> 2)) * 24 + i] = stamp_acc[i];
-    }
-  }
-
-  const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
-    if (row < M) {
-      if (EPI == LR_EPI_SWIGLU) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col);
-        }
-      }
-    }
-  }
-}
-
 // =============================================================================================
 // 256 x 256 x 64 kernel, ping-pong pipeline, balanced fragment reads + region-recycling DMA (variant 4)
 // =============================================================================================
-// Measured on variant 3 with s_memtime stamps (tools/gemm_stamps.py): every LOAD segment is longer
-// than the partner's 16-MFMA segment -- LOAD_0 lands 12 ds_read_b128 (~380 cycles), a pair of DMAs
-// takes ~190 cycles to issue, and the vmcnt wait of LOAD_3 stalls ~250 cycles on DMA latency
-// (issue -> landed ~ 1 us). This variant
+// The K tile is processed in 4 phases (one 64x32 quadrant of the wave's 128x64 output per phase, 16 MFMAs each):
+//     LOAD_p : ds_read the quadrant's new fragments + issue 2 global->LDS DMAs + counted s_waitcnt | s_barrier |
+//     MFMA_p : 16 x v_mfma_f32_16x16x32_bf16                                                       | s_barrier |
+// The two wave groups (wm = 0 / 1; one wave of each per SIMD) run ONE BARRIER APART, so on every SIMD one wave's
+// MFMA segment overlaps the other wave's LOAD segment. s_memtime stamps on the first ping-pong version (DESIGN.md
+// section 4, experiment log) showed every LOAD segment longer than the partner's 16-MFMA segment -- 12 ds_read_b128
+// land in ~380 cycles, a pair of DMAs takes ~190 cycles to issue, DMA issue -> landed ~ 1 us. Hence this schedule
 //  * reads (8,4,8,4) fragments per phase instead of (12,4,8,0): the next tile's B(nh0) fragments are
 //    read in LOAD_3 of the current tile into a second register set (tiles alternate b0x / b0y);
 //  * recycles each LDS region two phases after its last read, so every DMA is issued SIX phases
@@ -808,15 +462,16 @@ static int splitk_factor(int M, int N, int K) {
 }
 
 template <int EPI>
+static int gemm256_prepare() {
+  static bool done[LR_MAX_DEVICES] = {};
+  return lr_ensure_dynamic_lds(reinterpret_cast<const void*>(gemm256rb_kernel<EPI>), 2 * G2_STAGE_BYTES, done);
+}
+
+template <int EPI>
 static int launch_splitk(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int S, RopeArgs rope,
                          float* ws, hipStream_t st) {
   LrProfScope prof(LR_PROF_GEMM256, 2.0 * M * (double)N * K, st);
-  static bool attr_set = false;
-  if (!attr_set) {
-    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256rb_kernel<LR_EPI_PARTIAL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-    attr_set = true;
-  }
+  if (int rc = gemm256_prepare<LR_EPI_PARTIAL>()) return rc;
   const int nwg = ((M + 255) / 256) * (N / 256);
   hipLaunchKernelGGL(gemm256rb_kernel<LR_EPI_PARTIAL>, dim3(nwg, S), dim3(512), 2 * G2_STAGE_BYTES, st, A, B,
                      reinterpret_cast<u16*>(ws), nullptr, M, N, K, G2_GROUP_M, rope);
@@ -833,48 +488,12 @@ template <int EPI>
 static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
                       RopeArgs rope, hipStream_t st) {
   LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
-  const int nwg = ((M + 255) / 256) * (N / 256);
   if (variant == 4) {
-    static bool attr_set4 = false;
-    if (!attr_set4) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256rb_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-      attr_set4 = true;
-    }
+    if (int rc = gemm256_prepare<EPI>()) return rc;
+    const int nwg = ((M + 255) / 256) * (N / 256);
     hipLaunchKernelGGL(gemm256rb_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
                        G2_GROUP_M, rope);
     LR_CHECK_LAUNCH("gemm256rb_kernel");
-  } else if (variant == 9) {  // diagnostic stamps (timing perturbed by the stamps themselves; read shares, not totals)
-    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-    hipLaunchKernelGGL((gemm256pp_kernel<EPI, true>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N,
-                       K, G2_GROUP_M, rope);
-    LR_CHECK_LAUNCH("gemm256pp_kernel<stamp>");
-  } else if (variant == 3) {
-    static bool attr_set3 = false;
-    if (!attr_set3) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-      attr_set3 = true;
-    }
-    static int group_m = 0;
-    if (group_m == 0) {
-      const char* e = getenv("LR_GEMM_GROUP_M");  // tuning knob (tile raster), default 8
-      group_m = e ? atoi(e) : G2_GROUP_M;
-      if (group_m < 1) group_m = G2_GROUP_M;
-    }
-    hipLaunchKernelGGL(gemm256pp_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
-                       group_m, rope);
-    LR_CHECK_LAUNCH("gemm256pp_kernel");
-  } else if (variant == 2) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE_BYTES));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K, rope);
-    LR_CHECK_LAUNCH("gemm256_kernel");
   } else {
     dim3 grid((N + GG_BN - 1) / GG_BN, (M + GG_BM - 1) / GG_BM);
     hipLaunchKernelGGL(gemm_generic_kernel<EPI>, grid, dim3(256), 0, st, A, B, C, R, M, N, K, rope);
@@ -891,11 +510,12 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
   if (variant == 0) variant = (fast_ok && M >= 128) ? 4 : 1;
   if (variant == 5 && !fast_ok) variant = 1;  // latency mode: any row count (B last-token rows too), shapes as auto
-  if (variant >= 2 && !fast_ok)
-    LR_FAIL(LR_EUNSUPPORTED, "gemm variants 2..5 need N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
+  if (variant != 1 && variant != 4 && variant != 5)
+    LR_FAIL(LR_EINVAL, "gemm: unknown variant %d (0 auto, 1 generic, 4 = 256x256x64 MFMA tile, 5 = 4 + split-K)", variant);
+  if (variant == 4 && !fast_ok)
+    LR_FAIL(LR_EUNSUPPORTED, "gemm variant 4 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  if ((variant < 1 || variant > 5) && variant != 9) LR_FAIL(LR_EINVAL, "gemm: unknown variant %d", variant);
   RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols};
   if (epi == LR_EPI_ROPE) {
     if (!tok_pos || !rope_cs || head_dim < 2 || head_dim % 4 != 0 || rot_cols % 4 != 0 || rot_cols > N)
@@ -924,11 +544,4 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
     case LR_EPI_ROPE: return launch_epi<LR_EPI_ROPE>(A, B, C, R, M, N, K, variant, rope, st);
   }
   LR_FAIL(LR_EINVAL, "gemm: unknown epilogue %d", epi);
-}
-
-// debug: copy the stamp sums of the last variant-9 launch to the host (16 per (workgroup, group))
-extern "C" int lr_debug_gemm_stamps(unsigned long long* out, int n) {
-  if (!out || n < 1 || n > 8 * 2 * 24) LR_FAIL(LR_EINVAL, "lr_debug_gemm_stamps: bad arguments");
-  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), (size_t)n * sizeof(unsigned long long)));
-  return LR_OK;
 }

@@ -26,22 +26,26 @@ __device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
 #define LR_EPI_PARTIAL 4   // internal (split-K): fp32 partial sums to the workspace, real epilogue in the reduce pass
 #define LR_SPLITK_WS_BYTES ((size_t)64 << 20)  // splits x tiles <= 256 tiles of 256 x 256 fp32
 
-int lr_launch_token_meta(const int32_t* cu, int B, int32_t* tok_pos, int32_t* tok_seq, int32_t* last_rows,
-                         hipStream_t st);
+// packed-layout metadata (llama_elem.hip): prefix_len = P > 0 lays the batch out as [P shared prefix rows][rest of
+// prompt 0]...[rest of prompt B-1]; seg_start (optional) receives the B + 1 (P = 0: B) + 1 segment starts, tok_src
+// (optional) the index of every internal row in the caller's packed ids, last_rows (optional) each prompt's last row
+int lr_launch_token_meta(const int32_t* cu, int B, int prefix_len, int32_t* seg_start, int32_t* tok_pos,
+                         int32_t* tok_src, int32_t* last_rows, hipStream_t st);
 int lr_launch_gather_rows(const unsigned short* x, const int32_t* rows, int n_rows, int d, unsigned short* out,
                           hipStream_t st);
 int lr_launch_attention_rows(const unsigned short* qkv, unsigned short* out, const int32_t* cu, int B,
                              const int32_t* q_rows, int n_rows, int nh, int nkv, int hd, hipStream_t st);
-int lr_launch_embed(const int32_t* ids, const unsigned short* table, int vocab, int d, unsigned short* out,
-                    int n, hipStream_t st);
+int lr_launch_embed(const int32_t* ids, const int32_t* tok_src /*nullptr: identity*/, const unsigned short* table,
+                    int vocab, int d, unsigned short* out, int n, hipStream_t st);
 int lr_launch_rmsnorm(const unsigned short* x, const unsigned short* w, unsigned short* out, int rows, int d,
                       float eps, const int32_t* row_map, hipStream_t st);
 int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st);
-int lr_launch_head(const unsigned short* x, const int32_t* cu, const unsigned short* norm_w,
+int lr_launch_head(const unsigned short* x, const int32_t* rows /*[B]; nullptr: x holds one row per prompt*/,
+                   const unsigned short* norm_w,
                    const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
                    float* out, int vocab, hipStream_t st);
 
-// C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 2..4 256x256x64 MFMA tile,
+// C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 4 = 256x256x64 MFMA tile,
 // 5 = variant 4 with split-K when the tiles alone would leave most CUs idle (needs splitk_ws).
 int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned short* C,
                    const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st,
@@ -49,8 +53,10 @@ int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned sh
                    int rot_cols = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
 
 // varlen causal attention over packed qkv (RoPE applied). variant: 0 auto, 1 generic, 2 MFMA hd=128.
+// cu / cu_host = segment starts; prefix_len > 0: segment 0 is the prefix the other segments continue (MFMA kernel only)
 int lr_launch_attention(const unsigned short* qkv, unsigned short* out, const int32_t* cu,
                         const int32_t* cu_host, const int32_t* tok_pos, const int32_t* tok_seq, int B,
-                        int n_tok, int nh, int nkv, int hd, int variant, void* scratch, hipStream_t st);
+                        int n_tok, int nh, int nkv, int hd, int variant, void* scratch, hipStream_t st,
+                        int prefix_len = 0);
 
 #endif

@@ -29,6 +29,20 @@ void lr_set_error(const char* fmt, ...);
 
 static inline size_t lr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a launcher keeps one `done`
+// array per kernel and calls this before every launch (one hipGetDevice on the fast path). A racing first call from
+// two host threads sets the attribute twice, which is harmless.
+#define LR_MAX_DEVICES 64
+static inline int lr_ensure_dynamic_lds(const void* kernel, int bytes, bool* done /*[LR_MAX_DEVICES]*/) {
+  int dev = 0;
+  LR_CHECK_HIP(hipGetDevice(&dev));
+  const bool tracked = dev >= 0 && dev < LR_MAX_DEVICES;
+  if (tracked && done[dev]) return LR_OK;
+  LR_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (tracked) done[dev] = true;
+  return LR_OK;
+}
+
 // ---- packed LRURec device image (all float32; offsets in floats) ----------------------------
 // Produced by lr_lru_pack() on the host, consumed by the kernels in lru_encoder.hip / lru_topk.hip.
 #define LR_ITEM_TILE 32  // items per MFMA tile; the table is zero-padded to a multiple of this
@@ -127,7 +141,7 @@ struct lr_llama {
   const uint16_t* lm_head;
   LrLlamaLayerWeights* layers;  // host array
   int device;
-  int gemm_variant;  // 0 auto, 1 generic, 2 256x256x64 (falls back to generic per shape when 0)
+  int gemm_variant;  // 0 auto, 1 generic, 4 256x256x64 MFMA tile, 5 = 4 + split-K (latency mode)
   int attn_variant;  // 0 auto, 1 generic, 2 MFMA head_dim 128
   int prune_last;    // last layer: attention output / o_proj / MLP only for each prompt's last token
 };

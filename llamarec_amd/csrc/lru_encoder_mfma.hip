@@ -389,13 +389,9 @@ int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L,
   float* U = (float*)take(rows_cap * 256 * sizeof(float));
   float* Yl = (float*)take(users_cap * 64 * sizeof(float));
   float* Al = (float*)take(users_cap * 256 * sizeof(float));
-  static bool attr_set = false;
+  static bool lds_set[LR_MAX_DEVICES] = {};
   const size_t lds256 = (size_t)(64 * EM_WS + 4 * EM_TILE * EM_XS) * sizeof(float);
-  if (!attr_set) {
-    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(em_proj256_ln_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
-    attr_set = true;
-  }
+  if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(em_proj256_ln_kernel), (int)lds256, lds_set)) return rc;
   LrProfScope prof(LR_PROF_LRU_ENCODE, (double)B, st);
   const int nb = lay.num_blocks;
   for (size_t u0 = 0; u0 < (size_t)B; u0 += cu) {

@@ -139,7 +139,8 @@ __device__ __forceinline__ void sort_small(unsigned long long* b, int c, int lan
 // Table tiles are staged global -> VGPR -> LDS (an LDS-DMA ring was tried, but with ds_write / LDS
 // atomics in the same loop hipcc drains vmcnt(0) in front of every fragment read).
 
-// Diagnostic stamps (STAMP = true only under LR_TOPK_STAMPS=1, never in the product path): s_memtime
+// Diagnostic stamps: STAMP = true is instantiated only in a -DLR_EXPERIMENTS build (make EXPERIMENTS=1, then
+// LR_TOPK_STAMPS=1 at run time; tools/topk_stamps.py); the product library holds no stamping code. s_memtime
 // deltas of the tile loop's segments, summed over the loop, for wave 0 of the first 16 workgroups.
 __device__ unsigned long long g_topk_stamps[16 * 8];
 #define TK_STAMP(slot)                                                         \
@@ -428,11 +429,13 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
   }
 }
 
+#ifdef LR_EXPERIMENTS
 extern "C" int lr_debug_topk_stamps(unsigned long long* out, int n) {
   if (!out || n < 1 || n > 16 * 8) LR_FAIL(LR_EINVAL, "lr_debug_topk_stamps: bad arguments");
   LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_topk_stamps), (size_t)n * sizeof(unsigned long long)));
   return LR_OK;
 }
+#endif
 
 // ---- merge: one wave per user, K rounds of "largest head wins" over <= 256 sorted lists -----
 struct MergeParams {
@@ -662,20 +665,18 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
   }
   const size_t lds = (2 * 32 * TK_ESTRIDE + 128) * sizeof(float) +
                      (size_t)TK_USERS * TK_BSTRIDE * 8;
-  static bool attr_set = false;
-  static bool stamps = false;
-  if (!attr_set) {
-    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(item_topk_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(item_topk_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const char* e = getenv("LR_TOPK_STAMPS");
-    stamps = e && e[0] == '1';
-    attr_set = true;
-  }
+  static bool lds_set[LR_MAX_DEVICES] = {};
+  if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(item_topk_kernel<false>), (int)lds, lds_set)) return rc;
   dim3 grid(p.n_chunks, (B + TK_USERS - 1) / TK_USERS);
-  if (stamps) hipLaunchKernelGGL(item_topk_kernel<true>, grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(item_topk_kernel<false>, grid, dim3(256), lds, st, p);
+#ifdef LR_EXPERIMENTS
+  static bool lds_set_stamp[LR_MAX_DEVICES] = {};
+  const char* stamp_env = getenv("LR_TOPK_STAMPS");
+  if (stamp_env && stamp_env[0] == '1') {
+    if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(item_topk_kernel<true>), (int)lds, lds_set_stamp)) return rc;
+    hipLaunchKernelGGL(item_topk_kernel<true>, grid, dim3(256), lds, st, p);
+  } else
+#endif
+    hipLaunchKernelGGL(item_topk_kernel<false>, grid, dim3(256), lds, st, p);
   LR_CHECK_LAUNCH("item_topk_kernel");
 
   MergeParams m;

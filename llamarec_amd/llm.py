@@ -50,6 +50,26 @@ def pack_prompts(seqs) -> tuple[np.ndarray, np.ndarray]:
     return ids, cu
 
 
+def common_prefix_len(ids: np.ndarray, cu: np.ndarray) -> int:
+    """Length of the longest token prefix shared by ALL prompts of a packed batch, capped at min(T) - 1 so every prompt
+    keeps at least one token of its own (0 for a single prompt: nothing to share)."""
+    B = len(cu) - 1
+    if B < 2:
+        return 0
+    lens = np.diff(cu)
+    n = int(lens.min()) - 1
+    if n <= 0:
+        return 0
+    head = ids[cu[0]: cu[0] + n]
+    for b in range(1, B):
+        neq = np.nonzero(ids[cu[b]: cu[b] + n] != head[:n])[0]
+        if neq.size:
+            n = int(neq[0])
+            if n == 0:
+                return 0
+    return n
+
+
 def unpad_left(input_ids, attention_mask=None):
     """Left-padded [B,T] batch (trainer/llm.py:34-37 pads ids with 0, mask with 0) -> list of
     per-prompt id arrays."""
@@ -267,23 +287,29 @@ class LlamaRanker:
         ids, cu = pack_prompts(seqs)
         return (torch.from_numpy(ids).to(self.device), torch.from_numpy(cu).to(self.device), cu)
 
-    def prefill_verbalize_packed(self, ids_dev, cu_dev, cu_host, label_ids_dev, out=None):
-        """Device-resident inputs (the benchmark's timed region starts here)."""
+    def prefill_verbalize_packed(self, ids_dev, cu_dev, cu_host, label_ids_dev, out=None, prefix_len=0):
+        """Device-resident inputs (the benchmark's timed region starts here). prefix_len > 0: the caller has checked
+        (common_prefix_len on the host ids) that all prompts start with the same prefix_len tokens; they are then run
+        once per batch (bit-identical scores, lr_llama_prefill_verbalize_prefix)."""
         B, Cn = len(cu_host) - 1, label_ids_dev.numel()
         if out is None:
             out = torch.empty((B, Cn), dtype=torch.float32, device=self.device)
         ws = self._workspace(int(cu_host[-1]), B)
         with torch.cuda.device(self.device):
-            check(lib().lr_llama_prefill_verbalize(
-                self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), cu_host.ctypes.data, B, label_ids_dev.data_ptr(),
-                Cn, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()), "lr_llama_prefill_verbalize")
+            check(lib().lr_llama_prefill_verbalize_prefix(
+                self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), cu_host.ctypes.data, B, int(prefix_len),
+                label_ids_dev.data_ptr(), Cn, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+                "lr_llama_prefill_verbalize_prefix")
         return out
 
-    def prefill_verbalize(self, seqs, label_token_ids):
-        """scores[b, c] = logit of label word c at the last token of prompt b (fp32 [B, C])."""
-        ids, cu, cu_host = self._packed(seqs)
+    def prefill_verbalize(self, seqs, label_token_ids, share_prefix=True):
+        """scores[b, c] = logit of label word c at the last token of prompt b (fp32 [B, C]). The prompts' common
+        prefix (the template text) is evaluated once unless share_prefix is False."""
+        ids_host, cu_host = pack_prompts(seqs)
+        P = common_prefix_len(ids_host, cu_host) if share_prefix else 0
         lab = torch.as_tensor(np.asarray(label_token_ids, dtype=np.int32)).to(self.device)
-        return self.prefill_verbalize_packed(ids, cu, cu_host, lab)
+        return self.prefill_verbalize_packed(torch.from_numpy(ids_host).to(self.device),
+                                             torch.from_numpy(cu_host).to(self.device), cu_host, lab, prefix_len=P)
 
     def last_logits(self, seqs):
         ids, cu, cu_host = self._packed(seqs)

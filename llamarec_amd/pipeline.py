@@ -22,8 +22,9 @@ NUM_CAND = 20     # llm_negative_sample_size + 1
 
 
 class TwoStagePipeline:
-    def __init__(self, retriever, ranker, label_token_ids, device="cuda:0"):
+    def __init__(self, retriever, ranker, label_token_ids, device="cuda:0", shared_prefix=True):
         self.retriever, self.ranker = retriever, ranker
+        self.shared_prefix = shared_prefix   # run the prompts' common template prefix once per step (exact)
         self.device = torch.device(device)
         self.label_ids = torch.as_tensor(np.asarray(label_token_ids, dtype=np.int32)).to(self.device)
         assert self.label_ids.numel() == NUM_CAND
@@ -36,13 +37,15 @@ class TwoStagePipeline:
         self.hist_rerank.zero_()
         self.users = 0
 
-    def step(self, hist_ids, labels, prompt_ids, cu_dev, cu_host):
-        """hist_ids int64 [B,L] (device), labels int64 [B] (device), prompts packed (device + host cu).
+    def step(self, hist_ids, labels, prompt_ids, cu_dev, cu_host, prefix_len=0):
+        """hist_ids int64 [B,L] (device), labels int64 [B] (device), prompts packed (device + host cu);
+        prefix_len = llm.common_prefix_len of the packed prompts (0: nothing shared / not computed).
         Returns (top50 item ids, reranked top-20 item ids)."""
         top, _ = self.retriever.retrieve_topk(hist_ids, RETRIEVE_K, exclude_history=True)
         M.rank_histogram(top, labels, self.hist_retrieve)
         cands = top[:, :NUM_CAND].contiguous()
-        scores = self.ranker.prefill_verbalize_packed(prompt_ids, cu_dev, cu_host, self.label_ids)
+        scores = self.ranker.prefill_verbalize_packed(prompt_ids, cu_dev, cu_host, self.label_ids,
+                                                      prefix_len=prefix_len if self.shared_prefix else 0)
         reranked = M.rank_classes(scores, cands)
         M.rank_histogram(reranked, labels, self.hist_rerank)
         self.users += hist_ids.shape[0]

@@ -329,6 +329,12 @@ class LoraRankerTrainer:
         self.micro = args.lora_micro_batch_size
         self.accum = max(1, args.train_batch_size // args.lora_micro_batch_size)
         per_step = self.micro * self.accum * world
+        if len(train_samples) < per_step:
+            # HF's dataloader would yield one short batch; this trainer only takes whole optimizer steps, and train()
+            # would otherwise spin over empty epochs forever
+            raise ValueError(f"{len(train_samples)} training samples are fewer than one optimizer step "
+                             f"(micro batch {self.micro} x accumulation {self.accum} x world {world} = {per_step}): "
+                             f"lower --train_batch_size / --lora_micro_batch_size or the number of ranks")
         steps_per_epoch = max(1, len(train_samples) // per_step)
         self.total_steps = args.lora_max_steps if args.lora_max_steps and args.lora_max_steps > 0 \
             else steps_per_epoch * args.lora_num_epochs

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import metrics as M
+from . import packing as PK
 from . import prompt as P
 
 RERANK_METRIC_KS = [1, 5, 10]  # config.py:140-143
@@ -36,11 +37,15 @@ class LLMEvaluator:
     """test_items: list of dicts {"input_ids", "attention_mask", "labels"} as produced by
     prompt.seq_to_token_ids (== LLMTestDataset.__getitem__, dataloader/llm.py:368-387)."""
 
-    def __init__(self, args, model, test_items, verbalizer, export_root=None, batch_size=None):
+    def __init__(self, args, model, test_items, verbalizer, export_root=None, batch_size=None, token_budget="auto"):
+        """batch_size: the reference's prompts-per-batch cap (config.py:98); token_budget: prompt tokens per prefill
+        ("auto" = packing.TOKEN_BUDGET, None = plain fixed-size batches in dataset order like the reference's loader).
+        Scores do not depend on the batching (unpadded execution), so this only changes speed."""
         self.args, self.model, self.items, self.verbalizer = args, model, test_items, verbalizer
         self.export_root = export_root
         self.ks = list(getattr(args, "rerank_metric_ks", RERANK_METRIC_KS))
         self.batch_size = batch_size or getattr(args, "test_batch_size", 16)
+        self.token_budget = PK.TOKEN_BUDGET if token_budget == "auto" else token_budget
         self.max_text_len = getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN)
 
     def predict(self):
@@ -55,10 +60,16 @@ class LLMEvaluator:
         rank, world, _ = D.env_world()
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             rank, world = 0, 1
-        lo, hi = D.shard_range(len(self.items), rank, world)
+        # contiguous shards balanced by prompt TOKENS, then token-budget batches inside the shard
+        lens = np.array([min(len(it["input_ids"]), self.max_text_len) for it in self.items], dtype=np.int64)
+        lo, hi = PK.shard_by_tokens(lens, world)[rank]
         mine = self.items[lo:hi]
-        for i in range(0, len(mine), self.batch_size):
-            seqs, labels = P.eval_pack(mine[i:i + self.batch_size], self.max_text_len)
+        if self.token_budget:
+            batches = PK.token_budget_steps(lens[lo:hi], max(self.token_budget, int(lens.max()) if len(lens) else 1))
+        else:
+            batches = [np.arange(i, min(i + self.batch_size, len(mine))) for i in range(0, len(mine), self.batch_size)]
+        for idx in batches:
+            seqs, labels = P.eval_pack([mine[int(i)] for i in idx], self.max_text_len)
             scores = self.model.prefill_verbalize(seqs, self.verbalizer.label_token_ids)
             ranked = M.rank_classes(scores)
             M.rank_histogram(ranked, torch.from_numpy(labels).to(self.model.device), hist)

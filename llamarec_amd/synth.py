@@ -145,13 +145,31 @@ def synth_users(name: str, n_users: int | None = None, first_user: int = 0, seed
     return ids, labels, n, T
 
 
-def synth_prompt_tokens(T: np.ndarray, seed: int, vocab: int = 32000):
-    """Packed int32 prompt ids for prompt lengths T: BOS (=1) then uniform ids in [3, vocab)."""
+# Every prompt opens with the same template text (dataloader/utils.py:24-40, templates/alpaca_short.json:3,
+# config.py:247-249): BOS + "### Instruction:\n<system sentence>\n\n### Input:\nUser history:" -- with the Llama-2
+# sentencepiece vocabulary 1 + 5 + 20 + 2 + 4 + 3 = 35 tokens, then "(1)" of the first history item; the other
+# template tokens of SURVEY.md 8(d)'s 48 ("; \n Candidate pool:", "\n\n### Response:\n") sit at user-dependent
+# positions. Prompts clamped by the 1536-token LEFT truncation (config.py:236) lose that prefix.
+TEMPLATE_PREFIX_TOKENS = 36
+
+
+def synth_prompt_tokens(T: np.ndarray, seed: int, vocab: int = 32000, shared_prefix: bool = True):
+    """Packed int32 prompt ids for prompt lengths T: BOS (=1) then uniform ids in [3, vocab). With shared_prefix the
+    first TEMPLATE_PREFIX_TOKENS ids of every prompt shorter than LLM_MAX_TEXT_LEN are the same fixed template ids
+    (the ids of a truncated prompt stay random: its head was cut off)."""
     rng = np.random.default_rng(seed)
+    T = np.asarray(T, dtype=np.int64)
     cu = np.zeros(len(T) + 1, np.int32)
     cu[1:] = np.cumsum(T)
     ids = rng.integers(3, vocab, size=int(cu[-1]), dtype=np.int32)
     ids[cu[:-1]] = 1
+    if shared_prefix:
+        template = np.random.default_rng(20240807).integers(3, vocab, size=TEMPLATE_PREFIX_TOKENS, dtype=np.int32)
+        template[0] = 1
+        for b in range(len(T)):
+            if T[b] < LLM_MAX_TEXT_LEN:
+                n = min(TEMPLATE_PREFIX_TOKENS, int(T[b]))
+                ids[cu[b]: cu[b] + n] = template[:n]
     return ids, cu
 
 

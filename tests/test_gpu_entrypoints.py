@@ -172,3 +172,110 @@ def test_online_single_user_path(golden_dir):
     for j in range(9):
         if gaps[j] > 6e-2 and (j == 0 or gaps[j - 1] > 6e-2):
             assert top[j] == cands[order[j]]
+
+
+def _write_hf_dir(path, sd, cfg, shards=2):
+    """A local HF model directory as the reference's from_pretrained reads it (train_ranker.py:57-62): config.json +
+    `shards` safetensors files + the index json, bf16 tensors under HF's parameter names."""
+    from safetensors.torch import save_file
+
+    os.makedirs(path, exist_ok=True)
+    json.dump(dict(cfg, architectures=["LlamaForCausalLM"], model_type="llama", torch_dtype="bfloat16"),
+              open(os.path.join(path, "config.json"), "w"))
+    names = list(sd)
+    weight_map = {}
+    for s in range(shards):
+        fn = f"model-{s + 1:05d}-of-{shards:05d}.safetensors"
+        part = {n: torch.from_numpy(sd[n]).to(torch.bfloat16) for n in names[s::shards]}
+        save_file(part, os.path.join(path, fn), metadata={"format": "pt"})
+        weight_map.update({n: fn for n in part})
+    json.dump({"metadata": {}, "weight_map": weight_map}, open(os.path.join(path, "model.safetensors.index.json"), "w"))
+
+
+def _write_peft_adapter(path, cfg, r=8, alpha=32, seed=0):
+    from safetensors.torch import save_file
+
+    os.makedirs(path, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    d = cfg["hidden_size"]
+    hd = d // cfg["num_attention_heads"]
+    w, lora = {}, {}
+    for i in range(cfg["num_hidden_layers"]):
+        for proj, out in (("q_proj", cfg["num_attention_heads"] * hd), ("v_proj", cfg["num_key_value_heads"] * hd)):
+            base = f"model.layers.{i}.self_attn.{proj}"
+            A = (rng.standard_normal((r, d)) * 0.05).astype(np.float32)
+            B = (rng.standard_normal((out, r)) * 0.05).astype(np.float32)
+            w[f"base_model.model.{base}.lora_A.weight"] = torch.from_numpy(A)      # peft 0.11 key layout on disk
+            w[f"base_model.model.{base}.lora_B.weight"] = torch.from_numpy(B)
+            lora[f"{base}.lora_A.weight"], lora[f"{base}.lora_B.weight"] = A, B
+    save_file(w, os.path.join(path, "adapter_model.safetensors"))
+    json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj"],
+               "lora_dropout": 0.05, "bias": "none", "task_type": "CAUSAL_LM"},
+              open(os.path.join(path, "adapter_config.json"), "w"))
+    return dict(r=r, alpha=alpha, weights=lora)
+
+
+@pytest.mark.parametrize("load_in_4bit", [True, False])
+def test_from_pretrained_local_hf_dir_and_peft_adapter(tmp_path, load_in_4bit):
+    """a local HF directory (config.json + sharded safetensors) and a PEFT adapter directory, loaded
+    the way the reference loads them (train_ranker.py:57-79: NF4 base, adapter on top) -> the same scores, bit for bit,
+    as from_state_dict on the same tensors; and the adapter / the quantisation really change the model."""
+    from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.synth import synth_llama_state
+
+    cfg = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+               num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    sd = synth_llama_state(cfg, 21)
+    hf, ad = str(tmp_path / "hf"), str(tmp_path / "adapter")
+    _write_hf_dir(hf, sd, cfg, shards=2)
+    lora = _write_peft_adapter(ad, cfg)
+    rng = np.random.default_rng(0)
+    seqs = [np.concatenate([[1], rng.integers(3, 320, size=n)]) for n in (5, 70, 200, 33)]
+    label_ids = list(range(40, 60))
+    loaded = LlamaRanker.from_pretrained(hf, adapter_path=ad, load_in_4bit=load_in_4bit)
+    direct = LlamaRanker.from_state_dict(sd, cfg, lora=lora, nf4=load_in_4bit)
+    a, b = loaded.prefill_verbalize(seqs, label_ids), direct.prefill_verbalize(seqs, label_ids)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert loaded.config["hidden_size"] == 256 and loaded.config["num_hidden_layers"] == 2   # taken from config.json
+    plain = LlamaRanker.from_pretrained(hf, load_in_4bit=load_in_4bit).prefill_verbalize(seqs, label_ids)
+    assert (plain - a).abs().max() > 1e-2                                      # the adapter is really merged
+    other = LlamaRanker.from_pretrained(hf, adapter_path=ad, load_in_4bit=not load_in_4bit).prefill_verbalize(seqs, label_ids)
+    assert not torch.equal(other, a)                                           # and so is the NF4 round trip
+
+
+def test_train_retriever_reads_dataset_pkl_from_the_preprocessed_folder(tmp_path):
+    """`python train_retriever.py --dataset_code beauty --eval_only` WITHOUT --synthetic reads
+    data/preprocessed/beauty_min_rating0-min_uc5-min_sc5/dataset.pkl (llamarec_datasets/base.py:125-140) and a
+    best_acc_model.pth in the reference's checkpoint format (trainer/loggers.py:7-8), and writes the reference's
+    output layout."""
+    import train_retriever
+    from llamarec_amd import data as D
+    from llamarec_amd.lru import init_lru_state_dict
+
+    ds = D.synthetic_dataset(num_users=120, num_items=400, seed=3)
+    path = D.preprocessed_path(str(tmp_path / "data"), "beauty", 0, 5, 5)
+    assert path.endswith(os.path.join("preprocessed", "beauty_min_rating0-min_uc5-min_sc5", "dataset.pkl"))
+    os.makedirs(os.path.dirname(path))
+    pickle.dump(ds, open(path, "wb"))
+    assert set(D.load_dataset_pkl(path)) >= {"train", "val", "test", "meta", "umap", "smap"}
+    root = str(tmp_path / "experiments" / "lru" / "beauty")
+    os.makedirs(os.path.join(root, "models"))
+    sd = init_lru_state_dict(400, seed=9)
+    torch.save({"model_state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "epoch": 0},
+               os.path.join(root, "models", "best_acc_model.pth"))
+    out = train_retriever.main(["--dataset_code", "beauty", "--data_root", str(tmp_path / "data"), "--eval_only",
+                                "--export_root", root])
+    assert len(out["test_probs"]) == 120 and all(len(p) == 50 for p in out["test_probs"])
+    r = pickle.load(open(os.path.join(root, "retrieved.pkl"), "rb"))
+    assert r["test_probs"] == out["test_probs"] and os.path.exists(os.path.join(root, "test_metrics.json"))
+    # Beauty template defaults apply without --synthetic (config.py:57-61,103-111): L = 50, eval batch 64
+    from llamarec_amd import config as cfg
+
+    a = cfg.parse(["--dataset_code", "beauty"], model_code="lru")
+    assert a.bert_max_len == 50 and a.test_batch_size == 64
+    with pytest.raises(ValueError, match="missing key"):
+        pickle.dump({"train": {}}, open(path, "wb"))
+        D.load_dataset_pkl(path)
+    with pytest.raises(SystemExit):       # no checkpoint and not synthetic: refuse, do not invent weights
+        train_retriever.main(["--dataset_code", "beauty", "--data_root", str(tmp_path / "data"), "--eval_only",
+                              "--export_root", str(tmp_path / "nowhere")])

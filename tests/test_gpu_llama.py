@@ -67,9 +67,7 @@ def assert_bf16_close(got, ref32, what, absum=None):
 
 @pytest.mark.parametrize("M,N,K,variant", [
     (5, 7, 24, 1), (64, 64, 32, 1), (70, 130, 100, 1), (33, 96, 51, 1),
-    (256, 256, 64, 2), (300, 512, 256, 2), (1, 256, 128, 2), (1000, 256, 4096, 2), (515, 768, 704, 2),
-    (300, 512, 256, 0), (300, 512, 256, 3), (1000, 256, 4096, 3), (515, 768, 704, 3), (1, 256, 64, 3),
-    (700, 256, 128, 3), (260, 256, 192, 3),
+    (300, 512, 256, 0), (256, 256, 64, 4), (1, 256, 128, 4),
     (300, 512, 256, 4), (1000, 256, 4096, 4), (515, 768, 704, 4), (1, 256, 64, 4), (700, 256, 128, 4), (260, 256, 192, 4),
 ])
 def test_gemm_vs_numpy(M, N, K, variant):
@@ -113,7 +111,7 @@ def test_gemm_fast_equals_generic_on_integers():
     A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)   # asymmetric patterns
     B = ((np.arange(N * K).reshape(N, K) * 5) % 11 - 5).astype(np.float32)
     ref = A @ B.T
-    for v in (1, 2, 3, 4):
+    for v in (1, 4):
         assert np.array_equal(gemm(A, B, v), bf16_round(ref)), v
 
 
@@ -149,7 +147,7 @@ def attention_ref(qkv, cu, nh, nkv, hd):
     return out
 
 
-@pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 3), (4, 2, 128, 3), (4, 4, 128, 1),
+@pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 1),
                                                (4, 2, 16, 1), (2, 2, 64, 1)])
 def test_attention_vs_numpy(nh, nkv, hd, variant):
     lens = [1, 63, 64, 65, 128, 129, 300, 2]
@@ -172,7 +170,7 @@ def load_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,variants", [("tiny_hd16", (0, 0)), ("tiny_gqa", (0, 0)), ("tiny_hd128", (1, 1)),
-                                           ("tiny_hd128", (2, 2)), ("tiny_hd128", (2, 3)), ("tiny_hd128", (0, 0))])
+                                           ("tiny_hd128", (4, 2)), ("tiny_hd128", (0, 0))])
 def test_prefill_logits_vs_oracle_and_reference(golden_dir, name, variants):
     from llamarec_amd.llm import LlamaRanker
     from oracle import llama_oracle as LO
@@ -313,3 +311,115 @@ def test_full_depth_llama2_7b_properties():
     assert (lat - a[:2]).abs().max() < 5e-2 * scale
     # scores are bf16 values (lm_head output of a bf16 model, widened)
     assert np.array_equal(a.cpu().numpy(), bf16_round(a.cpu().numpy()))
+
+
+def _prefixed_prompts(P, tails, vocab, seed):
+    rng = np.random.default_rng(seed)
+    prefix = np.concatenate([[1], rng.integers(3, vocab, size=P - 1)]) if P > 1 else np.array([1])
+    return [np.concatenate([prefix, rng.integers(3, vocab, size=n)]).astype(np.int32) for n in tails]
+
+
+@pytest.mark.parametrize("nkv", [2, 1])
+def test_shared_prefix_is_bit_identical_and_matches_oracle(nkv):
+    """lr_llama_prefill_verbalize_prefix (every prompt opens with the same template text,
+    dataloader/utils.py:24-40): the common prefix is evaluated once and the other prompts attend to its K/V rows. The
+    scores must equal the unshared run BIT FOR BIT for prefix lengths on every side of the 64-key block and 128-row
+    query tile boundaries, and both must match the numpy oracle."""
+    from llamarec_amd.llm import LlamaRanker, common_prefix_len, pack_prompts
+    from oracle import llama_oracle as LO
+
+    cfg = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+               num_key_value_heads=nkv, max_position_embeddings=1024, rms_norm_eps=1e-5, rope_theta=10000.0)
+    sd = synth_llama_state(cfg, 11)
+    model = LlamaRanker.from_state_dict(sd, cfg)
+    label_ids = list(range(40, 60))
+    tails = [1, 5, 100, 300, 64, 27]
+    for P in (1, 36, 63, 64, 65, 127, 128, 130, 200):
+        seqs = _prefixed_prompts(P, tails, 320, P)
+        ids, cu = pack_prompts(seqs)
+        assert common_prefix_len(ids, cu) >= P
+        shared = model.prefill_verbalize(seqs, label_ids, share_prefix=True)
+        plain = model.prefill_verbalize(seqs, label_ids, share_prefix=False)
+        assert torch.isfinite(plain).all() and torch.equal(shared, plain), P
+        # the explicit-length form, with a prefix SHORTER than the common one, is the same numbers again
+        if P > 3:
+            lab = torch.as_tensor(np.asarray(label_ids, dtype=np.int32)).cuda()
+            part = model.prefill_verbalize_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), cu, lab,
+                                                  prefix_len=P - 3)
+            assert torch.equal(part, plain), P
+    seqs = _prefixed_prompts(36, tails, 320, 99)
+    ref = LO.prefill_verbalize(sd, cfg, seqs, label_ids, "bf16")
+    assert np.abs(model.prefill_verbalize(seqs, label_ids).cpu().numpy() - ref).max() < 3e-2
+    # full last layer (no pruning) goes through the same prefix-aware attention
+    full = model.set_last_layer_pruning(False).prefill_verbalize(seqs, label_ids, share_prefix=True)
+    full_plain = model.prefill_verbalize(seqs, label_ids, share_prefix=False)
+    assert torch.equal(full, full_plain)
+
+
+def test_shared_prefix_rejects_bad_lengths():
+    from llamarec_amd._lib import LlamaRecError
+    from llamarec_amd.llm import LlamaRanker, pack_prompts
+
+    cfg = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2,
+               num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5, rope_theta=10000.0)
+    model = LlamaRanker.from_state_dict(synth_llama_state(cfg, 3), cfg)
+    seqs = _prefixed_prompts(8, [1, 4], 320, 0)
+    ids, cu = pack_prompts(seqs)
+    lab = torch.arange(40, 60, dtype=torch.int32).cuda()
+    for bad in (9, 50, -1):   # shortest prompt has 9 tokens: a prefix must leave it one of its own
+        with pytest.raises(LlamaRecError):
+            model.prefill_verbalize_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), cu, lab, prefix_len=bad)
+
+
+def test_full_width_shared_prefix_and_token_budget_batch():
+    """Llama-2-7b layer shapes, 2 layers: a 16 384-token batch built by llamarec_amd.packing (the bench's step) with the
+    36-token template prefix shared gives bit-identical scores to the same prompts run unshared in the reference's
+    16-prompt batches."""
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+    from llamarec_amd.packing import token_budget_steps
+    from llamarec_amd.synth import synth_prompt_tokens, synth_users
+
+    model = LlamaRanker.random_init(dict(LLAMA2_7B, num_hidden_layers=2), seed=5)
+    _, _, _, T = synth_users("beauty", 60)
+    step = token_budget_steps(T)[0]
+    ids, cu = synth_prompt_tokens(T[step], seed=4)
+    assert cu[-1] == 16384
+    seqs = [ids[cu[i]:cu[i + 1]] for i in range(len(step))]
+    label_ids = list(range(319, 339))
+    shared = model.prefill_verbalize(seqs, label_ids, share_prefix=True)
+    plain = torch.cat([model.prefill_verbalize(seqs[i:i + 16], label_ids, share_prefix=False) for i in range(0, len(seqs), 16)])
+    assert torch.isfinite(shared).all() and torch.equal(shared, plain)
+
+
+def test_full_width_parity_vs_oracle():
+    """SURVEY.md 8(a) a16 at the width that matters: Llama-2-7b layer shapes (d 4096, d_ff 11008, 32 x 128, vocab 32000),
+    2 layers, random bf16 weights; prompts of 64..300 tokens whose packed rows cross the 256-row GEMM tiles. The HIP
+    prefill + verbalizer vs oracle.llama_oracle in bf16 mode (the reference's HF LlamaModel arithmetic restated,
+    model/llm.py:89-131): max-abs within TOL on O(1) scores, and the ORDER of the 20 candidate scores identical wherever
+    the oracle separates two candidates by more than 2 x TOL (what trainer/llm.py:63-72 ranks by)."""
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+    from llamarec_amd.synth import llama_param_shapes
+    from oracle import llama_oracle as LO
+
+    TOL = 3e-2
+    cfg = dict(LLAMA2_7B, num_hidden_layers=2)
+    rng = np.random.default_rng(123)
+    sd = {}
+    for name, shape in llama_param_shapes(cfg):
+        sd[name] = (np.float32(1.0) + bf16_round(rng.uniform(-0.1, 0.1, shape).astype(np.float32))) if len(shape) == 1 else \
+            bf16_round(rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02))
+    lens = [64, 300, 130, 257]            # packed rows 0..63 | 64..363 | 364..493 | 494..750: rows 256 and 512 are crossed
+    seqs = [np.concatenate([[1], rng.integers(3, 32000, size=n - 1)]).astype(np.int32) for n in lens]
+    label_ids = list(range(319, 339))
+    ref = LO.prefill_verbalize(sd, cfg, seqs, label_ids, "bf16")
+    model = LlamaRanker.from_state_dict(sd, cfg)
+    for share in (False, True):
+        got = model.prefill_verbalize(seqs, label_ids, share_prefix=share).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= TOL, np.abs(got - ref).max()
+        d_ref = ref[:, :, None] - ref[:, None, :]
+        d_got = got[:, :, None] - got[:, None, :]
+        decided = np.abs(d_ref) > 2 * TOL
+        assert decided.sum() > 100          # the check is not vacuous
+        assert (np.sign(d_ref[decided]) == np.sign(d_got[decided])).all()
+    assert float(np.abs(ref).max()) > 0.5    # O(1) scores: the tolerance is a relative statement too

@@ -228,3 +228,72 @@ def test_flag_defaults_match_reference_config(golden_dir):
                 shared += 1
                 assert mine[k] == v, (key, k, mine[k], v)
     assert shared >= 6 * 40
+
+
+def test_train_ranker_builds_its_replica_on_the_local_rank_device(tmp_path, monkeypatch):
+    """Data parallel = one replica per GPU (train_ranker.py:46-47 of the reference: device_map {"": process_index}). Both
+    constructors must receive cuda:<LOCAL_RANK>; everything downstream (workspace, LoRA gradient buffer, histograms handed
+    to the all-reduce) takes model.device."""
+    import pickle
+
+    import train_ranker
+    from llamarec_amd import llm
+
+    pickle.dump({"val_users": [], "val_candidates": [], "test_users": [], "test_candidates": [],
+                 "test_retrieval": {"original_size": 1, "retrieval_size": 0, "non_retrieval_metrics": {}}},
+                open(tmp_path / "retrieved.pkl", "wb"))
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_from_state_dict(cls, state_dict, config, device="cuda:0", lora=None, nf4=False):
+        seen["from_state_dict"] = device
+        raise Stop
+
+    def fake_from_pretrained(cls, path, device="cuda:0", adapter_path=None, load_in_4bit=False):
+        seen["from_pretrained"] = device
+        raise Stop
+
+    monkeypatch.setattr(llm.LlamaRanker, "from_state_dict", classmethod(fake_from_state_dict))
+    monkeypatch.setattr(llm.LlamaRanker, "from_pretrained", classmethod(fake_from_pretrained))
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    with pytest.raises(Stop):
+        train_ranker.main(["--dataset_code", "synthetic", "--synthetic", "--llm_retrieved_path", str(tmp_path),
+                           "--export_root", str(tmp_path / "out")])
+    assert seen["from_state_dict"] == "cuda:3"
+    # the real-asset branch: a dataset.pkl + a local tokenizer directory, then from_pretrained(device=...)
+    from llamarec_amd import data as D
+    from tests.local_tokenizer import build_llama_like_tokenizer
+
+    root = tmp_path / "data"
+    path = D.preprocessed_path(str(root), "beauty", 0, 5, 5)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    pickle.dump(D.synthetic_dataset(num_users=20, num_items=50, seed=0), open(path, "wb"))
+    tok_dir = tmp_path / "tok"
+    build_llama_like_tokenizer().save_pretrained(str(tok_dir))
+    with pytest.raises(Stop):
+        train_ranker.main(["--dataset_code", "beauty", "--data_root", str(root), "--llm_retrieved_path", str(tmp_path),
+                           "--llm_base_model", str(tmp_path / "hf"), "--llm_base_tokenizer", str(tok_dir),
+                           "--export_root", str(tmp_path / "out2")])
+    assert seen["from_pretrained"] == "cuda:3"
+    # --share_gpu (several ranks rehearsed on one card) pins every rank to cuda:0
+    with pytest.raises(Stop):
+        train_ranker.main(["--dataset_code", "synthetic", "--synthetic", "--share_gpu", "--llm_retrieved_path", str(tmp_path),
+                           "--export_root", str(tmp_path / "out3")])
+    assert seen["from_state_dict"] == "cuda:0"
+
+
+def test_lora_trainer_refuses_a_dataset_smaller_than_one_optimizer_step():
+    from types import SimpleNamespace
+
+    from llamarec_amd.rank_train import LoraRankerTrainer
+
+    args = SimpleNamespace(lora_micro_batch_size=4, train_batch_size=8, lora_max_steps=0, lora_num_epochs=1, warmup_steps=0)
+    with pytest.raises(ValueError, match="fewer than one optimizer step"):
+        LoraRankerTrainer(args, engine=None, train_samples=list(range(15)), val_items=[], verbalizer=None,
+                          export_root=None, rank=0, world=2)
+    LoraRankerTrainer(args, engine=None, train_samples=list(range(16)), val_items=[], verbalizer=None,
+                      export_root=None, rank=0, world=2)       # exactly one step: fine

@@ -1,4 +1,6 @@
-"""Diagnostic: where the flash-attention key-block loop spends its cycles (s_memtime stamps, LR_ATTN_STAMPS=1)."""
+"""Diagnostic: where the flash-attention key-block loop spends its cycles (s_memtime stamps). Needs the experiment
+build of the library: `make -C llamarec_amd/csrc clean && make -C llamarec_amd/csrc -j8 EXPERIMENTS=1` (the product
+library holds no stamping code); LR_ATTN_STAMPS=1 then selects the stamped instantiation."""
 import ctypes as C, os, sys
 os.environ["LR_ATTN_STAMPS"] = "1"
 import numpy as np, torch

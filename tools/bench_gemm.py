@@ -4,7 +4,7 @@ import numpy as np, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd._lib import check, lib, stream_ptr
 
-def run(variants, M=14800, rounds=5, check_equal=True):
+def run(variants, M=16384, rounds=5, check_equal=True):
     shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     ws = torch.empty((64 << 20) + 4096, dtype=torch.uint8, device="cuda")   # split-K planes / stream-K slots + flags
@@ -37,11 +37,14 @@ def run(variants, M=14800, rounds=5, check_equal=True):
         print(line, flush=True)
 
 if __name__ == "__main__":
-    vs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 3]
-    run(vs, M=int(sys.argv[2]) if len(sys.argv) > 2 else 14800)
+    # python tools/bench_gemm.py <variants, e.g. 4 or 1,4> <M, or M1,M2,...> [yardstick]
+    vs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4]
+    Ms = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] != "yardstick" else [16384]
+    for M in Ms:
+        run(vs, M=M)
 
 
-def yardstick(M=14800, rounds=5):
+def yardstick(M=16384, rounds=5):
     """torch.matmul (hipBLASLt) on the same shapes/data -- a yardstick only, never the product."""
     shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
     g = torch.Generator(device="cuda"); g.manual_seed(0)
@@ -61,5 +64,6 @@ def yardstick(M=14800, rounds=5):
         print(f"yardstick torch.matmul {name:8s}: {np.median(ts):.3f} ms {fl/np.median(ts)/1e9:.0f} TF/s", flush=True)
 
 
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "yardstick":
-    yardstick()
+if __name__ == "__main__" and "yardstick" in sys.argv[2:]:
+    for M in ([int(x) for x in sys.argv[2].split(",")] if sys.argv[2] != "yardstick" else [16384]):
+        yardstick(M)

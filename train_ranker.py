@@ -36,10 +36,15 @@ def main(argv=None, export_root=None):
     export_root = export_root or args.export_root or os.path.join(
         cfg.EXPERIMENT_ROOT, args.llm_base_model.rstrip("/").split("/")[-1], args.dataset_code)
     retrieved = pickle.load(open(os.path.join(args.llm_retrieved_path, "retrieved.pkl"), "rb"))
+    if args.share_gpu:                      # rehearsal of several ranks on one card (gloo): everybody on cuda:0
+        os.environ["LOCAL_RANK"] = "0"
     rank, world, local = DD.init_from_env(args.dist_backend)
-    if world > 1 and not args.share_gpu:
-        import torch
+    import torch
 
+    # one replica per GPU (train_ranker.py:46-47 of the reference: device_map = {"": process_index}): the model, the
+    # workspace, the flat LoRA gradient buffer and the histograms handed to the all-reduce all live on cuda:<local rank>
+    device = f"cuda:{local}"
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if args.synthetic:
         from llamarec_amd.synth import FakeTokenizer, synth_llama_state
@@ -51,7 +56,7 @@ def main(argv=None, export_root=None):
                  rms_norm_eps=1e-5, rope_theta=10000.0)
         from llamarec_amd.llm import load_peft_adapter
 
-        model = LlamaRanker.from_state_dict(synth_llama_state(c, args.seed), c,
+        model = LlamaRanker.from_state_dict(synth_llama_state(c, args.seed), c, device=device,
                                             lora=load_peft_adapter(args.llm_adapter_path) if args.llm_adapter_path
                                             else None, nf4=args.llm_load_in_4bit)
     else:
@@ -65,7 +70,7 @@ def main(argv=None, export_root=None):
         tokenizer.padding_side = "left"
         tokenizer.truncation_side = "left"
         tokenizer.clean_up_tokenization_spaces = True
-        model = LlamaRanker.from_pretrained(args.llm_base_model, adapter_path=args.llm_adapter_path,
+        model = LlamaRanker.from_pretrained(args.llm_base_model, device=device, adapter_path=args.llm_adapter_path,
                                             load_in_4bit=args.llm_load_in_4bit)
     ncls = args.llm_negative_sample_size + 1
     args.num_items = len(dataset["smap"])
