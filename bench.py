@@ -219,20 +219,22 @@ def build_steps(workload, rank, n_steps, budget, users_per_step, dev, shared_pre
 
     from llamarec_amd.llm import common_prefix_len
     from llamarec_amd.packing import token_budget_steps
-    from llamarec_amd.synth import WORKLOADS, synth_prompt_tokens, synth_users
+    from llamarec_amd.synth import LLM_MAX_TEXT_LEN, TEMPLATE_PREFIX_TOKENS, WORKLOADS, synth_prompt_tokens, synth_users
 
     w = WORKLOADS[workload]
     if users_per_step > 0:
         n_users = n_steps * users_per_step
     else:
         probe = synth_users(workload, 256, first_user=rank * w["U"])[3]
-        n_users = int(np.ceil((n_steps + 1.5) * budget / float(probe.mean())))
+        n_users = int(np.ceil((n_steps + 1.5) * budget / (float(probe.mean()) - (TEMPLATE_PREFIX_TOKENS if shared_prefix else 0))))
     n_users = min(max(n_users, 1), w["U"])
     hist, labels, _, T = synth_users(workload, n_users, first_user=rank * w["U"])
     if users_per_step > 0:
         groups = [np.arange(i, min(i + users_per_step, n_users)) for i in range(0, n_users, users_per_step)]
     else:
-        groups = token_budget_steps(T, budget)
+        # the template prefix is run once per step, so a step's rows are P + sum(T - P) (packing.token_budget_steps)
+        P = TEMPLATE_PREFIX_TOKENS if shared_prefix and T.max() < LLM_MAX_TEXT_LEN else 0
+        groups = token_budget_steps(T, budget, shared_prefix=P)
     groups = groups[:n_steps] if len(groups) >= n_steps else groups
     steps = []
     for b, g in enumerate(groups):
@@ -318,6 +320,8 @@ def main():
 
     users_rank = sum(steps[i % nb]["users"] for i in range(args.steps))
     tok_rank = sum(int(steps[i % nb]["cu"][-1]) for i in range(args.steps))
+    # rows the prefill executes: the shared prefix once per step instead of once per prompt
+    rows_rank = sum(int(steps[i % nb]["cu"][-1]) - (steps[i % nb]["users"] - 1) * steps[i % nb]["prefix"] for i in range(args.steps))
     users = total_users                      # all-reduced count of users scored in the timed region
     assert world > 1 or users == users_rank
 
@@ -371,6 +375,7 @@ def main():
                                     f"token budget {budget} per step (llamarec_amd/packing.py)"),
                        "shared_prompt_prefix_tokens": float(np.mean([steps[i % nb]["prefix"] for i in range(args.steps)])),
                        "users_per_step": users_rank / args.steps, "mean_prompt_tokens_per_step": tok_rank / args.steps,
+                       "mean_rows_per_step": rows_rank / args.steps,
                        "llama_layers": args.layers, "parallelism": f"dp{world}", "collective_backend": args.dist_backend or "nccl"},
             "roofline": roofline, "stage1_only_users_per_s": stage1_users_per_s,
             "prefill_algorithmic_tflops_per_gpu": alg_flops / elapsed / 1e12,

@@ -208,6 +208,20 @@ void lr_llama_destroy(lr_llama_t* h);
  * then reproducible only for the same packed batch size (bf16-level differences otherwise). */
 int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant);
 
+/* Folded RMSNorm (optional, scoring path only). HF's layer computes  proj(norm_w * bf16(x * rstd))  with its own
+ * read-and-write pass over the residual stream in front of q/k/v_proj and of gate/up_proj (LlamaRMSNorm, reached from
+ * model/llm.py:89-100). Here the norm weight can be multiplied into the projection matrices once at load
+ * (lr_fold_norm_bf16: out[j][k] = bf16(w[j][k] * norm_w[k]), DEVICE pointers) and handed over with
+ * lr_llama_set_folded_norms (HOST arrays [num_layers] of DEVICE pointers: wqkv * diag(input_norm), wgu *
+ * diag(post_norm), layouts as in LrLlamaLayerWeights; the caller keeps them alive). The prefill then reads each row
+ * once for rstd = 1 / sqrt(mean(x^2) + eps) and the GEMM epilogue scales its fp32 accumulator rows by it:
+ * rstd * (x . (W_j * w)) == (x * rstd * w) . W_j up to bf16 rounding points (two activation roundings fewer, one weight
+ * rounding more; within the parity tolerance of tests/test_gpu_llama.py). The original matrices stay in use for the
+ * last layer's B pruned rows and for LoRA fine-tuning. Passing two NULLs restores the separate RMSNorm pass. */
+int lr_fold_norm_bf16(const uint16_t* w, const uint16_t* norm_w, int32_t rows, int32_t cols, uint16_t* out,
+                      void* hip_stream);
+int lr_llama_set_folded_norms(lr_llama_t* h, const uint16_t* const* wqkv_folded, const uint16_t* const* wgu_folded);
+
 /* Last-layer pruning (default ON): after the final layer only each prompt's last token is consumed
  * (model/llm.py:131), so that layer computes K/V for all tokens but attention output, o_proj and the
  * MLP for B rows only. Results are unchanged up to bf16 summation order; disable for A/B tests. */

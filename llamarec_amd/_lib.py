@@ -55,6 +55,8 @@ PROTOTYPES = {
     "lr_llama_destroy": (None, [C.c_void_p]),
     "lr_llama_set_variants": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "lr_llama_set_last_layer_pruning": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lr_fold_norm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lr_llama_set_folded_norms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "lr_llama_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "lr_llama_prefill_verbalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -58,12 +58,38 @@ extern "C" int lr_llama_set_last_layer_pruning(lr_llama_t* h, int32_t enable) {
 extern "C" void lr_llama_destroy(lr_llama_t* h) {
   if (!h) return;
   free(h->layers);
+  free(h->wqkv_folded);
+  free(h->wgu_folded);
   free(h);
+}
+
+extern "C" int lr_fold_norm_bf16(const uint16_t* w, const uint16_t* norm_w, int32_t rows, int32_t cols, uint16_t* out,
+                                 void* hip_stream) {
+  if (!w || !norm_w || !out || rows < 1 || cols < 8) LR_FAIL(LR_EINVAL, "lr_fold_norm_bf16: bad argument");
+  return lr_launch_fold_norm(w, norm_w, out, (size_t)rows, cols, (hipStream_t)hip_stream);
+}
+
+extern "C" int lr_llama_set_folded_norms(lr_llama_t* h, const uint16_t* const* wqkv_folded,
+                                         const uint16_t* const* wgu_folded) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_llama_set_folded_norms: null handle");
+  free(h->wqkv_folded);
+  free(h->wgu_folded);
+  h->wqkv_folded = h->wgu_folded = nullptr;
+  if (!wqkv_folded && !wgu_folded) return LR_OK;  // back to the separate RMSNorm pass
+  if (!wqkv_folded || !wgu_folded) LR_FAIL(LR_EINVAL, "lr_llama_set_folded_norms: give both arrays or neither");
+  const int L = h->cfg.num_layers;
+  for (int l = 0; l < L; ++l)
+    if (!wqkv_folded[l] || !wgu_folded[l]) LR_FAIL(LR_EINVAL, "lr_llama_set_folded_norms: layer %d has a null matrix", l);
+  h->wqkv_folded = (const uint16_t**)malloc(sizeof(void*) * L);
+  h->wgu_folded = (const uint16_t**)malloc(sizeof(void*) * L);
+  memcpy(h->wqkv_folded, wqkv_folded, sizeof(void*) * L);
+  memcpy(h->wgu_folded, wgu_folded, sizeof(void*) * L);
+  return LR_OK;
 }
 
 struct LlamaWs {
   int32_t *tok_pos, *tok_src, *last_rows, *seg_start;
-  float* rope;
+  float *rope, *rstd;
   u16 *x, *xn, *qkv, *att, *hmid;
   u16 *x_last, *xn_last, *att_last, *h_last;  // compact [B][.] buffers of the pruned last layer
   float* splitk;                              // fp32 partial planes of the split-K GEMMs (gemm variant 5)
@@ -85,6 +111,7 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.tok_pos = (int32_t*)take(n * 4);
   w.tok_src = (int32_t*)take(n * 4);
   w.rope = (float*)take((size_t)c.max_positions * (c.head_dim / 2) * 2 * sizeof(float));
+  w.rstd = (float*)take(n * sizeof(float));
   w.x = (u16*)take(n * c.hidden_size * 2);
   w.xn = (u16*)take(n * c.hidden_size * 2);
   w.qkv = (u16*)take(n * qkv_w * 2);
@@ -164,10 +191,19 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->layers[l];
-    RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+    // RMSNorm: either its own pass (read + write every row), or -- folded -- only the row statistic, with the norm
+    // weight already inside the projection matrix and rstd applied to the accumulator rows in the GEMM epilogue
+    const bool folded = h->wqkv_folded != nullptr;
     // QKV projection with the rotary embedding applied in the epilogue (q/k rows pair-interleaved)
-    RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
-                       ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES));
+    if (folded) {
+      RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
+      RUN(lr_launch_gemm(ws.x, h->wqkv_folded[l], ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
+                         ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd));
+    } else {
+      RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+      RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
+                         ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES));
+    }
     if (l == c.num_layers - 1 && h->prune_last) {
       // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
       // last layer needs K/V for every token but attention output, o_proj, and the MLP for B rows only.
@@ -198,9 +234,15 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
                             h->attn_variant, nullptr, st, P));
     RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0,
                        0, ws.splitk, LR_SPLITK_WS_BYTES));
-    RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
-    RUN(lr_launch_gemm(ws.xn, w.wgu, ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr, nullptr,
-                       0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
+    if (folded) {
+      RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
+      RUN(lr_launch_gemm(ws.x, h->wgu_folded[l], ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr,
+                         nullptr, 0, 0, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd));
+    } else {
+      RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+      RUN(lr_launch_gemm(ws.xn, w.wgu, ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr, nullptr,
+                         0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
+    }
     RUN(lr_launch_gemm(ws.hmid, w.wdown, ws.x, ws.x, n, d, f, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0, 0,
                        ws.splitk, LR_SPLITK_WS_BYTES));
   }

@@ -95,6 +95,56 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* x, const u16* w
   }
 }
 
+// ---- RMSNorm statistic only (the normalisation itself is folded into the next GEMM, llama_gemm.hip RopeArgs) ------
+// one wave per row: 16-byte loads, fp32 square-sum in a fixed order (lane-strided, then the 6-step butterfly), so a
+// row's rstd never depends on what else is in the batch
+__global__ __launch_bounds__(256) void rms_rstd_kernel(const u16* x, float* rstd, int rows, int d, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const u16x8* xr = reinterpret_cast<const u16x8*>(x + (size_t)row * d);
+  float ss = 0.f;
+  for (int i = lane; i < d / 8; i += 64) {
+    const u16x8 v = xr[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf2f(v[j]);
+      ss = __builtin_fmaf(f, f, ss);
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) ss += __shfl_xor(ss, s, 64);
+  if (lane == 0) rstd[row] = 1.0f / sqrtf(ss / (float)d + eps);
+}
+
+__global__ __launch_bounds__(256) void fold_norm_kernel(const u16* w, const u16* nw, u16* out, size_t n_vec, int cols_vec) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_vec) return;
+  const u16x8 a = reinterpret_cast<const u16x8*>(w)[i];
+  const u16x8 b = reinterpret_cast<const u16x8*>(nw)[i % cols_vec];
+  u16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(a[j]) * bf2f(b[j]));
+  reinterpret_cast<u16x8*>(out)[i] = o;
+}
+
+int lr_launch_rms_rstd(const u16* x, float* rstd, int rows, int d, float eps, hipStream_t st) {
+  if (rows <= 0) return LR_OK;
+  if (d % 8 != 0) LR_FAIL(LR_EINVAL, "rms_rstd: hidden size %d is not a multiple of 8", d);
+  hipLaunchKernelGGL(rms_rstd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rstd, rows, d, eps);
+  LR_CHECK_LAUNCH("rms_rstd_kernel");
+  return LR_OK;
+}
+
+int lr_launch_fold_norm(const u16* w, const u16* norm_w, u16* out, size_t rows, int cols, hipStream_t st) {
+  if (rows == 0) return LR_OK;
+  if (cols % 8 != 0) LR_FAIL(LR_EINVAL, "fold_norm: %d columns are not a multiple of 8", cols);
+  const size_t n_vec = rows * (size_t)(cols / 8);
+  hipLaunchKernelGGL(fold_norm_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, w, norm_w, out, n_vec,
+                     cols / 8);
+  LR_CHECK_LAUNCH("fold_norm_kernel");
+  return LR_OK;
+}
+
 // ---- RoPE table: cos/sin(pos * theta^(-2i/hd)) rounded to bf16 like HF's bf16 rotary ---------
 __global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, float theta) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

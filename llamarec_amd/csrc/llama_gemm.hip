@@ -40,6 +40,10 @@ struct RopeArgs {
   const float* cs;         // [max_T][head_dim/2][2] (cos, sin), bf16-valued
   int head_dim;
   int rot_cols;            // columns [0, rot_cols) are q and k heads; the rest (v) is stored as is
+  // Folded RMSNorm (ROPE and SWIGLU epilogues): the GEMM ran on the un-normalised residual rows against weights with
+  // the norm weight multiplied in (lr_fold_norm_bf16), and the accumulator of row m is scaled by rstd[m] =
+  // 1 / sqrt(mean(x_m^2) + eps) here:  (x_m * rstd_m * w) . W_j  ==  rstd_m * (x_m . (W_j * w)).  nullptr: no scaling.
+  const float* row_scale;
 };
 
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
@@ -50,6 +54,11 @@ __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const 
   if (EPI == LR_EPI_PARTIAL) {  // C is the fp32 partial plane of this split
     *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(C) + off) = v;
     return;
+  }
+  if ((EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale) {
+    const float rs = rope.row_scale[row];
+    v *= rs;
+    up *= rs;
   }
   if (EPI == LR_EPI_ROPE) {
     float x[4];
@@ -154,17 +163,18 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const u16* __restrict
         if (col + 3 < N) {
           epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * N + col, rope, row, col);
         } else {
-          for (int j = 0; j < 4; ++j)
-            if (col + j < N) C[(size_t)row * N + col + j] = f2bf(acc[mt][nt][j]);  // only hit when N%4 != 0 (no rope cols there)
+          for (int j = 0; j < 4; ++j)  // only hit when N%4 != 0 (no rope cols there)
+            if (col + j < N) C[(size_t)row * N + col + j] = f2bf(acc[mt][nt][j] * (rope.row_scale ? rope.row_scale[row] : 1.0f));
         }
       }
     } else if (EPI == LR_EPI_SWIGLU) {
       int ocol = (n0 + wn * 32) / 2 + (lane >> 4) * 4;
+      const float rs = rope.row_scale ? rope.row_scale[row] : 1.0f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (n0 + wn * 32 + 16 + (lane >> 4) * 4 + j < N)
           C[(size_t)row * (N / 2) + ocol + j] =
-              swiglu_bf16(bf2f(f2bf(acc[mt][0][j])), bf2f(f2bf(acc[mt][1][j])));
+              swiglu_bf16(bf2f(f2bf(acc[mt][0][j] * rs)), bf2f(f2bf(acc[mt][1][j] * rs)));
     } else {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col);
+          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col, rope, row, col);
         }
       } else {
 #pragma unroll
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       g += *reinterpret_cast<const floatx4*>(part + s * plane + g_off);
       u += *reinterpret_cast<const floatx4*>(part + s * plane + g_off + 16);
     }
-    epi_store4<EPI>(g, u, C, R, (size_t)row * n_out + c);
+    epi_store4<EPI>(g, u, C, R, (size_t)row * n_out + c, rope, row, c);
   } else {
     const size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (off >= plane) return;
@@ -504,7 +514,7 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
 
 int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
                    int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs, int head_dim,
-                   int rot_cols, float* splitk_ws, size_t splitk_ws_bytes) {
+                   int rot_cols, float* splitk_ws, size_t splitk_ws_bytes, const float* row_scale) {
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
@@ -516,7 +526,9 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
     LR_FAIL(LR_EUNSUPPORTED, "gemm variant 4 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols};
+  RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols, row_scale};
+  if (row_scale && epi != LR_EPI_ROPE && epi != LR_EPI_SWIGLU)
+    LR_FAIL(LR_EINVAL, "gemm: a row scale (folded RMSNorm) is only applied by the rope and swiglu epilogues");
   if (epi == LR_EPI_ROPE) {
     if (!tok_pos || !rope_cs || head_dim < 2 || head_dim % 4 != 0 || rot_cols % 4 != 0 || rot_cols > N)
       LR_FAIL(LR_EINVAL, "rope epilogue: bad arguments (head_dim=%d rot_cols=%d)", head_dim, rot_cols);

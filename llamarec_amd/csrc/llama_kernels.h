@@ -50,7 +50,13 @@ int lr_launch_head(const unsigned short* x, const int32_t* rows /*[B]; nullptr: 
 int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned short* C,
                    const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st,
                    const int32_t* tok_pos = nullptr, const float* rope_cs = nullptr, int head_dim = 0,
-                   int rot_cols = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
+                   int rot_cols = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0,
+                   const float* row_scale = nullptr /* rope / swiglu epilogues: accumulator row m times row_scale[m] */);
+// rstd[m] = 1 / sqrt(mean(x[m][:]^2) + eps), fp32 (the statistic of HF's LlamaRMSNorm)
+int lr_launch_rms_rstd(const unsigned short* x, float* rstd, int rows, int d, float eps, hipStream_t st);
+// out[j][k] = bf16(w[j][k] * norm_w[k]): an RMSNorm weight folded into the following projection's [out][in] matrix
+int lr_launch_fold_norm(const unsigned short* w, const unsigned short* norm_w, unsigned short* out, size_t rows, int cols,
+                        hipStream_t st);
 
 // varlen causal attention over packed qkv (RoPE applied). variant: 0 auto, 1 generic, 2 MFMA hd=128.
 // cu / cu_host = segment starts; prefix_len > 0: segment 0 is the prefix the other segments continue (MFMA kernel only)

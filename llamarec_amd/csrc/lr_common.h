@@ -144,6 +144,9 @@ struct lr_llama {
   int gemm_variant;  // 0 auto, 1 generic, 4 256x256x64 MFMA tile, 5 = 4 + split-K (latency mode)
   int attn_variant;  // 0 auto, 1 generic, 2 MFMA head_dim 128
   int prune_last;    // last layer: attention output / o_proj / MLP only for each prompt's last token
+  // folded RMSNorm (lr_llama_set_folded_norms): per layer wqkv * diag(input_norm) and wgu * diag(post_norm), or null
+  const uint16_t** wqkv_folded;
+  const uint16_t** wgu_folded;
 };
 
 #endif  // LR_COMMON_H

@@ -111,6 +111,8 @@ class LlamaRanker:
         self._tensors = {}
         self._ws = None
         self._layers_arr = None
+        self._folded_arr = None
+        self.fold_norms = True   # scoring path: RMSNorm folded into the next projection (set_fold_norms)
         self.training = False
 
     # -- construction ------------------------------------------------------------------------
@@ -254,6 +256,38 @@ class LlamaRanker:
             torch.cuda.synchronize()
             check(lib().lr_llama_create(C.byref(cfg), C.byref(desc), C.byref(h)), "lr_llama_create")
         self._h, self._layers_arr = h, arr
+        if self.fold_norms:
+            self.set_fold_norms(True)
+
+    def set_fold_norms(self, enable=True):
+        """Fold the two RMSNorms of every layer into the following projection (include/llamarec_mi355x.h,
+        lr_llama_set_folded_norms): wqkv * diag(input_norm) and wgu * diag(post_norm) are built once on the GPU and
+        kept beside the originals (+66 % of the q/k/v/gate/up bytes; the originals serve LoRA fine-tuning and the
+        pruned last layer)."""
+        T, L = self._tensors, self.config["num_hidden_layers"]
+        if not enable:
+            check(lib().lr_llama_set_folded_norms(self._h, None, None), "lr_llama_set_folded_norms")
+            for i in range(L):
+                T.pop(f"{i}.wqkv_folded", None)
+                T.pop(f"{i}.wgu_folded", None)
+            self._folded_arr = None
+            self.fold_norms = False
+            return self
+        qa, ga = (C.c_void_p * L)(), (C.c_void_p * L)()
+        with torch.cuda.device(self.device):
+            for i in range(L):
+                for name, norm, arr in (("wqkv", "input_norm", qa), ("wgu", "post_norm", ga)):
+                    w = T[f"{i}.{name}"]
+                    out = torch.empty_like(w)
+                    check(lib().lr_fold_norm_bf16(w.data_ptr(), T[f"{i}.{norm}"].data_ptr(), w.shape[0], w.shape[1],
+                                                  out.data_ptr(), stream_ptr()), "lr_fold_norm_bf16")
+                    T[f"{i}.{name}_folded"] = out
+                    arr[i] = out.data_ptr()
+            torch.cuda.synchronize()
+            check(lib().lr_llama_set_folded_norms(self._h, qa, ga), "lr_llama_set_folded_norms")
+        self._folded_arr = (qa, ga)
+        self.fold_norms = True
+        return self
 
     def set_variants(self, gemm=0, attention=0):
         """Kernel selection (include/llamarec_mi355x.h): 0 = auto; gemm=5 = latency mode for the online

@@ -26,11 +26,18 @@ TOKEN_BUDGET = 16384
 WINDOW = 64
 
 
-def token_budget_steps(lengths, budget: int = TOKEN_BUDGET, window: int = WINDOW, max_prompts: int | None = None):
+def token_budget_steps(lengths, budget: int = TOKEN_BUDGET, window: int = WINDOW, max_prompts: int | None = None,
+                       shared_prefix: int = 0):
     """lengths: prompt lengths in tokens (each 1..budget). Returns a list of int64 index arrays (ascending inside
     a step), every index exactly once, each step's lengths summing to <= budget (and holding <= max_prompts
-    prompts if given)."""
+    prompts if given). shared_prefix = P > 0: every prompt starts with the same P tokens, which the prefill runs once
+    per step (lr_llama_prefill_verbalize_prefix), so a step of prompts T_1..T_n occupies P + sum(T_i - P) rows: the
+    budget is applied to that."""
     T = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    if shared_prefix:
+        if shared_prefix < 0 or (T.size and shared_prefix >= T.min()):
+            raise ValueError("shared_prefix must be shorter than every prompt")
+        return token_budget_steps(T - shared_prefix, budget - shared_prefix, window, max_prompts)
     if T.size and (T.min() < 1 or T.max() > budget):
         raise ValueError(f"prompt lengths must be in [1, {budget}] (got {int(T.min())}..{int(T.max())})")
     if window < 1:

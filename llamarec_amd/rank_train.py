@@ -233,6 +233,8 @@ class LoraTrainEngine:
             dv = s * (p[f"layers.{l}.v_proj.lora_B"] @ p[f"layers.{l}.v_proj.lora_A"])
             w[:nq] = (w[:nq].float() + dq).to(torch.bfloat16)
             w[nq + nkv:] = (w[nq + nkv:].float() + dv).to(torch.bfloat16)
+        if rk.fold_norms:
+            rk.set_fold_norms(True)   # the scoring path's wqkv * diag(input_norm) copies follow the merged weights
         self.merged = True
         return rk
 

@@ -65,7 +65,13 @@ class LLMEvaluator:
         lo, hi = PK.shard_by_tokens(lens, world)[rank]
         mine = self.items[lo:hi]
         if self.token_budget:
-            batches = PK.token_budget_steps(lens[lo:hi], max(self.token_budget, int(lens.max()) if len(lens) else 1))
+            # the prompts' common template prefix is run once per batch (llm.prefill_verbalize): budget the rows it leaves
+            from .llm import common_prefix_len, pack_prompts
+
+            shared = common_prefix_len(*pack_prompts([np.asarray(it["input_ids"][-self.max_text_len:]) for it in mine])) \
+                if len(mine) > 1 else 0
+            batches = PK.token_budget_steps(lens[lo:hi], max(self.token_budget, int(lens.max()) if len(lens) else 1),
+                                            shared_prefix=shared)
         else:
             batches = [np.arange(i, min(i + self.batch_size, len(mine))) for i in range(0, len(mine), self.batch_size)]
         for idx in batches:

@@ -273,9 +273,9 @@ def test_train_retriever_reads_dataset_pkl_from_the_preprocessed_folder(tmp_path
 
     a = cfg.parse(["--dataset_code", "beauty"], model_code="lru")
     assert a.bert_max_len == 50 and a.test_batch_size == 64
-    with pytest.raises(ValueError, match="missing key"):
-        pickle.dump({"train": {}}, open(path, "wb"))
-        D.load_dataset_pkl(path)
     with pytest.raises(SystemExit):       # no checkpoint and not synthetic: refuse, do not invent weights
         train_retriever.main(["--dataset_code", "beauty", "--data_root", str(tmp_path / "data"), "--eval_only",
                               "--export_root", str(tmp_path / "nowhere")])
+    with pytest.raises(ValueError, match="missing key"):
+        pickle.dump({"train": {}}, open(path, "wb"))
+        D.load_dataset_pkl(path)

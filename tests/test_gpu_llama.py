@@ -423,3 +423,30 @@ def test_full_width_parity_vs_oracle():
         assert decided.sum() > 100          # the check is not vacuous
         assert (np.sign(d_ref[decided]) == np.sign(d_got[decided])).all()
     assert float(np.abs(ref).max()) > 0.5    # O(1) scores: the tolerance is a relative statement too
+
+
+def test_folded_rmsnorm_matches_separate_pass_and_oracle(golden_dir):
+    """lr_llama_set_folded_norms: norm weights multiplied into wqkv / wgu at load, rstd applied in the GEMM epilogue.
+    Same scores as the separate RMSNorm pass up to bf16 rounding points, both within the oracle tolerance (HF body,
+    model/llm.py:89-100), for the MFMA kernels (tiny_hd128: every projection on the 256-wide tile path), the generic
+    kernels (tiny_hd16, tiny_gqa) and latency mode (split-K reduce epilogues). Norm weights are 1 + U(0.1) here."""
+    from llamarec_amd.llm import LlamaRanker
+    from oracle import llama_oracle as LO
+
+    for name in ("tiny_hd128", "tiny_hd16", "tiny_gqa"):
+        z, cfg, sd, seqs = load_golden(golden_dir, name)
+        model = LlamaRanker.from_state_dict(sd, cfg)
+        assert model.fold_norms
+        folded = model.last_logits(seqs).cpu().numpy()
+        plain = model.set_fold_norms(False).last_logits(seqs).cpu().numpy()
+        orc = LO.last_logits(sd, cfg, seqs, "bf16")
+        assert np.abs(folded - plain).max() < 2e-2 and not np.array_equal(folded, plain), name
+        assert np.abs(folded - orc).max() < 3e-2 and np.abs(plain - orc).max() < 3e-2, name
+        assert np.abs(folded - z["logits_bf16"]).max() < 3e-2, name          # the reference's own bf16 run
+        if name == "tiny_hd128":
+            lat = model.set_fold_norms(True).set_variants(5, 0).last_logits(seqs).cpu().numpy()
+            assert np.abs(lat - orc).max() < 3e-2
+    # the fold itself: out[j][k] = bf16(w[j][k] * norm[k]) exactly
+    w = model._tensors["0.wqkv"].float().cpu().numpy()
+    nw = model._tensors["0.input_norm"].float().cpu().numpy()
+    assert np.array_equal(model._tensors["0.wqkv_folded"].float().cpu().numpy(), bf16_round(w * nw[None, :]))
