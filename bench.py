@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--users-per-step", type=int, default=0, help="> 0: the reference's fixed-size batches "
                     "(config.py:98: 16, ML-100k 32) instead of token-budget batches")
     ap.add_argument("--no-shared-prefix", action="store_true", help="do not compute the prompts' common template prefix once per step")
+    ap.add_argument("--fold-norms", action="store_true", help="A/B only: RMSNorm folded into the QKV and gate/up GEMMs "
+                    "(LlamaRanker.set_fold_norms; not the default because it leaves the reference's rounding points)")
     ap.add_argument("--layers", type=int, default=32, help="Llama layers (32 = Llama-2-7b; other values are for profiling only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that reuses it)")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the short ML-100k-shape and LoRA-step side measurements")
@@ -292,6 +294,8 @@ def main():
     retriever = LRURec.from_state_dict(lru_sd, device=dev)
     cfg = dict(LLAMA2_7B, num_hidden_layers=args.layers)
     ranker = LlamaRanker.random_init(cfg, seed=42, device=dev)
+    if args.fold_norms:
+        ranker.set_fold_norms(True)
     label_ids = list(range(319, 339))  # stand-in ids of "A".."T" (taken from the tokenizer at run time in real use)
     pipe = TwoStagePipeline(retriever, ranker, label_ids, device=dev, shared_prefix=shared)
 
@@ -376,7 +380,7 @@ def main():
                        "shared_prompt_prefix_tokens": float(np.mean([steps[i % nb]["prefix"] for i in range(args.steps)])),
                        "users_per_step": users_rank / args.steps, "mean_prompt_tokens_per_step": tok_rank / args.steps,
                        "mean_rows_per_step": rows_rank / args.steps,
-                       "llama_layers": args.layers, "parallelism": f"dp{world}", "collective_backend": args.dist_backend or "nccl"},
+                       "rmsnorm_folded_into_gemm": bool(args.fold_norms), "llama_layers": args.layers, "parallelism": f"dp{world}", "collective_backend": args.dist_backend or "nccl"},
             "roofline": roofline, "stage1_only_users_per_s": stage1_users_per_s,
             "prefill_algorithmic_tflops_per_gpu": alg_flops / elapsed / 1e12,
             "metrics": {"retrieve_NDCG@10": retr["NDCG@10"], "rerank_overall_NDCG@10": rer["NDCG@10"],

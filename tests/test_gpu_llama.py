@@ -413,6 +413,11 @@ def test_full_width_parity_vs_oracle():
     label_ids = list(range(319, 339))
     ref = LO.prefill_verbalize(sd, cfg, seqs, label_ids, "bf16")
     model = LlamaRanker.from_state_dict(sd, cfg)
+    # the opt-in folded RMSNorm is a different (not worse in exact arithmetic) set of bf16 rounding points: at this width
+    # it sits 2-3x further from the oracle than the default path, which is why it is not the default (measured 0.074)
+    folded = model.set_fold_norms(True).prefill_verbalize(seqs, label_ids).cpu().numpy()
+    model.set_fold_norms(False)
+    assert np.isfinite(folded).all() and np.abs(folded - ref).max() <= 5 * TOL
     for share in (False, True):
         got = model.prefill_verbalize(seqs, label_ids, share_prefix=share).cpu().numpy()
         assert np.isfinite(got).all()
@@ -436,17 +441,19 @@ def test_folded_rmsnorm_matches_separate_pass_and_oracle(golden_dir):
     for name in ("tiny_hd128", "tiny_hd16", "tiny_gqa"):
         z, cfg, sd, seqs = load_golden(golden_dir, name)
         model = LlamaRanker.from_state_dict(sd, cfg)
-        assert model.fold_norms
-        folded = model.last_logits(seqs).cpu().numpy()
-        plain = model.set_fold_norms(False).last_logits(seqs).cpu().numpy()
+        assert not model.fold_norms                       # opt-in (parity first, see LlamaRanker.fold_norms)
+        plain = model.last_logits(seqs).cpu().numpy()
+        folded = model.set_fold_norms(True).last_logits(seqs).cpu().numpy()
         orc = LO.last_logits(sd, cfg, seqs, "bf16")
         assert np.abs(folded - plain).max() < 2e-2 and not np.array_equal(folded, plain), name
         assert np.abs(folded - orc).max() < 3e-2 and np.abs(plain - orc).max() < 3e-2, name
         assert np.abs(folded - z["logits_bf16"]).max() < 3e-2, name          # the reference's own bf16 run
         if name == "tiny_hd128":
-            lat = model.set_fold_norms(True).set_variants(5, 0).last_logits(seqs).cpu().numpy()
+            lat = model.set_variants(5, 0).last_logits(seqs).cpu().numpy()
             assert np.abs(lat - orc).max() < 3e-2
-    # the fold itself: out[j][k] = bf16(w[j][k] * norm[k]) exactly
-    w = model._tensors["0.wqkv"].float().cpu().numpy()
-    nw = model._tensors["0.input_norm"].float().cpu().numpy()
-    assert np.array_equal(model._tensors["0.wqkv_folded"].float().cpu().numpy(), bf16_round(w * nw[None, :]))
+        # the fold itself: out[j][k] = bf16(w[j][k] * norm[k]) exactly
+        w = model._tensors["0.wqkv"].float().cpu().numpy()
+        nw = model._tensors["0.input_norm"].float().cpu().numpy()
+        assert np.array_equal(model._tensors["0.wqkv_folded"].float().cpu().numpy(), bf16_round(w * nw[None, :]))
+        again = model.set_variants(0, 0).set_fold_norms(False).last_logits(seqs).cpu().numpy()
+        assert np.array_equal(again, plain) and "0.wqkv_folded" not in model._tensors
