@@ -45,7 +45,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-STAGE2_TOL = 3e-2          # |GPU - oracle| bound on the O(1) verbalizer scores (bf16 path), as in tests/
+STAGE2_TOL = 3e-2          # floor of the |GPU - oracle| bound on the O(1) verbalizer scores; at full width the bound is
+                           # 2 x the bf16 oracle's own distance from its fp32 mode on the same sample (tests/test_gpu_llama.py)
 # SURVEY.md section 6 / BASELINE.md section 2: the REFERENCE code's own stage-1 CPU path (model/lru.py + masking +
 # top-20 of trainer/lru.py), torch 2.10 CPU, 8 cores, measured in the survey container (not on the GPU box)
 REFERENCE_CODE_STAGE1_USERS_PER_S = {"ml-100k": 242.0, "beauty": 554.0, "games": 1706.0}
@@ -152,6 +153,7 @@ def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retrie
     t0 = time.perf_counter()
     o_scores = LO.prefill_verbalize(sd, cfg, seqs, label_ids, mode="bf16")
     t2 = time.perf_counter() - t0
+    o_exact = LO.prefill_verbalize(sd, cfg, seqs, label_ids, mode="fp32")   # untimed: the yardstick of the parity block
     s2_per_user = t2 / len(seqs) * (32 / cfg["num_hidden_layers"])
     base = {
         "value": 1.0 / (s1_per_user + s2_per_user), "unit": "users/s", "kind": "port",
@@ -173,22 +175,27 @@ def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retrie
     g_scores = small.prefill_verbalize(seqs, label_ids).cpu().numpy()
     del small
     err = float(np.abs(g_scores - o_scores).max())
+    # Two bf16 evaluations of a 4096-wide network decorrelate after one layer (profiles/r02_parity_growth_full_width.txt):
+    # the bound is twice the bf16 oracle's own distance from exact (fp32) arithmetic on this sample
+    gap = float(np.abs(o_scores - o_exact).max())
+    tol = max(STAGE2_TOL, 2 * gap)
     # ordering of the 20 candidate scores: every pair the oracle separates by more than 2 x tolerance must agree
     d_o = o_scores[:, :, None] - o_scores[:, None, :]
     d_g = g_scores[:, :, None] - g_scores[:, None, :]
-    decided = np.abs(d_o) > 2 * STAGE2_TOL
+    decided = np.abs(d_o) > 2 * tol
     agree = float((np.sign(d_o[decided]) == np.sign(d_g[decided])).mean()) if decided.any() else 1.0
     lab2 = np.arange(len(seqs)) % 20  # stand-in answer letters for an NDCG@10 of the two rankings
     parity = {
         "stage1_users": int(len(hist_ids)), "stage1_top50_equal": bool(np.array_equal(g_top, o_top)),
         "stage1_ndcg10_gpu": ndcg_at_10(g_top, labels), "stage1_ndcg10_oracle": ndcg_at_10(o_top, labels),
         "stage2_prompts": len(seqs), "stage2_layers": cfg["num_hidden_layers"], "stage2_width": cfg["hidden_size"],
-        "stage2_max_abs_err": err, "stage2_tolerance": STAGE2_TOL, "stage2_rank_agree": agree,
+        "stage2_max_abs_err": err, "stage2_tolerance": tol, "stage2_oracle_bf16_vs_fp32_max_abs": gap,
+        "stage2_max_abs_err_vs_fp32_oracle": float(np.abs(g_scores - o_exact).max()), "stage2_rank_agree": agree,
         "stage2_pairs_decided": int(decided.sum() // 2),
         "stage2_ndcg10_gpu": ndcg_at_10(np.argsort(-g_scores, axis=1, kind="stable"), lab2),
         "stage2_ndcg10_oracle": ndcg_at_10(np.argsort(-o_scores, axis=1, kind="stable"), lab2),
     }
-    parity["ok"] = bool(parity["stage1_top50_equal"] and err <= STAGE2_TOL and agree == 1.0)
+    parity["ok"] = bool(parity["stage1_top50_equal"] and err <= tol and agree == 1.0)
     return base, parity
 
 

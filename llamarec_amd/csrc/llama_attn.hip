@@ -172,15 +172,40 @@ __device__ unsigned long long g_attn_stamps[64 * 8];
 template <bool STAMP>
 __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
                                                               const int32_t* cu, int prefix_len, int nh, int nkv,
-                                                              int max_qblocks, float* lse) {
+                                                              int max_qblocks, int n_pairs, float* lse) {
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   // [2 stages][K 16 KiB | V 16 KiB]; filled by LDS-DMA (lane-linear 1 KiB pieces = 4 rows x 256 B),
   // the XOR swizzles are applied to the SOURCE chunk: position p of row r holds chunk p ^ s(r).
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hd = 128;
-  const int seg = blockIdx.z, h = blockIdx.y;
-  const int qb = max_qblocks - 1 - (int)blockIdx.x;  // heavy (late) query blocks first
+  // ---- workgroup -> (segment, head, query tile). A (segment, head) PAIR is bound to one of 8 dispatch streams
+  // (blocks b and b + 8 are observed to share an XCD: speed only, never correctness), so the 3..12 query tiles that
+  // re-read one pair's K/V hit that XCD's L2; inside a stream the pairs' heavy tiles (qb >= 2, heaviest first) run pair
+  // after pair, and the two lightest tiles of every pair are kept for the end, where they fill the tail of the launch
+  // (a causal tile costs ~ its key-block count 2 qb + 2: launched last, a heavy tile would leave most CUs idle).
+  int seg, h, qb;
+  {
+    const int id = blockIdx.x, stream = id & 7, j = id >> 3;
+    const int ppx = (n_pairs + 7) >> 3;                  // pairs per stream
+    const int n_light = min(max_qblocks, 2), n_heavy = max_qblocks - n_light;
+    int pl;
+    if (j < ppx * n_heavy) {
+      pl = j / n_heavy;
+      qb = max_qblocks - 1 - j % n_heavy;
+    } else {
+      const int j2 = j - ppx * n_heavy;
+      pl = j2 / n_light;
+      qb = n_light - 1 - j2 % n_light;
+    }
+    const int pair = pl * 8 + stream;
+    if (pair >= n_pairs) return;
+    // the integer divisions above run on the vector ALU (there is no scalar divide): hand the wave-uniform results
+    // back to scalar registers, or every buffer descriptor built from them is wrapped in a waterfall loop
+    seg = __builtin_amdgcn_readfirstlane(pair / nh);
+    h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
+    qb = __builtin_amdgcn_readfirstlane(qb);
+  }
   const int tok0 = cu[seg];
   const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;  // keys [0, P) live in segment 0's rows [0, P)
   const int T = P + cu[seg + 1] - tok0;                        // sequence length, prefix included
@@ -188,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int quad = lane >> 4, li = lane & 15;
-  const int kvh = h / (nh / nkv);
+  const int kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
   const int stride = (nh + 2 * nkv) * hd;
   const int vtok0 = tok0 - P;  // the row of position p >= P is vtok0 + p (tok0 >= P: segment 0 precedes it)
   const u16* kbase = qkv + (size_t)vtok0 * stride + (nh + kvh) * hd;
@@ -224,9 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   // ---- DMA staging: 16 pieces per tile (4 rows each); wave w moves pieces 4w..4w+3 of K and of V
   const int prow = lane >> 4, ppos = lane & 15;
   // per-lane byte offsets of this wave's 4 K pieces and 4 V pieces inside a key block (row and swizzled chunk are
-  // block-invariant): a full block then costs one 64-bit add per DMA, and only the sequence's last, ragged block
-  // (per-row clamp to T - 1) and the blocks that hold shared-prefix keys (rows < P come from segment 0) pay per-row
-  // addressing (a wave-uniform branch: as selects inside one loop hipcc predicates every block)
+  // block-invariant)
   unsigned koff[4], voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -234,17 +257,28 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     koff[i] = (unsigned)(row * stride + (ppos ^ (row & 15)) * 8) * 2u;
     voff[i] = (unsigned)(row * stride + (ppos ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 8) * 2u;
   }
+  // A block that lies inside the segment's own rows is fetched through a per-block buffer descriptor: base = the
+  // block's first K (V) row, num_records = the bytes up to the end of the segment's last row, so rows past the sequence
+  // end are range-checked to ZERO by the hardware (those keys are causally masked for every stored query row: P = 0
+  // exactly, whatever finite bytes K and V hold -- same bits as fetching a clamped row). Descriptor, LDS base (M0) and
+  // block offset are scalar work; the per-lane offsets koff / voff are block-invariant: no vector ALU in the staging.
   auto stage = [&](int kb, int buf) {
     char* base = smem + buf * FA_STAGE_BYTES + wave * 4096;
-    if ((kb + 1) * FA_KB <= T && kb * FA_KB >= P) {
-      const char* kblk = reinterpret_cast<const char*>(kbase) + (size_t)kb * FA_KB * stride * 2;
-      const char* vblk = reinterpret_cast<const char*>(vbase) + (size_t)kb * FA_KB * stride * 2;
+    if (kb * FA_KB >= P) {
+      const size_t blk_off = (size_t)kb * FA_KB * stride * 2;
+      const int records = ((T - 1 - kb * FA_KB) * stride + hd) * 2;  // bytes from the block's first K (V) element
+      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(kbase) + blk_off), 0, records, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(vbase) + blk_off), 0, records, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        attn_glds16(kblk + koff[i], base + i * 1024);
-        attn_glds16(vblk + voff[i], base + FA_TILE_BYTES + i * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(base + i * 1024), 16,
+                                                 koff[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(base + FA_TILE_BYTES + i * 1024),
+                                                 16, voff[i], 0, 0, 0);
       }
-    } else {
+    } else {  // the block holds shared-prefix keys: rows < P come from segment 0 (per-lane addresses)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 4 + prow;
@@ -392,22 +426,34 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   for (int qt = 0; qt < 2; ++qt) {
     const float l = fa_sum_xor16_32(l_run[qt]);
     const float inv = 1.0f / l;
-    if (qabs[qt] < T && qabs[qt] >= P) {
-      if (lse && quad == 0)  // natural-log log-sum-exp of the scaled scores, kept for the backward pass
-        lse[(size_t)(vtok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
-      u16* op = out + (size_t)(vtok0 + qabs[qt]) * nh * hd + h * hd + quad * 4;
+    if (qabs[qt] < T && qabs[qt] >= P && lse && quad == 0)  // natural-log log-sum-exp of the scaled scores (backward pass)
+      lse[(size_t)(vtok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+    // A lane holds d = 16 dt + 4 quad + r of its row: 8 bytes per tile. v_permlane16_swap (vdst rows 1 / 3 <-> src rows
+    // 0 / 2 of 16 lanes) on the packed tiles (2k, 2k+1) leaves even quads with d = 8 (quad/2) .. +7 of tile 2k and odd
+    // quads with the same of tile 2k + 1: 4 x 16-byte stores per row instead of 8 x 8 bytes (the tail is store-ISSUE
+    // bound). Every lane takes part in the swaps; only rows of this segment store.
+    const bool live = qabs[qt] < T && qabs[qt] >= P;
+    u16* op = out + (size_t)(vtok0 + (live ? qabs[qt] : P)) * nh * hd + h * hd + (quad & 1) * 16 + (quad >> 1) * 8;
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        u16x4 o;
+    for (int k = 0; k < 4; ++k) {
+      unsigned a[2], b[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(ot[qt][dt][r] * inv);
-        *reinterpret_cast<u16x4*>(op + dt * 16) = o;
+      for (int w = 0; w < 2; ++w) {
+        a[w] = (unsigned)f2bf(ot[qt][2 * k][2 * w] * inv) | ((unsigned)f2bf(ot[qt][2 * k][2 * w + 1] * inv) << 16);
+        b[w] = (unsigned)f2bf(ot[qt][2 * k + 1][2 * w] * inv) | ((unsigned)f2bf(ot[qt][2 * k + 1][2 * w + 1] * inv) << 16);
+        const auto sw = __builtin_amdgcn_permlane16_swap(a[w], b[w], false, false);
+        a[w] = sw[0];
+        b[w] = sw[1];
+      }
+      if (live) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(op + k * 32) = u32x4{a[0], a[1], b[0], b[1]};
       }
     }
   }
   if (STAMP) {
     FA_STAMP(6)  // epilogue
-    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int wg = blockIdx.x;
     if (wg < 64 && tid == 0) {
       stamp_acc[7] = kb_last + 1;
 #pragma unroll
@@ -464,6 +510,12 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 2 needs head_dim 128 (got %d)", hd);
     const int mq = (maxT + FA_QROWS - 1) / FA_QROWS;
     if (mq == 0) return LR_OK;
+    const long long n_pairs_ll = (long long)B * nh, grid_ll = 8 * ((n_pairs_ll + 7) / 8) * mq;
+    if (grid_ll > 0x7fffffffLL) LR_FAIL(LR_EUNSUPPORTED, "attention: %lld workgroups exceed the grid limit", grid_ll);
+    if ((long long)n_tok * (nh + 2 * nkv) * hd * 2 > 0x7fffffffLL * 2)
+      LR_FAIL(LR_EUNSUPPORTED, "attention: packed qkv of %d tokens exceeds the 4 GiB a buffer descriptor addresses", n_tok);
+    const int n_pairs = (int)n_pairs_ll;
+    const unsigned grid = (unsigned)grid_ll;
     static bool lds_set[LR_MAX_DEVICES] = {};
     if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<false>), 2 * FA_STAGE_BYTES, lds_set))
       return rc;
@@ -474,12 +526,12 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
       if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<true>), 2 * FA_STAGE_BYTES,
                                          lds_set_stamp))
         return rc;
-      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
-                         prefix_len, nh, nkv, mq, lse);
+      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(grid), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
+                         prefix_len, nh, nkv, mq, n_pairs, lse);
     } else
 #endif
-      hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(mq, nh, B), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
-                         prefix_len, nh, nkv, mq, lse);
+      hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(grid), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
+                         prefix_len, nh, nkv, mq, n_pairs, lse);
     LR_CHECK_LAUNCH("attn_mfma128_kernel");
   } else if (variant == 1) {
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);

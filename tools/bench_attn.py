@@ -1,21 +1,46 @@
-"""Stand-alone timing of the varlen flash-attention kernel at the bench's shape (32 prompts x 460 tokens, 32 heads x 128)."""
+"""Stand-alone timing of the varlen flash-attention kernel (32 heads x 128) at the bench's shapes:
+   python tools/bench_attn.py            -> 32 x 460 tokens (ML-100k step), 16 x 740 (Beauty reference batch), and a
+                                            token-budget Beauty step (about 23 prompts of 565..1125 tokens, 16 384 rows)
+   python tools/bench_attn.py B T [VAR]  -> B prompts of T tokens"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd._lib import check, lib, stream_ptr
-B, T, nh, hd = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 460, 32, 128
-VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-g = torch.Generator(device="cuda"); g.manual_seed(0)
-qkv = (torch.randn(B * T, 3 * nh * hd, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
-out = torch.empty(B * T, nh * hd, dtype=torch.bfloat16, device="cuda")
-cu_h = np.arange(B + 1, dtype=np.int32) * T
-cu = torch.from_numpy(cu_h).cuda(); l = lib()
-run = lambda: check(l.lr_attention_varlen(qkv.data_ptr(), out.data_ptr(), cu.data_ptr(), cu_h.ctypes.data, B, nh, nh, hd, VAR, stream_ptr()), "attn")
-for _ in range(3): run()
-torch.cuda.synchronize()
-t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-t0.record()
-for _ in range(20): run()
-t1.record(); torch.cuda.synchronize()
-us = t0.elapsed_time(t1) * 50
-print("attention variant %d B=%d T=%d: %.1f us, %.0f TF/s (causal flops)" % (VAR, B, T, us, B * 4 * nh * hd * (T * (T + 1) / 2) / us / 1e6))
+
+nh, hd = 32, 128
+
+
+def run(lens, var=0, name=""):
+    lens = np.asarray(lens, dtype=np.int64)
+    B, n = len(lens), int(lens.sum())
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    qkv = (torch.randn(n, 3 * nh * hd, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    out = torch.empty(n, nh * hd, dtype=torch.bfloat16, device="cuda")
+    cu_h = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cu = torch.from_numpy(cu_h).cuda(); l = lib()
+    call = lambda: check(l.lr_attention_varlen(qkv.data_ptr(), out.data_ptr(), cu.data_ptr(), cu_h.ctypes.data, B, nh, nh, hd, var, stream_ptr()), "attn")
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(10): call()
+        t1.record(); torch.cuda.synchronize()
+        ts.append(t0.elapsed_time(t1) * 100)
+    us = float(np.median(ts))
+    fl = float((4.0 * nh * hd * (lens * (lens + 1) / 2)).sum())
+    print("attention variant %d %s B=%d tokens=%d: %.1f us (min %.1f), %.0f TF/s (causal flops)" % (var, name, B, n, us, min(ts), fl / us / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2:
+        run([int(sys.argv[2])] * int(sys.argv[1]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    else:
+        from llamarec_amd.packing import token_budget_steps
+        from llamarec_amd.synth import synth_users
+        run([460] * 32, name="ml-100k step (32 x 460)")
+        run([740] * 16, name="beauty reference batch (16 x 740)")
+        T = synth_users("beauty", 100)[3]
+        run(T[token_budget_steps(T)[0]], name="beauty token-budget step")
+        run([1000] * 16, name="16 x 1000")
