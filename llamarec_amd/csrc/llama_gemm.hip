@@ -471,6 +471,22 @@ static int splitk_factor(int M, int N, int K) {
   return S < 2 ? 1 : S;
 }
 
+// tile raster: M tiles per group (llama_gemm.hip header). An XCD's 32 concurrent workgroups form a group_m x (32 / group_m)
+// block of tiles that marches along N: every step of that march re-reads the group's A panels (group_m x 256 rows x K)
+// and reads 32 / group_m new B panels, so the bytes an XCD's L2 pulls per tile are (group_m + 32 / group_m) / 32 of a
+// tile's operand bytes: minimal at 4 x 8 or 8 x 4. Measured at M = 16384 (tools/gpu_gemm_groupm.sh): 8 is best for the
+// K = 4096 products, 4 (shorter A panels stay closer to the 4 MiB L2) for down_proj's K = 11008 (+3 %).
+// LR_GEMM_GROUP_M overrides it for tuning runs only.
+static int gemm256_group_m(int K) {
+  static int g = -1;
+  if (g < 0) {
+    const char* e = getenv("LR_GEMM_GROUP_M");
+    g = e ? atoi(e) : 0;
+    if (g < 0) g = 0;
+  }
+  return g ? g : (K >= 8192 ? 4 : G2_GROUP_M);
+}
+
 template <int EPI>
 static int gemm256_prepare() {
   static bool done[LR_MAX_DEVICES] = {};
@@ -484,7 +500,7 @@ static int launch_splitk(const u16* A, const u16* B, u16* C, const u16* R, int M
   if (int rc = gemm256_prepare<LR_EPI_PARTIAL>()) return rc;
   const int nwg = ((M + 255) / 256) * (N / 256);
   hipLaunchKernelGGL(gemm256rb_kernel<LR_EPI_PARTIAL>, dim3(nwg, S), dim3(512), 2 * G2_STAGE_BYTES, st, A, B,
-                     reinterpret_cast<u16*>(ws), nullptr, M, N, K, G2_GROUP_M, rope);
+                     reinterpret_cast<u16*>(ws), nullptr, M, N, K, gemm256_group_m(K), rope);
   LR_CHECK_LAUNCH("gemm256rb_kernel<partial>");
   const size_t quads = (EPI == LR_EPI_SWIGLU ? (size_t)M * (N >> 1) : (size_t)M * N) / 4;
   hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, ws, S, C, R, M,
@@ -502,7 +518,7 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
     if (int rc = gemm256_prepare<EPI>()) return rc;
     const int nwg = ((M + 255) / 256) * (N / 256);
     hipLaunchKernelGGL(gemm256rb_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
-                       G2_GROUP_M, rope);
+                       gemm256_group_m(K), rope);
     LR_CHECK_LAUNCH("gemm256rb_kernel");
   } else {
     dim3 grid((N + GG_BN - 1) / GG_BN, (M + GG_BM - 1) / GG_BM);

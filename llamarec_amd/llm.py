@@ -112,9 +112,11 @@ class LlamaRanker:
         self._ws = None
         self._layers_arr = None
         self._folded_arr = None
-        # RMSNorm folded into the next projection (set_fold_norms): OFF by default. It saves one read + write pass per norm
-        # (~1 % of a step) but drops the reference's bf16 rounding of the normalised activations, and at Llama-2-7b
-        # width that moves the scores 2-3x further from the oracle than the separate pass does
+        # RMSNorm folded into the next projection (set_fold_norms): OFF by default. Numerically it is one more valid bf16
+        # realisation (as close to the fp32 oracle as the separate pass: tools/parity_growth.py), but on this GEMM it does
+        # not pay: the norm passes it removes (2.6 ms of a 163 ms step) cost less than the rstd sweep (1.3 ms) plus the
+        # epilogue's dependent rstd load, which nothing hides at one workgroup per CU (GEMMs 1370 -> 1347 TF/s):
+        # 164.2 vs 163.5 ms per step in a same-box A/B
         self.fold_norms = False
         self.training = False
 
