@@ -1,5 +1,6 @@
 // api_lru.hip -- C ABI entry points for stage 1 (declared in include/llamarec_mi355x.h) plus the
 // library-wide error plumbing.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,6 +38,33 @@ extern "C" int lr_lru_pack(const LrLruWeightsDesc* d, void* host_out, size_t hos
   const size_t rows = (size_t)d->num_items + 1;
   memcpy(o + L.item_emb, d->item_emb, rows * 64 * sizeof(float));
   memcpy(o + L.item_bias, d->item_bias, rows * sizeof(float));
+  // The table is padded to whole 32-row tiles. A padding row is not an item: its bias is NaN, so its "score" fails every
+  // `score >= threshold` test of the top-K kernels without a row-bound check per element (item_scores_mfma_kernel
+  // never stores rows >= V + 1; fmaxf in the bound pre-pass ignores NaN).
+  for (size_t i = rows; i < (size_t)L.rows_padded; ++i) o[L.item_bias + i] = NAN;
+  {  // bf16 copy of the table (RNE) in MFMA A-FRAGMENT order and the two norms the top-K bound pre-pass needs (lru_topk.hip,
+     // item_bound_kernel): [tile][step s][lane][j] = bf16(E[32 tile + (lane & 31)][32 (lane >> 5) + 8 s + j]), so that a
+     // wave's fragment load of one MFMA step is 1 KiB of contiguous memory
+    uint16_t* e16 = reinterpret_cast<uint16_t*>(o + L.item_emb_bf16);
+    double emax = 0.0, bmax = 0.0;
+    for (size_t i = 0; i < rows; ++i) {
+      double ss = 0.0;
+      for (int k = 0; k < 64; ++k) {
+        const float v = d->item_emb[i * 64 + k];
+        ss += (double)v * (double)v;
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        const uint16_t b = (v != v) ? (uint16_t)0x7fc0 : (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        const size_t tile = i / 32, lane = (i % 32) + 32 * (size_t)(k / 32), step = (size_t)(k % 32) / 8, j = (size_t)k % 8;
+        e16[((tile * 4 + step) * 64 + lane) * 8 + j] = b;
+      }
+      const double nrm = sqrt(ss), ab = fabs((double)d->item_bias[i]);
+      if (nrm > emax || nrm != nrm) emax = nrm;
+      if (ab > bmax || ab != ab) bmax = ab;
+    }
+    o[L.item_stats + 0] = nextafterf((float)emax, INFINITY);
+    o[L.item_stats + 1] = nextafterf((float)bmax, INFINITY);
+  }
   memcpy(o + L.emb_ln_w, d->emb_ln_w, 64 * sizeof(float));
   memcpy(o + L.emb_ln_b, d->emb_ln_b, 64 * sizeof(float));
   for (int b = 0; b < d->num_blocks; ++b) {
@@ -110,12 +138,12 @@ static int encode(lr_lru_t* h, const int64_t* ids, int B, int L, float* q, void*
 }
 
 extern "C" size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k, int32_t max_len) {
-  (void)h;
   if (max_users < 1) max_users = 1;
   if (max_k < 1) max_k = 1;
   if (max_len < 1) max_len = 1;
   // [q | encoder scratch or top-K scratch (never live together)]
-  const size_t enc = lr_encoder_mfma_workspace_bytes(max_users, max_len), tk = lr_topk_workspace_bytes(max_users, max_k, max_len);
+  const size_t enc = lr_encoder_mfma_workspace_bytes(max_users, max_len),
+               tk = lr_topk_workspace_bytes(max_users, max_k, max_len, h ? h->lay.rows_padded / LR_ITEM_TILE : 0);
   return q_bytes(max_users) + (enc > tk ? enc : tk);
 }
 

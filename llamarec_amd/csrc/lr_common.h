@@ -67,6 +67,8 @@ struct LrLruLayout {
   int32_t num_blocks;
   size_t item_emb;       // [rows_padded][64]
   size_t item_bias;      // [rows_padded]
+  size_t item_emb_bf16;  // [rows_padded][64] bfloat16 (round-to-nearest-even copy of item_emb): the top-K bound pre-pass
+  size_t item_stats;     // [0] >= max_i ||item_emb[i]||_2, [1] >= max_i |item_bias[i]|  (rounded up)
   size_t emb_ln_w, emb_ln_b;
   LrLruBlockLayout blk[LR_MAX_LRU_BLOCKS];
   size_t total_floats;
@@ -85,6 +87,8 @@ static inline LrLruLayout lr_lru_layout(int32_t num_items, int32_t num_blocks) {
   };
   L.item_emb = take((size_t)L.rows_padded * 64);
   L.item_bias = take((size_t)L.rows_padded);
+  L.item_emb_bf16 = take((size_t)L.rows_padded * 32);
+  L.item_stats = take(64);
   L.emb_ln_w = take(64);
   L.emb_ln_b = take(64);
   for (int b = 0; b < LR_MAX_LRU_BLOCKS; ++b) {
@@ -126,7 +130,7 @@ int lr_launch_lru_encode(const lr_lru* h, const int64_t* ids, int B, int L, floa
 size_t lr_encoder_mfma_workspace_bytes(int B, int L);
 int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L, float* out_q, void* ws,
                               size_t ws_bytes, hipStream_t st);
-size_t lr_topk_workspace_bytes(int B, int K, int L);
+size_t lr_topk_workspace_bytes(int B, int K, int L, int n_tiles);
 int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int B, int L, int K,
                         int exclude_history, int32_t* out_idx, float* out_score, void* ws,
                         size_t ws_bytes, hipStream_t st);

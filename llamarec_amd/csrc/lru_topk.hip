@@ -47,6 +47,9 @@ struct TopkParams {
   int B, L, K, exclude;
   int tiles_per_chunk, n_chunks;
   unsigned long long* partial;  // [B][n_chunks][K] rank keys, best first, 0 = empty
+  const float* thresh;          // [B] proven lower bounds of every user's K-th best eligible score (bound pre-pass), or null
+  const int* run_flag;          // null: always run. Else the kernel is the FALLBACK of the candidate path and runs only
+                                // if *run_flag != 0 (some user's candidate list overflowed)
 };
 
 // ---- pre-pass: ascending sort of each user's history ids (LDS bitonic sort, one WG per user) ----
@@ -76,6 +79,27 @@ __global__ __launch_bounds__(256) void hist_sort_kernel(const int64_t* ids, int 
     }
   }
   for (int i = threadIdx.x; i < L; i += 256) out[(size_t)u * L + i] = sk[i];
+}
+
+// The same for L <= 64 (every BASELINE shape but ML-100k): one WAVE per user, the 64 ids in one register per lane, a
+// bitonic network of 21 compare-exchange steps over __shfl_xor -- no LDS, no barriers, 4 users per workgroup.
+__global__ __launch_bounds__(256) void hist_sort_wave_kernel(const int64_t* ids, int B, int L, int n_rows, int32_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= B) return;
+  const long long v = lane < L ? ids[(size_t)u * L + lane] : -1;
+  int x = (v >= 0 && v < n_rows) ? (int)v : INT_MAX;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int y = __shfl_xor(x, j, 64);
+      const bool up = (lane & k) == 0;           // ascending block
+      const bool lower = (lane & j) == 0;        // this lane keeps the smaller of the pair in an ascending block
+      x = (lower == up) ? min(x, y) : max(x, y);
+    }
+  }
+  if (lane < L) out[(size_t)u * L + lane] = x;
 }
 
 // ---- wave-cooperative helpers on one user's candidate buffer ---------------------------------
@@ -161,6 +185,7 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
   float* btile = etile + 2 * 32 * TK_ESTRIDE;                         // [4][32]
   unsigned long long* buf = reinterpret_cast<unsigned long long*>(btile + 128);  // [128][BSTRIDE]
 
+  if (p.run_flag && *p.run_flag == 0) return;  // wave-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
   // (the K-th best seen at the last compaction; +inf for users past B: nothing ever passes)
   unsigned long long* mine = buf + u_local * TK_BSTRIDE + half * 64;
   int pos = 0;
-  float thf = user_ok ? -__builtin_inff() : __builtin_inff();
+  float thf = user_ok ? (p.thresh ? p.thresh[user] : -__builtin_inff()) : __builtin_inff();
   // sorted-history cursor of this lane's user (kept by the half-0 lane): first entry >= chunk start
   const bool walker = p.exclude && half == 0 && user_ok;
   const int32_t* hs = p.hist_sorted + (size_t)(user_ok ? user : 0) * p.L;
@@ -270,28 +295,39 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
   //     user's threshold is appended to the lane's own candidate list (no atomics);
   //   * has tile t+1's A fragments on their way from LDS into the other fragment register set;
   //   * walks the sorted history for tile t's mask (needed one iteration later).
-  floatx16 accp;  // scores (with bias) of the previous tile
+  // Two accumulator sets and two bias sets alternate between tiles: tile t's chain runs in accs[t & 1] while the filter
+  // reads the finished scores of tile t - 1 straight from accs[(t - 1) & 1] (+ that tile's bias), so the next chain's
+  // first MFMA issues right behind the previous chain's last one -- no copy-out of 16 scores between two chains.
+  floatx16 accs[2];
+  float4 bias4s[2][4];
   unsigned hmaskp = 0u;
   int tilep = 0;
   bool prev_ok = false;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+  for (int r = 0; r < 16; ++r) accs[0][r] = accs[1][r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bias4s[0][g] = bias4s[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-#define TK_ELEM(r, thv, SLOW)                                                                           \
+#define TK_BIAS(B4, r) ((r & 3) == 0 ? B4[(r) >> 2].x : (r & 3) == 1 ? B4[(r) >> 2].y : (r & 3) == 2 ? B4[(r) >> 2].z : B4[(r) >> 2].w)
+// One finished score of the previous tile. On gfx950 the f32-input MFMA runs on the f32 vector datapath, so vector ALU
+// work between the chained MFMAs is NOT free (timing ablation: the 12-instruction filter per element costs as much
+// as 0.7 of the chain). The common case is therefore two instructions -- bias add, threshold compare -- and a
+// wave-uniform branch: with a seeded or settled threshold about one element in three has ANY of its 64 lanes pass.
+// Only then: history mask (a bit test on hm = the tile's mask shifted to this lane half; a masked item keeps the
+// reference's score -1e9, trainer/lru.py:37-38, and is re-tested), rank key, append to the lane's list. Padding rows of
+// the last tile carry a NaN bias (lr_lru_pack): NaN >= threshold is false.
+#define TK_ELEM(ACC, B4, r, thv)                                                                        \
   {                                                                                                     \
-    const int row_ = ((r)&3) + 8 * ((r) >> 2) + 4 * half;                                               \
-    float v_ = accp[r];                                                                                 \
-    bool ok_;                                                                                           \
-    if (SLOW) {                                                                                         \
-      if ((hmaskp >> row_) & 1u) v_ = LR_MASK_SCORE;                                                    \
-      ok_ = v_ >= (thv) && (tilep * 32 + row_ < p.n_rows);                                              \
-    } else {                                                                                            \
-      ok_ = v_ >= (thv);                                                                                \
-    }                                                                                                   \
-    if (STAMP) stamp_acc[7] += __popcll(__ballot(ok_));                                                 \
-    if (ok_) {                                                                                          \
-      mine[pos] = lr_rank_key(v_, (uint32_t)(tilep * 32 + row_));                                       \
-      ++pos;                                                                                            \
+    const float s_ = ACC[r] + TK_BIAS(B4, r);                                                           \
+    if (__ballot(s_ >= (thv)) != 0ull) {                                                                \
+      const int rowc_ = ((r)&3) + 8 * ((r) >> 2); /* row = rowc_ + 4 * half */                          \
+      const float v_ = ((hm >> rowc_) & 1u) ? LR_MASK_SCORE : s_;                                       \
+      const bool ok_ = v_ >= (thv);                                                                     \
+      if (STAMP) stamp_acc[7] += __popcll(__ballot(ok_));                                               \
+      if (ok_) {                                                                                        \
+        mine[pos] = lr_rank_key(v_, (uint32_t)(tilep * 32 + rowc_ + 4 * half));                         \
+        ++pos;                                                                                          \
+      }                                                                                                 \
     }                                                                                                   \
   }
   // after a tile's inserts: compact every user whose list could overflow on the next tile (a lane
@@ -341,51 +377,37 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
   // body of one tile; `su` = (tile - tile_begin) & 3 is a constant after unrolling
   auto do_tile = [&](int tile, const int su) {
     TK_LOAD((su + 1) & 3, tile + 5);  // that set went to LDS one tile ago
+    // tile + 2 (loaded three tiles ago) goes to the LDS buffer of tile `tile`, whose fragments every wave read during the
+    // previous tile (the barrier that closed it separates those reads from this store); the barrier that closes THIS
+    // tile publishes it for the fragment reads of the next one. Up here the stores drain in the chain's shadow.
+    TK_WAIT_LOADS(9);  // tile + 2 has landed; tiles + 3, + 4, + 5 may still be in flight
+    TK_STORE((su + 2) & 3);
     if (tile + 1 < tile_end) TK_FRAGS(afr[(su + 1) & 1], (su + 1) & 1);
-    // this tile's bias rows (rows 8g + 4*half + 0..3 = one aligned float4 per g), added when the scores are saved
-    float4 bias4[4];
+    // this tile's bias rows (rows 8g + 4*half + 0..3 = one aligned float4 per g), added when the scores are filtered
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      bias4[g] = *reinterpret_cast<const float4*>(btile + su * 32 + 8 * g + 4 * half);
+      bias4s[su & 1][g] = *reinterpret_cast<const float4*>(btile + su * 32 + 8 * g + 4 * half);
     TK_STAMP(0)
 
     const float thv = prev_ok ? thf : __builtin_inff();
-    const bool slow = __any(hmaskp != 0u) || (tilep + 1) * 32 > p.n_rows;  // masks or rows past V: rare
+    const unsigned hm = hmaskp >> (4 * half);
     unsigned hmaskn = 0u;
-    floatx16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    if (!slow) {
+    for (int r = 0; r < 16; ++r) accs[su & 1][r] = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r], bq[2 * r], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r + 1], bq[2 * r + 1], acc, 0, 0, 0);
-        TK_ELEM(r, thv, false)
-        if (r == 15) hmaskn = walk(tile);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r], bq[2 * r], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r + 1], bq[2 * r + 1], acc, 0, 0, 0);
-        TK_ELEM(r, thv, true)
-        if (r == 15) hmaskn = walk(tile);
-      }
+    for (int r = 0; r < 16; ++r) {
+      accs[su & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r], bq[2 * r], accs[su & 1], 0, 0, 0);
+      accs[su & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[su & 1][2 * r + 1], bq[2 * r + 1], accs[su & 1], 0, 0, 0);
+      TK_ELEM(accs[(su + 1) & 1], bias4s[(su + 1) & 1], r, thv)
+      if (r == 15) hmaskn = walk(tile);
     }
-    if (STAMP) asm volatile("" ::"v"(acc));
+    if (STAMP) asm volatile("" ::"v"(accs[su & 1]));
     TK_STAMP(2)
     make_room();
     TK_STAMP(3)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 b4 = bias4[r >> 2];
-      accp[r] = acc[r] + ((r & 3) == 0 ? b4.x : (r & 3) == 1 ? b4.y : (r & 3) == 2 ? b4.z : b4.w);
-    }
     hmaskp = hmaskn;
     tilep = tile;
     prev_ok = true;
-    TK_WAIT_LOADS(9);  // tile + 2 has landed; tiles + 3, + 4, + 5 may still be in flight
-    TK_STORE((su + 2) & 3);
     TK_STAMP(4)
     __syncthreads();
     TK_STAMP(5)
@@ -396,11 +418,18 @@ __global__ __launch_bounds__(256) void item_topk_kernel(TopkParams p) {
     for (int u = 0; u < 4; ++u)
       if (base + u < tile_end) do_tile(base + u, u);
   }
-  if (prev_ok) {  // drain the pipeline: the last tile's scores
+  if (prev_ok) {  // drain the pipeline: the last tile's scores sit in the set of its parity
+    const unsigned hm = hmaskp >> (4 * half);
+    if ((tilep - tile_begin) & 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) TK_ELEM(r, thf, true)
+      for (int r = 0; r < 16; ++r) TK_ELEM(accs[1], bias4s[1], r, thf)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) TK_ELEM(accs[0], bias4s[0], r, thf)
+    }
   }
 #undef TK_ELEM
+#undef TK_BIAS
 #undef TK_LOAD
 #undef TK_STORE
 #undef TK_FRAGS
@@ -437,12 +466,363 @@ extern "C" int lr_debug_topk_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+// =============================================================================================
+// Bound pre-pass (small catalogs): a proven lower bound of every user's K-th best score, 16x cheaper than the scores
+// =============================================================================================
+// A user's threshold in item_topk_kernel only reaches the K/n quantile after n items, so a chunk pays ~ K ln(n / K)
+// list inserts and a compaction per ~23 of them per lane -- on a catalog that is ONE chunk (Beauty: 378 tiles) that
+// overhead is 3x the MFMA chain itself. The pre-pass hands the exact pass a threshold that is already (almost) final:
+//   1. item_bound_kernel scores every (user, item) APPROXIMATELY on v_mfma_f32_32x32x16_bf16 (bf16 copies of q and of
+//      the table: 4 MFMAs of 32 cycles per 32 x 32 tile instead of 32 of 64 cycles) and keeps only each tile's maximum
+//      per user: tmax[user][tile].
+//   2. bound_select_kernel takes m = the R-th largest tile maximum, R = K + (number of masked ids of the user): the R
+//      tiles hold R DIFFERENT items with approximate score >= m, at most R - K of them masked, so at least K eligible
+//      items have exact score >= m - delta, where delta bounds |approximate - exact| for every item of that user:
+//          |s~ - s| <= ((2u + u^2) + 2 gamma_65) sum_k |q_k e_k| + 2^-23 max(|s~|, |s|),   u = 2^-8, gamma_65 ~ 65 * 2^-24
+//                   <= 0.00785 ||q||_2 E_max + 2.5e-7 (||q||_2 E_max + B_max)            (Cauchy-Schwarz; E_max = max row
+//      norm of the table, B_max = max |bias|, both rounded up at pack time). T = m - delta (rounded down) is therefore
+//      <= the user's true K-th best eligible score: filtering the exact scores by `>= T` loses nothing, the ranked
+//      output is bit-identical, and only ~1.2 K items per user pass instead of ~K ln(V / K).
+// A 32-item tile maximum at rank R sits at item quantile ~ 1 - (1 - R / n_tiles)^(1/32): for Beauty (R = 59 of 378
+// tiles) 0.53 % of 12 086 items = 64 candidates per user against 275 inserts without the bound.
+typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
+
+#define TK_BUSERS 256  // users per workgroup of the pre-pass: 4 waves x 2 MFMA column tiles of 32 users
+
+struct BoundParams {
+  const unsigned short* emb16;  // bf16 table in A-fragment order [tile][step][lane][8] (lr_lru_pack)
+  const float* bias;            // [rows_padded]
+  int n_rows, n_tiles;
+  const float* q;               // [B][64]
+  int B;
+  float* tmax;                  // [B][ld]
+  int ld;                       // n_tiles rounded up to 4
+  int tiles_per_chunk;          // multiple of 4
+};
+
+__global__ __launch_bounds__(256) void item_bound_kernel(BoundParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int tile_begin = blockIdx.x * p.tiles_per_chunk;
+  const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
+  if (tile_begin >= tile_end) return;
+  // B operands: q[user][k], k = 32 half + 8 s + j for MFMA step s -- the k order of the packed A fragments; any order
+  // is as good as another for a sum that only has to be APPROXIMATELY the score. Two column tiles of 32 users per
+  // wave share every A fragment.
+  int user[2];
+  tk_bf16x8 bq[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    user[c] = blockIdx.y * TK_BUSERS + wave * 64 + c * 32 + col;
+    const float4* qp = reinterpret_cast<const float4*>(p.q + (size_t)(user[c] < p.B ? user[c] : 0) * 64 + 32 * half);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 a = qp[2 * s], b = qp[2 * s + 1];
+      bq[c][s][0] = (__bf16)a.x; bq[c][s][1] = (__bf16)a.y; bq[c][s][2] = (__bf16)a.z; bq[c][s][3] = (__bf16)a.w;
+      bq[c][s][4] = (__bf16)b.x; bq[c][s][5] = (__bf16)b.y; bq[c][s][6] = (__bf16)b.z; bq[c][s][7] = (__bf16)b.w;
+    }
+  }
+  const tk_bf16x8* frag = reinterpret_cast<const tk_bf16x8*>(p.emb16) + lane;
+  for (int t4 = tile_begin; t4 < tile_end; t4 += 4) {
+    float m4[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tile = min(t4 + u, p.n_tiles - 1);   // clamped: a duplicate of the last tile is harmless (same maximum)
+      tk_bf16x8 a[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = frag[((size_t)tile * 4 + s) * 64];   // 1 KiB contiguous per wave-instruction
+      float4 b4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(p.bias + (size_t)tile * 32 + 8 * g + 4 * half);
+      const bool ragged = (tile + 1) * 32 > p.n_rows;   // rows past V + 1 are padding, not items
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[c][s], acc, 0, 0, 0);
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float bv[4] = {b4[g].x, b4[g].y, b4[g].z, b4[g].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[4 * g + e] + bv[e];
+            if (ragged && tile * 32 + 8 * g + 4 * half + e >= p.n_rows) v = -__builtin_inff();
+            m = fmaxf(m, v);
+          }
+        }
+        m4[c][u] = fmaxf(m, __shfl_xor(m, 32, 64));   // the other lane half holds the tile's other 16 items
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (user[c] < p.B && half == 0)
+        *reinterpret_cast<float4*>(p.tmax + (size_t)user[c] * p.ld + t4) = make_float4(m4[c][0], m4[c][1], m4[c][2], m4[c][3]);
+  }
+}
+
+#define TK_BOUND_MAX_TILES 2048  // 32 tile maxima per lane in bound_select_kernel (catalogs up to 65 536 items)
+
+// One wave per user: T[user] = (R-th largest of tmax[user][0..n_tiles)) - delta, R = K + masked ids; -inf if there are
+// fewer than R tiles (no bound: the exact pass then starts from -inf as it does without the pre-pass).
+template <int NS>  // NS x 64 >= n_tiles key slots per wave
+__global__ __launch_bounds__(256) void bound_select_kernel(const float* tmax, int ld, int n_tiles, const float* q,
+                                                           const int64_t* ids, int L, int n_rows, int exclude, int B, int K,
+                                                           const float* stats /*[0] E_max, [1] B_max*/, float* thresh,
+                                                           float* cand_thresh, int* cand_count, int* overflow_flag) {
+  const int lane = threadIdx.x & 63;
+  const int user = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (user >= B) return;
+  int R = K;
+  if (exclude) {  // masked: the pad id 0 and every history id inside the catalog (duplicates only loosen the bound)
+    int n = 0;
+    for (int t = lane; t < L; t += 64) {
+      const long long id = ids[(size_t)user * L + t];
+      n += (id > 0 && id < n_rows) ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) n += __shfl_xor(n, s, 64);
+    R += n + 1;
+  }
+  float qq = q[(size_t)user * 64 + lane];
+  qq *= qq;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) qq += __shfl_xor(qq, s, 64);
+  float T = -__builtin_inff(), Tc = -__builtin_inff();
+  if (user == 0 && lane == 0) *overflow_flag = 0;
+  if (R <= n_tiles) {
+    // monotone uint keys of this user's tile maxima, 32 per lane; R-th largest by bisection on the key bits
+    uint32_t key[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int t = lane + 64 * i;
+      key[i] = t < n_tiles ? lr_float_ord(tmax[(size_t)user * ld + t]) : 0u;   // 0 sorts below every float, even -inf
+    }
+    uint32_t ans = 0u;   // the largest x with count(key >= x) >= R
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t x = ans | (1u << bit);
+      int c = 0;   // wave-uniform: ballots + scalar popcounts, no cross-lane shuffles
+#pragma unroll
+      for (int i = 0; i < NS; ++i) c += __popcll(__ballot(key[i] >= x));
+      if (c >= R) ans = x;
+    }
+    const float m = lr_ord_float(ans);
+    const float e_max = stats[0], b_max = stats[1];
+    const float qn = sqrtf(qq) * 1.00001f;
+    const float delta = 0.00785f * qn * e_max + 2.5e-7f * (qn * e_max + b_max);
+    const float t = m - delta * 1.001f - fabsf(m) * 1e-6f;   // every rounding of this line moves T down, never up
+    // candidate threshold on the APPROXIMATE scores: a true top-K item has exact score >= T, hence approximate score
+    // >= T - delta (item_cand_kernel keeps every item at or above it)
+    const float tc = m - 2.0f * delta * 1.001f - fabsf(m) * 2e-6f;
+    if (ans != 0u && t == t && fabsf(t) != __builtin_inff() && tc == tc) {   // non-finite inputs: no bound
+      T = t;
+      Tc = tc;
+    }
+  }
+  if (lane == 0) {
+    thresh[user] = T;
+    cand_thresh[user] = Tc;
+    cand_count[user] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate path (the default for small catalogs): with the bound in hand the exact f32 pass over ALL items is not
+// needed at all. item_cand_kernel repeats the bf16 scoring and keeps every item whose approximate score reaches
+// T - delta (~1.5 K per user: a superset of the true top-K, see bound_select_kernel); cand_rescore_kernel scores just
+// those EXACTLY -- lr_item_score's fmaf chain, the bits of the oracle and of item_topk_kernel -- drops masked ids and
+// ranks them. If any user's list overflows TK_CAND_CAP (degenerate data: thousands of near-equal scores) a device flag
+// turns on the exact full pass (item_topk_kernel + merge, launched behind it with run_flag) for the whole call.
+#define TK_CAND_CAP 512  // candidate slots per user
+
+struct CandParams {
+  const unsigned short* emb16;
+  const float* bias;
+  int n_tiles;
+  const float* q;
+  int B;
+  const float* cand_thresh;  // [B]
+  int* cand_count;           // [B]
+  int32_t* cand;             // [B][TK_CAND_CAP] item ids
+  int tiles_per_chunk;
+};
+
+#define TK_CAND_LCAP 48  // candidate slots per user in the workgroup's LDS list (one chunk of tiles: ~3 expected)
+
+// Passing items are collected in LDS (one list per user of the workgroup, LDS atomics only) and appended to the user's
+// global list once per workgroup: a returning global atomic per passing element inside the tile loop cost 4x the
+// scoring itself. Per element the common path is bias add + compare + one bit of a per-lane mask; one wave-uniform
+// branch per 32 x 32 tile handles the lanes that caught something.
+__global__ __launch_bounds__(256) void item_cand_kernel(CandParams p) {
+  __shared__ int lcnt[TK_BUSERS];
+  __shared__ int32_t llist[TK_BUSERS * TK_CAND_LCAP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int tile_begin = blockIdx.x * p.tiles_per_chunk;
+  const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
+  if (tile_begin >= tile_end) return;
+  lcnt[tid] = 0;
+  int user[2];
+  float thr[2];
+  tk_bf16x8 bq[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {   // the same operands, in the same order, as item_bound_kernel: the same approximate scores
+    user[c] = blockIdx.y * TK_BUSERS + wave * 64 + c * 32 + col;
+    const bool ok = user[c] < p.B;
+    thr[c] = ok ? p.cand_thresh[user[c]] : __builtin_inff();
+    const float4* qp = reinterpret_cast<const float4*>(p.q + (size_t)(ok ? user[c] : 0) * 64 + 32 * half);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 a = qp[2 * s], b = qp[2 * s + 1];
+      bq[c][s][0] = (__bf16)a.x; bq[c][s][1] = (__bf16)a.y; bq[c][s][2] = (__bf16)a.z; bq[c][s][3] = (__bf16)a.w;
+      bq[c][s][4] = (__bf16)b.x; bq[c][s][5] = (__bf16)b.y; bq[c][s][6] = (__bf16)b.z; bq[c][s][7] = (__bf16)b.w;
+    }
+  }
+  __syncthreads();
+  const tk_bf16x8* frag = reinterpret_cast<const tk_bf16x8*>(p.emb16) + lane;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    tk_bf16x8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = frag[((size_t)tile * 4 + s) * 64];
+    float4 b4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b4[g] = *reinterpret_cast<const float4*>(p.bias + (size_t)tile * 32 + 8 * g + 4 * half);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      floatx16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[c][s], acc, 0, 0, 0);
+      unsigned mask = 0u;   // bit 4 g + e: the item of accumulator register 4 g + e passed (padding rows: NaN bias, never)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float bv[4] = {b4[g].x, b4[g].y, b4[g].z, b4[g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mask |= (acc[4 * g + e] + bv[e] >= thr[c] ? 1u : 0u) << (4 * g + e);
+      }
+      if (__ballot(mask != 0u) != 0ull) {   // wave-uniform
+        if (mask) {
+          const int ul = wave * 64 + c * 32 + col;
+          int slot = atomicAdd(&lcnt[ul], __popc(mask));   // the user's two lane halves share the counter
+          do {
+            const int idx = __ffs(mask) - 1;
+            mask &= mask - 1u;
+            if (slot < TK_CAND_LCAP) llist[ul * TK_CAND_LCAP + slot] = tile * 32 + 8 * (idx >> 2) + (idx & 3) + 4 * half;
+            ++slot;
+          } while (mask);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {  // thread = one user of the workgroup: reserve room in the global list once, copy
+    const int gu = blockIdx.y * TK_BUSERS + tid;
+    const int n = lcnt[tid];
+    if (gu < p.B && n > 0) {
+      // an overflowing LDS list is reported as an overflowing global count: cand_rescore_kernel then raises the flag
+      const int base = atomicAdd(p.cand_count + gu, n > TK_CAND_LCAP ? TK_CAND_CAP + 1 : n);
+      const int m = min(n, TK_CAND_LCAP);
+      for (int i = 0; i < m; ++i)
+        if (base + i < TK_CAND_CAP) p.cand[(size_t)gu * TK_CAND_CAP + base + i] = llist[tid * TK_CAND_LCAP + i];
+    }
+  }
+}
+
+// One wave per user: exact scores of the candidates, masked ids dropped, rank by counting, ordered top-K written.
+__global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, const float* bias, const float* q,
+                                                           const int32_t* hist_sorted, int L, int exclude, int B, int K,
+                                                           const int* cand_count, const int32_t* cand, int* overflow_flag,
+                                                           int32_t* out_idx, float* out_score) {
+  __shared__ float qs[4][64];
+  __shared__ int32_t hsl[4][64];   // the user's sorted history when L <= 64 (else the search reads global memory)
+  __shared__ unsigned long long keys[4][TK_CAND_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int user = blockIdx.x * 4 + wave;
+  if (user >= B) return;
+  int n = cand_count[user];
+  if (n > TK_CAND_CAP) {   // the list is incomplete: the exact full pass behind this kernel redoes the call
+    if (lane == 0) atomicOr(overflow_flag, 1);
+    n = TK_CAND_CAP;
+  }
+  qs[wave][lane] = q[(size_t)user * 64 + lane];
+  const bool hist_in_lds = exclude && L <= 64;
+  if (hist_in_lds) hsl[wave][lane] = lane < L ? hist_sorted[(size_t)user * L + lane] : INT_MAX;
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const int32_t* hs = hist_in_lds ? hsl[wave] : hist_sorted + (size_t)user * L;
+  int valid = 0;
+  for (int c = lane; c < n; c += 64) {
+    const int item = cand[(size_t)user * TK_CAND_CAP + c];
+    bool masked = false;
+    if (exclude) {
+      masked = item == 0;
+      int lo = 0, hi = L;   // sorted ascending, INT_MAX = unused entry
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int h = hs[mid];
+        if (h < item) lo = mid + 1;
+        else hi = mid;
+      }
+      masked = masked || (lo < L && hs[lo] == item);   // (generic address space: LDS or global, same code)
+    }
+    unsigned long long key = 0ull;
+    if (!masked) {   // lr_item_score(): the one summation order stage 1 uses everywhere (lr_math.h)
+      const float4* e4 = reinterpret_cast<const float4*>(emb + (size_t)item * 64);
+      const float4* q4 = reinterpret_cast<const float4*>(qs[wave]);
+      float ev[64];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float4 v = e4[j];
+        ev[4 * j + 0] = v.x; ev[4 * j + 1] = v.y; ev[4 * j + 2] = v.z; ev[4 * j + 3] = v.w;
+      }
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {   // s = 4 j .. 4 j + 3: fma(e[32 + s], q[32 + s], fma(e[s], q[s], acc))
+        const float4 qa = q4[j], qb = q4[8 + j];
+        acc = __builtin_fmaf(ev[4 * j + 0], qa.x, acc);
+        acc = __builtin_fmaf(ev[32 + 4 * j + 0], qb.x, acc);
+        acc = __builtin_fmaf(ev[4 * j + 1], qa.y, acc);
+        acc = __builtin_fmaf(ev[32 + 4 * j + 1], qb.y, acc);
+        acc = __builtin_fmaf(ev[4 * j + 2], qa.z, acc);
+        acc = __builtin_fmaf(ev[32 + 4 * j + 2], qb.z, acc);
+        acc = __builtin_fmaf(ev[4 * j + 3], qa.w, acc);
+        acc = __builtin_fmaf(ev[32 + 4 * j + 3], qb.w, acc);
+      }
+      key = lr_rank_key(acc + bias[item], (uint32_t)item);
+      ++valid;
+    }
+    keys[wave][c] = key;
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) valid += __shfl_xor(valid, s, 64);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int j = valid + lane; j < K; j += 64) {   // fewer than K eligible candidates (overflow only): the open slots
+    out_idx[(size_t)user * K + j] = -1;
+    if (out_score) out_score[(size_t)user * K + j] = -__builtin_inff();
+  }
+  for (int c = lane; c < n; c += 64) {
+    const unsigned long long key = keys[wave][c];
+    if (key == 0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += keys[wave][j] > key ? 1 : 0;
+    if (rank < K) {
+      out_idx[(size_t)user * K + rank] = (int32_t)lr_key_item(key);
+      if (out_score) out_score[(size_t)user * K + rank] = lr_key_score(key);
+    }
+  }
+}
+
 // ---- merge: one wave per user, K rounds of "largest head wins" over <= 256 sorted lists -----
 struct MergeParams {
   const unsigned long long* partial;
   int B, K, n_chunks;
   int32_t* out_idx;
   float* out_score;
+  const int* run_flag;  // as in TopkParams
 };
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -455,6 +835,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 __global__ __launch_bounds__(256) void topk_merge_kernel(MergeParams p) {
+  if (p.run_flag && *p.run_flag == 0) return;
   const int lane = threadIdx.x & 63;
   const int user = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (user >= p.B) return;
@@ -492,6 +873,57 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeParams p) {
         ptr[i] += 1;
         hk[i] = (ptr[i] < p.K) ? base[(size_t)l * p.K + ptr[i]] : 0ull;
       }
+    }
+  }
+}
+
+// Few chunks (n_chunks * K <= TK_MERGE_KEYS): every key's final rank is its index in its own list plus, for each other
+// list, the number of keys there that beat it -- a binary search per list over LDS (lists are sorted best first, keys are
+// unique, 0 = empty and sorts last). One wave per user, no dependent global loads (the round-by-round kernel above pays
+// one per output position).
+#define TK_MERGE_KEYS 1024
+__global__ __launch_bounds__(256) void topk_merge_small_kernel(MergeParams p) {
+  __shared__ unsigned long long keys[4][TK_MERGE_KEYS];
+  if (p.run_flag && *p.run_flag == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int user = blockIdx.x * 4 + wave;
+  if (user >= p.B) return;
+  unsigned long long* k = keys[wave];
+  const int n = p.n_chunks * p.K;
+  const unsigned long long* base = p.partial + (size_t)user * n;
+  int total = 0;
+  for (int i = lane; i < n; i += 64) {
+    const unsigned long long v = base[i];
+    k[i] = v;
+    total += v != 0ull ? 1 : 0;
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) total += __shfl_xor(total, s, 64);
+  for (int j = total + lane; j < p.K; j += 64) {  // fewer than K candidates in all: the slots no key will claim
+    p.out_idx[(size_t)user * p.K + j] = -1;
+    if (p.out_score) p.out_score[(size_t)user * p.K + j] = -__builtin_inff();
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int i = lane; i < n; i += 64) {
+    const unsigned long long key = k[i];
+    if (key == 0ull) continue;
+    const int c = i / p.K;
+    int rank = i - c * p.K;
+    for (int c2 = 0; c2 < p.n_chunks && rank < p.K; ++c2) {
+      if (c2 == c) continue;
+      const unsigned long long* l = k + c2 * p.K;
+      int lo = 0, hi = p.K;  // first index whose key is < mine (keys in [0, lo) beat mine)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (l[mid] > key) lo = mid + 1;
+        else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < p.K) {
+      p.out_idx[(size_t)user * p.K + rank] = (int32_t)lr_key_item(key);
+      if (p.out_score) p.out_score[(size_t)user * p.K + rank] = lr_key_score(key);
     }
   }
 }
@@ -592,7 +1024,11 @@ __global__ void mask_history_kernel(float* scores, int n_rows, const int64_t* id
 // minimise rounds x (tiles per chunk + the per-chunk fixed cost). The fixed cost -- the unfiltered first tiles
 // while the thresholds settle, plus compaction + sort of 128 users' lists at the end -- measures ~130 tile-times
 // (Beauty sweep: 1.41 / 1.97 / 2.27 / 2.00 / 2.28 ms for 1..5 chunks = rounds x (0.36 ms + 2.8 us x tiles)).
-static void topk_geometry(int n_tiles, int B, int* n_chunks, int* tiles_per_chunk) {
+// With a seeded threshold (bound pre-pass) a chunk's fixed cost is what is left of that: the prologue and the final
+// compaction + sort (~ TK_FIXED_SEEDED tile-times), so more, shorter chunks are worth it where they fill the last round.
+#define TK_FIXED_PLAIN 128
+#define TK_FIXED_SEEDED 24
+static void topk_geometry(int n_tiles, int B, bool seeded, int* n_chunks, int* tiles_per_chunk) {
   const int n_ut = (B + TK_USERS - 1) / TK_USERS;
   int max_chunks = TK_MAX_WGS / n_ut;
   if (max_chunks > TK_MAX_CHUNKS) max_chunks = TK_MAX_CHUNKS;
@@ -604,7 +1040,7 @@ static void topk_geometry(int n_tiles, int B, int* n_chunks, int* tiles_per_chun
     const int tpc = (n_tiles + c - 1) / c;
     const int real = (n_tiles + tpc - 1) / tpc;
     const long rounds = ((long)n_ut * real + 255) / 256;
-    const long cost = rounds * (tpc + 128);
+    const long cost = rounds * (tpc + (seeded ? TK_FIXED_SEEDED : TK_FIXED_PLAIN));
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       best = c;
@@ -627,8 +1063,28 @@ static size_t partial_bytes_max(int B, int K) {
   return lr_align_up(rows * K * sizeof(unsigned long long), 256);
 }
 
-size_t lr_topk_workspace_bytes(int B, int K, int L) {
-  return partial_bytes_max(B, K) + lr_align_up((size_t)B * (L > 0 ? L : 1) * sizeof(int32_t), 256);
+// the bound pre-pass runs for catalogs of TK_BOUND_MIN_TILES .. TK_BOUND_MAX_TILES tiles (LR_TOPK_BOUND=0 switches it off)
+#define TK_BOUND_MIN_TILES 64
+// ... and only where EVERY user is sure to get a bound: rank R = K + masked ids <= K + L + 1 must not exceed the tile count
+// (ML-100k: L = 200 against 115 tiles -- its users keep the exact full pass)
+static bool bound_enabled(int n_tiles, int K, int L) {
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("LR_TOPK_BOUND");
+    env = (e && e[0] == '0') ? 0 : 1;
+  }
+  return env && n_tiles >= TK_BOUND_MIN_TILES && n_tiles <= TK_BOUND_MAX_TILES && K + L + 1 <= n_tiles;
+}
+// tmax [B][ld] | thresh [B] | cand_thresh [B] | cand_count [B] + overflow flag | cand [B][TK_CAND_CAP]
+static size_t bound_bytes(int B, int n_tiles) {
+  const size_t ld = lr_align_up((size_t)n_tiles, 4);
+  return lr_align_up((size_t)B * ld * sizeof(float), 256) + 2 * lr_align_up((size_t)B * sizeof(float), 256) +
+         lr_align_up(((size_t)B + 1) * sizeof(int), 256) + lr_align_up((size_t)B * TK_CAND_CAP * sizeof(int32_t), 256);
+}
+
+size_t lr_topk_workspace_bytes(int B, int K, int L, int n_tiles) {
+  return partial_bytes_max(B, K) + lr_align_up((size_t)B * (L > 0 ? L : 1) * sizeof(int32_t), 256) +
+         (bound_enabled(n_tiles, K, L) ? bound_bytes(B, n_tiles) : 0);
 }
 
 int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int B, int L, int K,
@@ -645,23 +1101,88 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
   p.L = L;
   p.K = K;
   p.exclude = exclude_history ? 1 : 0;
-  topk_geometry(p.n_tiles, B, &p.n_chunks, &p.tiles_per_chunk);
+  const bool seeded = bound_enabled(p.n_tiles, K, L);
+  topk_geometry(p.n_tiles, B, seeded, &p.n_chunks, &p.tiles_per_chunk);
   const size_t need_partial = lr_align_up((size_t)B * p.n_chunks * K * sizeof(unsigned long long), 256);
   const size_t need_hist = p.exclude ? lr_align_up((size_t)B * L * sizeof(int32_t), 256) : 0;
-  if (need_partial + need_hist > ws_bytes)
-    LR_FAIL(LR_EWORKSPACE, "top-K workspace: need %zu bytes, have %zu", need_partial + need_hist, ws_bytes);
+  const size_t need_bound = seeded ? bound_bytes(B, p.n_tiles) : 0;
+  if (need_partial + need_hist + need_bound > ws_bytes)
+    LR_FAIL(LR_EWORKSPACE, "top-K workspace: need %zu bytes, have %zu", need_partial + need_hist + need_bound, ws_bytes);
   p.partial = reinterpret_cast<unsigned long long*>(ws);
   int32_t* hist_sorted = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + need_partial);
   p.hist_sorted = p.exclude ? hist_sorted : nullptr;
+  p.thresh = nullptr;
+  p.run_flag = nullptr;
+  int* overflow_flag = nullptr;
 
   LrProfScope prof(LR_PROF_ITEM_TOPK, 2.0 * 64 * (double)p.n_rows * B, st);
   if (p.exclude) {
     int Lp = 2;
     while (Lp < L) Lp <<= 1;
     if (Lp > 8192) LR_FAIL(LR_EUNSUPPORTED, "history length %d > 8192 is not supported by the mask pre-pass", L);
-    hipLaunchKernelGGL(hist_sort_kernel, dim3(B), dim3(256), (size_t)Lp * sizeof(int32_t), st, ids, L, Lp, p.n_rows,
-                       hist_sorted);
-    LR_CHECK_LAUNCH("hist_sort_kernel");
+    if (L <= 64) {
+      hipLaunchKernelGGL(hist_sort_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, B, L, p.n_rows, hist_sorted);
+      LR_CHECK_LAUNCH("hist_sort_wave_kernel");
+    } else {
+      hipLaunchKernelGGL(hist_sort_kernel, dim3(B), dim3(256), (size_t)Lp * sizeof(int32_t), st, ids, L, Lp, p.n_rows,
+                         hist_sorted);
+      LR_CHECK_LAUNCH("hist_sort_kernel");
+    }
+  }
+  if (seeded) {
+    BoundParams bp;
+    bp.emb16 = reinterpret_cast<const unsigned short*>(h->img + h->lay.item_emb_bf16);
+    bp.bias = p.bias;
+    bp.n_rows = p.n_rows;
+    bp.n_tiles = p.n_tiles;
+    bp.q = q;
+    bp.B = B;
+    bp.ld = (int)lr_align_up((size_t)p.n_tiles, 4);
+    char* bw = reinterpret_cast<char*>(ws) + need_partial + need_hist;
+    bp.tmax = reinterpret_cast<float*>(bw);
+    bw += lr_align_up((size_t)B * bp.ld * sizeof(float), 256);
+    float* thresh = reinterpret_cast<float*>(bw);
+    bw += lr_align_up((size_t)B * sizeof(float), 256);
+    float* cand_thresh = reinterpret_cast<float*>(bw);
+    bw += lr_align_up((size_t)B * sizeof(float), 256);
+    int* cand_count = reinterpret_cast<int*>(bw);   // [B], then the overflow flag
+    overflow_flag = cand_count + B;
+    bw += lr_align_up(((size_t)B + 1) * sizeof(int), 256);
+    int32_t* cand = reinterpret_cast<int32_t*>(bw);
+    const int n_ut = (B + TK_BUSERS - 1) / TK_BUSERS;
+    int chunks = (2048 + n_ut - 1) / n_ut;                 // ~8 light workgroups per CU
+    const int groups = bp.ld / 4;
+    if (chunks > groups) chunks = groups;
+    bp.tiles_per_chunk = 4 * ((groups + chunks - 1) / chunks);
+    chunks = (p.n_tiles + bp.tiles_per_chunk - 1) / bp.tiles_per_chunk;
+    hipLaunchKernelGGL(item_bound_kernel, dim3(chunks, n_ut), dim3(256), 0, st, bp);
+    LR_CHECK_LAUNCH("item_bound_kernel");
+#define TK_SELECT(NS_)                                                                                               \
+  hipLaunchKernelGGL(bound_select_kernel<NS_>, dim3((B + 3) / 4), dim3(256), 0, st, bp.tmax, bp.ld, p.n_tiles, q, ids, L, \
+                     p.n_rows, p.exclude, B, K, h->img + h->lay.item_stats, thresh, cand_thresh, cand_count, overflow_flag)
+    if (p.n_tiles <= 128) TK_SELECT(2);
+    else if (p.n_tiles <= 512) TK_SELECT(8);
+    else TK_SELECT(TK_BOUND_MAX_TILES / 64);
+#undef TK_SELECT
+    LR_CHECK_LAUNCH("bound_select_kernel");
+    CandParams cp;
+    cp.emb16 = bp.emb16;
+    cp.bias = p.bias;
+    cp.n_tiles = p.n_tiles;
+    cp.q = q;
+    cp.B = B;
+    cp.cand_thresh = cand_thresh;
+    cp.cand_count = cand_count;
+    cp.cand = cand;
+    cp.tiles_per_chunk = bp.tiles_per_chunk;
+    hipLaunchKernelGGL(item_cand_kernel, dim3(chunks, n_ut), dim3(256), 0, st, cp);
+    LR_CHECK_LAUNCH("item_cand_kernel");
+    hipLaunchKernelGGL(cand_rescore_kernel, dim3((B + 3) / 4), dim3(256), 0, st, p.emb, p.bias, q, p.hist_sorted, L,
+                       p.exclude, B, K, cand_count, cand, overflow_flag, out_idx, out_score);
+    LR_CHECK_LAUNCH("cand_rescore_kernel");
+    // behind the candidate path: the exact full pass, which runs only if a candidate list overflowed
+    p.thresh = thresh;
+    p.run_flag = overflow_flag;
   }
   const size_t lds = (2 * 32 * TK_ESTRIDE + 128) * sizeof(float) +
                      (size_t)TK_USERS * TK_BSTRIDE * 8;
@@ -686,7 +1207,11 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
   m.n_chunks = p.n_chunks;
   m.out_idx = out_idx;
   m.out_score = out_score;
-  hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, m);
+  m.run_flag = p.run_flag;
+  if (p.n_chunks > 1 && p.n_chunks * K <= TK_MERGE_KEYS)
+    hipLaunchKernelGGL(topk_merge_small_kernel, dim3((B + 3) / 4), dim3(256), 0, st, m);
+  else
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, m);
   LR_CHECK_LAUNCH("topk_merge_kernel");
   return LR_OK;
 }

@@ -39,7 +39,20 @@ def test_pack_is_pure_cpu_and_layout_is_consistent(golden_dir):
     assert np.array_equal(img[: 301 * 64].reshape(301, 64), sd["embedding.token.weight"])
     assert not img[301 * 64: rows_padded * 64].any()
     # first block: lambda/gamma derived from params_log, |lambda| < 1
-    off = rows_padded * 64 + rows_padded + 64 + 64
+    # bf16 copy of the table + its two norms (the top-K bound pre-pass) sit between the bias and the embedding LayerNorm
+    e16 = img[rows_padded * 64 + rows_padded: rows_padded * 64 + rows_padded + rows_padded * 32].view(np.uint16).reshape(rows_padded, 64)
+    from llamarec_amd.synth import f32_to_bf16_bits
+
+    # ... stored in MFMA A-fragment order: [tile][step][lane][8] = E[32 tile + (lane & 31)][32 (lane >> 5) + 8 step + j]
+    frag = e16.reshape(rows_padded // 32, 4, 64, 8)
+    want = np.zeros((rows_padded, 64), np.uint16)
+    want[:301] = f32_to_bf16_bits(sd["embedding.token.weight"])
+    want = want.reshape(rows_padded // 32, 32, 2, 4, 8)            # [tile][row][half][step][j]
+    assert np.array_equal(frag.reshape(-1, 4, 2, 32, 8), want.transpose(0, 3, 2, 1, 4))   # lane = 32 half + row
+    stats = img[rows_padded * 64 + rows_padded + rows_padded * 32:][:2]
+    assert stats[0] >= np.linalg.norm(sd["embedding.token.weight"].astype(np.float64), axis=1).max() > 0.99 * stats[0]
+    assert stats[1] >= np.abs(sd["model.bias"]).max() >= 0.99 * stats[1]
+    off = rows_padded * 64 + rows_padded + rows_padded * 32 + 64 + 64 + 64
     lam_re, lam_im, gamma = img[off:off + 128], img[off + 128:off + 256], img[off + 256:off + 384]
     pl = sd["model.lru_blocks.0.lru_layer.params_log"].astype(np.float64)
     lam = np.exp(-np.exp(pl[0]) + 1j * np.exp(pl[1]))

@@ -6,7 +6,7 @@ os.environ["LR_ATTN_STAMPS"] = "1"
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from llamarec_amd._lib import check, lib, stream_ptr
-B, T, nh, hd = 32, 460, 32, 128
+B, T, nh, hd = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 460, 32, 128
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 qkv = (torch.randn(B * T, 3 * nh * hd, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
 out = torch.empty(B * T, nh * hd, dtype=torch.bfloat16, device="cuda")

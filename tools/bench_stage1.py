@@ -6,7 +6,8 @@ import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__fil
 from llamarec_amd.lru import LRURec, init_lru_state_dict
 from llamarec_amd.synth import WORKLOADS, synth_users
 
-for name, U in (("ml-100k", 610), ("beauty", 22332), ("games", 15264), ("synth-1m", 4096)):
+ALL = (("ml-100k", 610), ("beauty", 22332), ("games", 15264), ("synth-1m", 4096))
+for name, U in [x for x in ALL if len(sys.argv) < 2 or x[0] in sys.argv[1:]]:
     w = WORKLOADS[name]
     t0 = time.time()
     hist, labels, n, T = synth_users(name, U)
