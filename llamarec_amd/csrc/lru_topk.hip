@@ -734,7 +734,8 @@ __global__ __launch_bounds__(256) void item_cand_kernel(CandParams p) {
 // One wave per user: exact scores of the candidates, masked ids dropped, rank by counting, ordered top-K written.
 __global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, const float* bias, const float* q,
                                                            const int32_t* hist_sorted, int L, int exclude, int B, int K,
-                                                           const int* cand_count, const int32_t* cand, int* overflow_flag,
+                                                           int n_rows, const int* cand_count, const int32_t* cand,
+                                                           int* overflow_flag,
                                                            int32_t* out_idx, float* out_score) {
   __shared__ float qs[4][64];
   __shared__ int32_t hsl[4][64];   // the user's sorted history when L <= 64 (else the search reads global memory)
@@ -742,10 +743,10 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int user = blockIdx.x * 4 + wave;
   if (user >= B) return;
-  int n = cand_count[user];
-  if (n > TK_CAND_CAP) {   // the list is incomplete: the exact full pass behind this kernel redoes the call
-    if (lane == 0) atomicOr(overflow_flag, 1);
-    n = TK_CAND_CAP;
+  const int n = cand_count[user];
+  if (n > TK_CAND_CAP) {   // the list is incomplete (its slots may never have been written): the exact full pass behind
+    if (lane == 0) atomicOr(overflow_flag, 1);   // this kernel redoes the whole call, this user included
+    return;
   }
   qs[wave][lane] = q[(size_t)user * 64 + lane];
   const bool hist_in_lds = exclude && L <= 64;
@@ -756,8 +757,9 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, con
   int valid = 0;
   for (int c = lane; c < n; c += 64) {
     const int item = cand[(size_t)user * TK_CAND_CAP + c];
-    bool masked = false;
-    if (exclude) {
+    bool masked = (unsigned)item >= (unsigned)n_rows;   // cannot happen (padding rows never pass); never index past the table
+
+    if (exclude && !masked) {
       masked = item == 0;
       int lo = 0, hi = L;   // sorted ascending, INT_MAX = unused entry
       while (lo < hi) {
@@ -1178,7 +1180,7 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     hipLaunchKernelGGL(item_cand_kernel, dim3(chunks, n_ut), dim3(256), 0, st, cp);
     LR_CHECK_LAUNCH("item_cand_kernel");
     hipLaunchKernelGGL(cand_rescore_kernel, dim3((B + 3) / 4), dim3(256), 0, st, p.emb, p.bias, q, p.hist_sorted, L,
-                       p.exclude, B, K, cand_count, cand, overflow_flag, out_idx, out_score);
+                       p.exclude, B, K, p.n_rows, cand_count, cand, overflow_flag, out_idx, out_score);
     LR_CHECK_LAUNCH("cand_rescore_kernel");
     // behind the candidate path: the exact full pass, which runs only if a candidate list overflowed
     p.thresh = thresh;

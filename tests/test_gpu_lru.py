@@ -180,3 +180,51 @@ def test_full_size_catalog_properties():
     # and the oracle on two users (about a second each on the CPU)
     oi, osc = O.LruOracle(sd).retrieve_topk(hist[[3, 211]], 50, True)
     assert np.array_equal(oi, i50n[[3, 211]]) and np.array_equal(osc, s50n[[3, 211]])
+
+
+@pytest.mark.parametrize("variant", ["norms_and_bias", "history_is_the_top", "tie_blocks", "all_equal", "no_exclude_k7"])
+def test_candidate_path_adversarial(variant):
+    """Catalogs of 64..2048 tiles take the bf16 bound + candidate + exact-rescore path (lru_topk.hip): its output must
+    still be the oracle's ordered top-K BIT FOR BIT when the proven error bound is stressed --
+      norms_and_bias      item rows scaled by 0.05..20 and biases ~ N(0, 1): a loose delta, many candidates
+      history_is_the_top  every user's history = its own unmasked top-50 (full L): the masked-id count R = K + 51 is needed
+      tie_blocks          100 items with identical rows and biases (exact score ties, broken by id) around the top
+      all_equal           every item identical: every approximate score passes, the candidate lists overflow and the
+                          device-side flag must hand the call to the exact full pass
+      no_exclude_k7       validation mode (no masking, the pad id 0 stays eligible) with a small K."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from oracle import lru_oracle as O
+
+    V, B, L = 4000, 70, 50          # 126 tiles: seeded (K + L + 1 <= tiles)
+    rng = np.random.default_rng(hash(variant) % 2 ** 31)
+    sd = init_lru_state_dict(V, seed=5)
+    E = sd["embedding.token.weight"].copy()
+    bias = sd["model.bias"].copy()
+    K, excl = 50, True
+    if variant == "norms_and_bias":
+        E *= rng.uniform(0.05, 20.0, size=(V + 1, 1)).astype(np.float32)
+        bias = rng.standard_normal(V + 1).astype(np.float32)
+    elif variant == "tie_blocks":
+        E[100:200] = E[100] * np.float32(6.0)        # large norm: these rows are near the top for many users
+        bias[100:200] = np.float32(0.25)
+    elif variant == "all_equal":
+        E[:] = E[7]
+        bias[:] = np.float32(0.5)
+    elif variant == "no_exclude_k7":
+        K, excl = 7, False
+        E[0] *= np.float32(30.0)                      # the pad row is a strong candidate when it is not masked
+    sd["embedding.token.weight"], sd["model.bias"] = E, bias
+    ids = np.zeros((B, L), np.int64)
+    for b in range(B):
+        n = int(rng.integers(1, L + 1))
+        ids[b, L - n:] = rng.integers(1, V + 1, size=n)
+    model, orc = LRURec.from_state_dict(sd), O.LruOracle(sd)
+    if variant == "history_is_the_top":
+        top_unmasked, _ = orc.retrieve_topk(ids, 50, False)
+        ids = np.where(top_unmasked == 0, 1, top_unmasked).astype(np.int64)   # (history ids: 0 is the pad)
+    idx, sc = model.retrieve_topk(ids, K, excl)
+    oi, os_ = orc.retrieve_topk(ids, K, excl)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(_bits(sc.cpu().numpy()), _bits(os_))
+    idx2, sc2 = model.retrieve_topk(ids[5:6], K, excl)      # alone in the call: same list
+    assert np.array_equal(idx2.cpu().numpy(), oi[5:6]) and np.array_equal(_bits(sc2.cpu().numpy()), _bits(os_[5:6]))
