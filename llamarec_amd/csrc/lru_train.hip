@@ -557,9 +557,14 @@ __global__ void tr_begin_pass(unsigned long long* ctr, unsigned long long seedba
   ctr[2] = seedbase + ctr[1] * 0xA24BAED4963EE407ull;
   ctr[1] += 1;
 }
-// zero / copy as kernels, not hipMemsetAsync / hipMemcpyAsync: under stream capture those become memset / memcpy
-// graph nodes, and a replayed graph then ran them out of order with the neighbouring kernels (wrong gradients
-// from the second step on); kernel nodes keep the captured stream order
+// zero / copy as kernels, not hipMemsetAsync / hipMemcpyAsync. Round 1 saw wrong gradients "from the second step on"
+// with memset / memcpy nodes in the captured step and blamed their ordering. tools/diag/graph_memset_order.cpp
+// (profiles/r02_graph_memset_order.txt) shows the ordering is fine on this stack -- a captured kernel -> memset ->
+// kernel -> memcpy chain gets the linear dependency edges and replays like the eager stream. What does differ is what
+// a captured memcpy node REMEMBERS: the host POINTER, not the bytes. The step used to copy its per-call scalars from a
+// stack variable; the first launch (same call) read it alive, every later replay read a dead stack slot. The scalars
+// now travel as launch arguments of a 1-thread kernel (tr_set_step_scalars, outside the captured part), and zeroing /
+// copying stays in kernels so that nothing in the replayed graph refers to host memory at all.
 __global__ void tr_zero_kernel(float* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
