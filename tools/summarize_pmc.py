@@ -29,7 +29,8 @@ def main():
         _, path = spec.split("=", 1)
         by, dur = load(path)
         for k, ctrs in by.items():
-            if not any(t in k for t in ("gemm", "attn", "rmsnorm", "rope", "lru_", "item_", "topk", "head", "embed", "em_")):
+            if not any(t in k for t in ("gemm", "attn", "rmsnorm", "rope", "lru_", "item_", "topk", "head", "embed", "em_", "cand_",
+                                        "bound_", "rms_rstd")):
                 continue
             e = res[k]
             e["launches_profiled"] = max(e.get("launches_profiled", 0), len(dur[k]))
@@ -43,6 +44,13 @@ def main():
             e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_per_launch"] * 1024
         if "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
             e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        if "TCC_HIT_sum_per_launch" in e and "TCC_MISS_sum_per_launch" in e:
+            tot = e["TCC_HIT_sum_per_launch"] + e["TCC_MISS_sum_per_launch"]
+            e["l2_hit_rate"] = e["TCC_HIT_sum_per_launch"] / tot if tot else None
+        if "TCC_EA0_RDREQ_sum_per_launch" in e and "TCC_EA0_RDREQ_DRAM_sum_per_launch" in e and e["TCC_EA0_RDREQ_sum_per_launch"]:
+            # requests the L2 sends out that are destined for DRAM (the memory-side Infinity Cache sits in front of DRAM and
+            # has no counter of its own in rocprofv3 -L on gfx950: this ratio does NOT separate MALL hits from HBM reads)
+            e["ea_rdreq_dram_fraction"] = e["TCC_EA0_RDREQ_DRAM_sum_per_launch"] / e["TCC_EA0_RDREQ_sum_per_launch"]
         if "GRBM_GUI_ACTIVE_per_launch" in e and "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in e:
             g = e["GRBM_GUI_ACTIVE_per_launch"] / 8
             e["mfma_busy_fraction"] = e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (1024 * g)
@@ -50,7 +58,8 @@ def main():
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
     for k, e in sorted(res.items()):
         print(k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in e.items()
-                  if x in ("avg_duration_us", "hbm_bytes_per_launch", "mfma_busy_fraction", "effective_clock_ghz")})
+                  if x in ("avg_duration_us", "hbm_bytes_per_launch", "mfma_busy_fraction", "effective_clock_ghz", "l2_hit_rate",
+                           "ea_rdreq_dram_fraction")})
 
 
 if __name__ == "__main__":
