@@ -53,7 +53,7 @@ cp "$(f $OUT/kt_s1 '*kernel_stats.csv')" profiles/${TAG}_stage1_kernel_stats.csv
 cp "$(f $OUT/kt_s1b '*kernel_stats.csv')" profiles/${TAG}_stage1_beauty_kernel_stats.csv
 cp "$(f $OUT/kt_train '*kernel_stats.csv')" profiles/${TAG}_train_beauty_kernel_stats.csv
 cp "$(f $OUT/kt_rank_train '*kernel_stats.csv')" profiles/${TAG}_rank_train_kernel_stats.csv
-{ python3 tools/kstats.py profiles/${TAG}_bench_steps5_kernel_stats.csv 16 6; echo "# python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-shapes (6 passes of the step incl. the warm-up)"; tail -1 "$OUT/bench_kt.log" | head -c 1500; echo; } > profiles/${TAG}_bench_summary.txt
+{ python3 tools/kstats.py profiles/${TAG}_bench_steps5_kernel_stats.csv 16 6; echo "# python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-shapes (6 passes of the step incl. the warm-up)"; grep '^{"metric"' "$OUT/bench_kt.log" | tail -1 | head -c 2500; echo; } > profiles/${TAG}_bench_summary.txt
 { python3 tools/kstats.py profiles/${TAG}_stage1_beauty_kernel_stats.csv 16 6; echo "# python3 tools/bench_stage1.py beauty (1 warm-up + 5 timed calls of 22 332 users)"; grep beauty "$OUT/stage1_beauty_kt.log" | grep -v simple_timer; } > profiles/${TAG}_stage1_beauty_summary.txt
 { python3 tools/kstats.py profiles/${TAG}_rank_train_kernel_stats.csv 24 4; echo "# tools/bench_rank_train.py --layers 32 --steps 3 (1 warm-up + 3 timed passes; lt_transpose_kernel and the at::native initialisers are setup)"; grep "^layers=" "$OUT/rank_train_kt.log"; } > profiles/${TAG}_rank_train_summary.txt
 TCC=$(f $OUT/pmc_tcc '*counter_collection.csv')
