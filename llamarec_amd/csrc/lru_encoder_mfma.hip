@@ -21,7 +21,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __device__ const float em_erf_tab[LR_ERF_NINT * (LR_ERF_DEG + 1)] = LR_ERF_TABLE;  // same table as lru_encoder.hip
 
-#define EM_TILE 32
 #define EM_XS 68  // LDS row stride (floats) of a 64-float row: conflict-free ds_read_b128
 
 struct EmChunk {
@@ -30,6 +29,10 @@ struct EmChunk {
   int* n;         // [users] live tokens
   int* off;       // [users + 1] first row of each user; off[users] = live rows of the chunk
   int* last_row;  // [users]
+  int* row_tag;   // [rows] (user << 2) | (last row of the user) << 1 | (first row of the user)
+  int* row_item;  // [rows] item id of the row (out-of-range ids -> 0, the padding row)
+  int* wg_row;    // [G + 1] row ranges of the G layer workgroups: about rows / G each, starting at a user's first row
+  int G;
 };
 
 // ---- live length per user (positions after the last pad id among the first L-1), one wave per user --------
@@ -45,29 +48,53 @@ __global__ __launch_bounds__(256) void em_live_kernel(EmChunk c) {
   if (lane == 0) c.n[u] = c.L - loc;
 }
 
-// ---- exclusive prefix sum of n over the chunk's users (one workgroup; users <= a few thousand) -------------
+// ---- exclusive prefix sum of n over the chunk's users + the layer workgroups' row ranges (one workgroup) --------
+// Wave w owns a contiguous block of users: pass 1 sums its block (coalesced, no barrier inside), one barrier publishes
+// the 16 block totals, pass 2 walks the block again with a shuffle scan per 64 users and writes the offsets.
 __global__ __launch_bounds__(1024) void em_offsets_kernel(EmChunk c) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int per = (c.users + 1023) / 1024;
-  const int u0 = tid * per, u1 = min(c.users, u0 + per);
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_wave = ((c.users + 16 * 64 - 1) / (16 * 64)) * 64;  // users per wave, a multiple of 64
+  const int ua = min(c.users, wave * per_wave), ub = min(c.users, ua + per_wave);
   int s = 0;
-  for (int u = u0; u < u1; ++u) s += c.n[u];
-  part[tid] = s;
+  for (int u = ua + lane; u < ub; u += 64) s += c.n[u];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) wsum[wave] = s;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int run = 0, carry = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) run += wsum[w];
+    carry += wsum[w];
   }
-  int run = part[tid] - s;
-  for (int u = u0; u < u1; ++u) {
-    c.off[u] = run;
-    run += c.n[u];
-    c.last_row[u] = run - 1;
+  for (int u0 = ua; u0 < ub; u0 += 64) {
+    const int u = u0 + lane;
+    const int n = u < ub ? c.n[u] : 0;
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    if (u < ub) {
+      c.off[u] = run + incl - n;
+      c.last_row[u] = run + incl - 1;
+    }
+    run += __shfl(incl, 63, 64);
   }
-  if (tid == 1023) c.off[c.users] = part[1023];
+  const int total = carry;
+  if (tid == 0) c.off[c.users] = total;
+  __syncthreads();  // off[] is complete and visible to this workgroup
+  // wg_row[g] = first row of the first user that starts at or after row g * ceil(total / G)  (wg_row[G] = total)
+  if (tid <= c.G) {
+    const int target = (int)min((long long)total, (long long)tid * ((total + c.G - 1) / c.G));
+    int lo = 0, hi = c.users;  // smallest u with off[u] >= target (off[users] = total >= target)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__builtin_nontemporal_load(c.off + mid) >= target) hi = mid; else lo = mid + 1;
+    }
+    c.wg_row[tid] = lo == c.users ? total : __builtin_nontemporal_load(c.off + lo);
+  }
 }
 
 // ---- the 64-lane butterfly sum of lru_encoder.hip, for the 64 features of a token held as v[blk][r] on a lane
@@ -95,260 +122,529 @@ __device__ __forceinline__ float em_butterfly64(const float (&v)[2][16]) {
   return e0 + e1;                                   // xor 1
 }
 
-// ---- embedding gather + LayerNorm: workgroup = user, wave per token (identical to lru_encoder.hip) ---------
-__device__ __forceinline__ float em_wave_sum64(float v) {
+// ---- row -> (item id, tag): thread = (user, position) --------------------------------------------------------
+__global__ __launch_bounds__(256) void em_rows_kernel(EmChunk c) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)c.users * c.L) return;
+  const int u = (int)(g / c.L), pos = (int)(g - (long long)u * c.L);
+  const int n = c.n[u], t = pos - (c.L - n);
+  if (t < 0) return;
+  long long id = c.ids[g];
+  if (id < 0 || id > c.num_items) id = 0;
+  const int row = c.off[u] + t;
+  c.row_item[row] = (int)id;
+  c.row_tag[row] = (u << 2) | ((t == n - 1) << 1) | (t == 0);
+}
+
+// ---- embedding gather + LayerNorm: 16 lanes per row, 4 features per lane ----------------------------------------
+// The sums are the 64-lane butterfly of lru_encoder.hip (levels xor 32, 16, 8, 4, 2, 1 over the feature index) with the
+// feature index split as 4 * lane + component: levels 32..4 exchange lanes 8, 4, 2, 1 apart, levels 2 and 1 add the
+// lane's own components (0,2), (1,3), then the two sums -- the same pairs at every level.
+__device__ __forceinline__ float em_sum64_q(const float4 v) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
 #pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
-  return v;
+  for (int s = 8; s >= 1; s >>= 1) {
+    a = a + __shfl_xor(a, s, 64);
+    b = b + __shfl_xor(b, s, 64);
+    c = c + __shfl_xor(c, s, 64);
+    d = d + __shfl_xor(d, s, 64);
+  }
+  const float e0 = a + c, e1 = b + d;
+  return e0 + e1;
 }
 __global__ __launch_bounds__(256) void em_embed_kernel(EmChunk c, const float* img, LrLruLayout lay, float* X) {
-  const int u = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = c.n[u], row0 = c.off[u], start = c.L - n;
-  const float w = img[lay.emb_ln_w + lane], b = img[lay.emb_ln_b + lane];
-  for (int t = wave; t < n; t += 4) {
-    long long id = c.ids[(size_t)u * c.L + start + t];
-    if (id < 0 || id > c.num_items) id = 0;
-    const float e = img[lay.item_emb + (size_t)id * 64 + lane];
-    const float mean = em_wave_sum64(e) * 0.015625f;
-    const float d = e - mean;
-    const float var = em_wave_sum64(d * d) * 0.015625f;
+  const int n_rows = c.off[c.users];
+  const int l = threadIdx.x & 15;
+  const float4 w = *reinterpret_cast<const float4*>(img + lay.emb_ln_w + 4 * l);
+  const float4 b = *reinterpret_cast<const float4*>(img + lay.emb_ln_b + 4 * l);
+  const int rows_per_pass = gridDim.x * 16;
+  for (int base = blockIdx.x * 16; base < n_rows; base += rows_per_pass) {  // workgroup-uniform trip count
+    const int row = base + (threadIdx.x >> 4);
+    const bool live = row < n_rows;
+    const int id = c.row_item[live ? row : 0];
+    const float4 e = *reinterpret_cast<const float4*>(img + lay.item_emb + (size_t)id * 64 + 4 * l);
+    const float mean = em_sum64_q(e) * 0.015625f;
+    const float4 d = make_float4(e.x - mean, e.y - mean, e.z - mean, e.w - mean);
+    const float var = em_sum64_q(make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w)) * 0.015625f;
     const float rstd = 1.0f / sqrtf(var + LR_LN_EPS);
-    X[(size_t)(row0 + t) * 64 + lane] = lr_fma(d * rstd, w, b);
+    if (live)
+      *reinterpret_cast<float4*>(X + (size_t)row * 64 + 4 * l) =
+          make_float4(lr_fma(d.x * rstd, w.x, b.x), lr_fma(d.y * rstd, w.y, b.y), lr_fma(d.z * rstd, w.z, b.z),
+                      lr_fma(d.w * rstd, w.w, b.w));
   }
 }
 
-// ---- K = 64 layer: OUT[row][256] = epi( bias + sum_k W[k][.] x[row][k] ); EPI 0: * gamma (in_proj), 1: GELU ----
-// Workgroup = 4 waves, wave w owns output blocks 2w, 2w+1 (32 outputs each) for every row tile it walks.
-// wt: k-major [64][256] (the packed image). rows: optional gather list (last-row path), n_rows_ptr: live rows.
-template <int EPI>
-__global__ __launch_bounds__(256) void em_proj64_kernel(const float* __restrict__ wt, const float* __restrict__ bias,
-                                                        const float* __restrict__ gamma, const float* __restrict__ X,
-                                                        const int* __restrict__ rows, const int* n_rows_ptr, int n_rows_fixed,
-                                                        float* OUT, int tiles_cap) {
-  __shared__ __attribute__((aligned(16))) float xs[EM_TILE * EM_XS];
-  __shared__ float erf_lds[LR_ERF_NINT * (LR_ERF_DEG + 1)];  // lane-divergent coefficient gathers: LDS, not global
+// GELU of lr_math.h (lr_gelu_tab / lr_erff_tab: same operations in the same order) reading the erf table from an LDS
+// copy with 12-float rows: the nine coefficients of a lane's interval arrive in three 16-byte reads instead of nine
+// 4-byte ones (rows of different intervals fall on disjoint banks).
+#define EM_ERF_ROW 12
+// N values at a time, stage by stage (arguments, coefficient reads, the N Horner chains in lockstep, finish): the table
+// reads of one value and its eight dependent fmas would otherwise run back to back with nothing beside them.
+template <int N>
+__device__ __forceinline__ void em_gelu_tab12(const float (&x)[N], float (&y)[N], const float* tab12) {
+  static_assert(LR_ERF_DEG == 8, "em_gelu_tab12 unrolls a degree-8 Horner chain");
+  float xe[N], a[N], t[N], r[N];
+  bool in[N];
+  float4 c0[N], c1[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    xe[n] = x[n] * 0.70710678118654752440f;
+    a[n] = __builtin_fabsf(xe[n]);
+    in[n] = a[n] < 4.0f;                   // false for NaN too
+    const float ai = in[n] ? a[n] : 0.0f;  // the polynomial is evaluated unconditionally, on a harmless argument where
+    const int i = (int)(ai * 2.0f);        // its result is not used
+    t[n] = ai - ((float)i * 0.5f + 0.25f);
+    const float* c = tab12 + i * EM_ERF_ROW;
+    c0[n] = *reinterpret_cast<const float4*>(c);
+    c1[n] = *reinterpret_cast<const float4*>(c + 4);
+    r[n] = c[8];
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c1[n].w);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c1[n].z);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c1[n].y);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c1[n].x);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c0[n].w);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c0[n].z);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c0[n].y);
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = lr_fma(r[n], t[n], c0[n].x);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const float rr = in[n] ? r[n] : (a[n] != a[n] ? a[n] : 1.0f);  // erf(4) rounds to 1 in binary32; a NaN stays a NaN
+    const float e = __builtin_copysignf(rr, xe[n]);
+    y[n] = (0.5f * x[n]) * (1.0f + e);
+  }
+}
+
+// ---- one fused position-wise layer pair on 64-row super tiles ------------------------------------------------
+//   MODE 0  LRU layer      : in_proj (* gamma) -> recurrence -> out_proj + residual + LayerNorm        X -> Y
+//   MODE 1  feed-forward   : w_1 + GELU -> w_2 + residual + LayerNorm                                  Y -> X
+//   MODE 2  LRU, last block: in_proj -> recurrence, the state of each user's LAST row only             X -> Ul[user][256]
+//   MODE 3  out_proj + residual + LayerNorm of rows given as [row][256] (the last rows)                Ul -> Yl
+// The 256-wide intermediate of a super tile (in_proj output / FFN hidden) lives only in LDS: the layer reads 256 B and
+// writes 256 B per row instead of 1 KiB + 1 KiB (+ 2 KiB for the recurrence) per row through HBM.
+//   phase A (K = 64, weights in registers): wave w owns output blocks 2w, 2w+1 for both 32-row tiles of the super
+//     tile; D[token][out] goes to LDS at ul[token][pos(out)], pos() = the de-interleaved order phase B reads.
+//   recurrence: thread = complex channel, walks the 64 rows in LDS; its carry stays in registers from one super tile
+//     to the next -- a workgroup's row range starts at a user's first row (wg_row, em_offsets_kernel), row_tag says
+//     where users start / end inside it.
+//   phase B (K = 256, weights in LDS): wave (rt, j) = (row tile, 32-feature block), one 128-step chain; block 1 hands
+//     its 16 values per lane to the block-0 wave through LDS, which finishes the LayerNorm butterfly (first level =
+//     feature f + feature f+32, exactly that hand-over) and stores the row.
+// Per row the arithmetic is that of lru_encoder.hip: which rows share a tile never changes a row's chain.
+#define EM_ST 64   // rows per super tile
+#define EM_US 260  // LDS row stride (floats) of a 256-float row: 16-byte aligned, conflict-free ds_read_b128
+#define EM_WS 260  // same for the K = 256 weight rows
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would expose the latency of
+// the next super tile's input rows (requested a whole tile ahead) at every barrier.
+#define EM_BARRIER()                                   \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                      \
+    asm volatile("" ::: "memory");                     \
+  } while (0)
+
+// Diagnostic stamps (-DLR_EXPERIMENTS build only, LR_EM_STAMPS=1): wave 0 of the first 16 workgroups sums s_memtime
+// ticks per phase over its super tiles; tools/em_stamps.py prints them. The product build contains none of this.
+#ifdef LR_EXPERIMENTS
+__device__ unsigned long long g_em_stamps[4][16][12];
+#define EM_STAMP(k)                                                      \
+  do {                                                                   \
+    if (p.stamp) {                                                       \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+      st_acc[k] += now_ - st_prev;                                       \
+      st_prev = now_;                                                    \
+    }                                                                    \
+  } while (0)
+#else
+#define EM_STAMP(k) do { } while (0)
+#endif
+
+struct EmLayer {
+  const float *wa, *ba, *gamma, *lam_re, *lam_im;  // phase A: k-major [64][256], bias[256], gamma[128], lambda[128]
+  const float *wb, *bb, *lnw, *lnb;                // phase B: k-major [256][64], bias[64], LayerNorm weight / bias
+  const float* IN;        // phase A input rows [.][64] (MODE 3: phase B input rows [.][256])
+  const float* RES;       // residual rows [.][64]
+  const int* res_rows;    // optional gather list for RES
+  float* OUT;             // [.][64]; MODE 2: [users][256]
+  const int* row_tag;     // (user << 2) | last << 1 | first, per row (MODE 0, 2)
+  const int* wg_row;      // [gridDim.x + 1] user-aligned row ranges; null: super tiles strided over n_rows
+  const int* n_rows_ptr;
+  int n_rows_fixed;
+  int stamp;
+};
+
+__device__ __forceinline__ int em_pos(int out) { return (out >> 6) * 64 + (out & 1) * 32 + ((out & 63) >> 1); }
+
+// floats [part*16, part*16 + 16) of row r0 + row of a [.][64] matrix; zeros past rb
+__device__ __forceinline__ void em_load_rows16(float4 (&v)[4], const float* M, int r0, int rb, int row, int part) {
+  if (r0 + row < rb) {
+    const float* src = M + (size_t)(r0 + row) * 64 + part * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(src + 4 * i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void em_layer_kernel(EmLayer p) {
+  constexpr bool HAS_A = MODE != 3, HAS_B = MODE != 2, SCAN = MODE == 0 || MODE == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float* ws = smem_f;                    // [64][EM_WS]   phase B weights, de-interleaved per 64-k chunk
+  float* ul = ws + 64 * EM_WS;           // [EM_ST][EM_US] the 256-wide intermediate
+  float* xs = ul + EM_ST * EM_US;        // [EM_ST][EM_XS] phase A input, de-interleaved
+  float* ex = xs + EM_ST * EM_XS;        // [2][16][64]    feature block 1 -> block 0 hand-over
+  float* lnp = ex + 2 * 16 * 64;         // [2][64]        LayerNorm weight, bias
+  int* tags = reinterpret_cast<int*>(lnp + 128);      // [EM_ST]
+  float* erf_lds = reinterpret_cast<float*>(tags + EM_ST);  // [LR_ERF_NINT][EM_ERF_ROW]
+  float* carry = erf_lds + LR_ERF_NINT * EM_ERF_ROW;       // [2][64 lanes][4] recurrence state after row 63, by super tile parity
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int n_rows = n_rows_ptr ? *n_rows_ptr : n_rows_fixed;
-  const int n_tiles = (n_rows + EM_TILE - 1) / EM_TILE;
-  if ((int)blockIdx.x >= n_tiles) return;
-  if (EPI == 1)
-    for (int i = tid; i < LR_ERF_NINT * (LR_ERF_DEG + 1); i += 256) erf_lds[i] = em_erf_tab[i];
-  // B operand: weights of my two output blocks, de-interleaved k: step s of half h uses k = 2s + h
-  float wq[2][32], bq[2], gq[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int out = (2 * wave + j) * 32 + col;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) wq[j][s] = wt[(size_t)(2 * s + half) * 256 + out];
-    bq[j] = bias[out];
-    gq[j] = EPI == 0 ? gamma[out & 127] : 0.f;
+
+#ifdef LR_EXPERIMENTS
+  unsigned long long st_acc[12] = {}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
+  int ra, rb, step;
+  if (p.wg_row) {
+    ra = p.wg_row[blockIdx.x];
+    rb = p.wg_row[blockIdx.x + 1];
+    step = EM_ST;
+  } else {
+    ra = blockIdx.x * EM_ST;
+    rb = p.n_rows_ptr ? *p.n_rows_ptr : p.n_rows_fixed;
+    step = gridDim.x * EM_ST;
   }
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int r0 = tile * EM_TILE;
-    __syncthreads();  // previous tile consumed
-    // stage the tile de-interleaved: xs[row][h*32 + s] = x[row][2s + h]; thread -> (row = tid>>3, 8 floats)
-    {
-      const int row = tid >> 3, k0 = (tid & 7) * 8;
-      const int gr = r0 + row;
-      float v[8];
-      if (gr < n_rows) {
-        const float* src = X + (size_t)(rows ? rows[gr] : gr) * 64 + k0;
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = k0 + i;
-        xs[row * EM_XS + (k & 1) * 32 + (k >> 1)] = v[i];
-      }
+  if (ra >= rb) return;
+
+  if (HAS_B) {
+    for (int i = tid; i < 64 * 256; i += 256) {
+      const int k = i >> 6, out = i & 63;  // coalesced read of W[k][out]
+      ws[out * EM_WS + (k >> 6) * 64 + (k & 1) * 32 + ((k & 63) >> 1)] = p.wb[i];
     }
-    __syncthreads();
-    // A operand: token row `col`, 32 de-interleaved values of my half
-    float a[32];
-    {
-      const float* xr = xs + col * EM_XS + 32 * half;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 v4 = *reinterpret_cast<const float4*>(xr + 4 * q);
-        a[4 * q + 0] = v4.x; a[4 * q + 1] = v4.y; a[4 * q + 2] = v4.z; a[4 * q + 3] = v4.w;
-      }
+    if (tid < 64) lnp[tid] = p.lnw[tid];
+    else if (tid < 128) lnp[tid] = p.lnb[tid - 64];
+  }
+  if (MODE == 1)
+    for (int i = tid; i < LR_ERF_NINT * EM_ERF_ROW; i += 256) {
+      const int c = i % EM_ERF_ROW;
+      erf_lds[i] = c <= LR_ERF_DEG ? em_erf_tab[(i / EM_ERF_ROW) * (LR_ERF_DEG + 1) + c] : 0.f;
     }
+  // phase A operand B: weights of my two output blocks, de-interleaved k: step s of half h uses k = 2s + h
+  float wq[2][32], bq[2], gq[2];
+  if (HAS_A) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      floatx16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = bq[j];
-#pragma unroll
-      for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wq[j][s], acc, 0, 0, 0);
-      // D[token i][out j]: lane = out column, register r = token (r&3) + 8*(r>>2) + 4*half
       const int out = (2 * wave + j) * 32 + col;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gr = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (gr < n_rows) {
-          const float v = EPI == 0 ? acc[r] * gq[j] : lr_gelu_tab(acc[r], erf_lds);
-          OUT[(size_t)gr * 256 + out] = v;
+      for (int s = 0; s < 32; ++s) wq[j][s] = p.wa[(size_t)(2 * s + half) * 256 + out];
+      bq[j] = p.ba[out];
+      gq[j] = MODE == 1 ? 0.f : p.gamma[out & 127];
+    }
+  }
+  // phase B: my chain = feature block jb of row tile rt
+  const int rt = wave >> 1, jb = wave & 1;
+  float bb[16];
+  if (HAS_B) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[r] = p.bb[jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+  }
+  // recurrence: lane = two complex channels k, k + 2 (neighbours in the de-interleaved row), wave = a segment of rows
+  const int sc_k = (lane >> 5) * 64 + 4 * (lane & 15) + ((lane >> 4) & 1);
+  const int sc_pos = em_pos(sc_k);  // em_pos(sc_k + 2) = sc_pos + 1, em_pos(128 + k) = em_pos(k) + 128
+  float lam_r0 = 0.f, lam_i0 = 0.f, lam_r1 = 0.f, lam_i1 = 0.f;
+  if (SCAN) {
+    lam_r0 = p.lam_re[sc_k];
+    lam_i0 = p.lam_im[sc_k];
+    lam_r1 = p.lam_re[sc_k + 2];
+    lam_i1 = p.lam_im[sc_k + 2];
+    *reinterpret_cast<float4*>(carry + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);  // every wave: same zeros
+  }
+
+  float4 pre[4];  // my 16 floats of the NEXT super tile's phase A input: their latency hides behind this tile's MFMAs
+  if (HAS_A) em_load_rows16(pre, p.IN, ra, rb, tid >> 2, tid & 3);
+  int par = 0;
+  int pre_tag = 1;  // rows past the range restart the recurrence and are never a user's last row
+  if (SCAN && tid < EM_ST && ra + tid < rb) pre_tag = p.row_tag[ra + tid];
+
+  EM_STAMP(0);
+  for (int r0 = ra; r0 < rb; r0 += step) {
+    const int nv = min(EM_ST, rb - r0);
+    EM_BARRIER();  // the previous super tile is consumed
+    EM_STAMP(1);
+    {
+      const int row = tid >> 2, part = tid & 3;
+      if (HAS_A) {  // 16 floats of a 64-float row (loaded one super tile ahead), de-interleaved: xs[row][h*32 + s] = x[row][2s + h]
+        float* dst = xs + row * EM_XS + part * 8;  // even k -> [part*8, +8), odd k -> 32 + the same: four 16-byte stores
+        *reinterpret_cast<float4*>(dst) = make_float4(pre[0].x, pre[0].z, pre[1].x, pre[1].z);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(pre[2].x, pre[2].z, pre[3].x, pre[3].z);
+        *reinterpret_cast<float4*>(dst + 32) = make_float4(pre[0].y, pre[0].w, pre[1].y, pre[1].w);
+        *reinterpret_cast<float4*>(dst + 36) = make_float4(pre[2].y, pre[2].w, pre[3].y, pre[3].w);
+        em_load_rows16(pre, p.IN, r0 + step, rb, row, part);
+      } else {  // MODE 3: one 64-k chunk of a 256-float row, de-interleaved inside the chunk
+        float* dst = ul + row * EM_US + part * 64;
+        const float* src = p.IN + (size_t)(r0 + (row < nv ? row : 0)) * 256 + part * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
+          if (row >= nv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[2 * i] = v.x;
+          dst[32 + 2 * i] = v.y;
+          dst[2 * i + 1] = v.z;
+          dst[32 + 2 * i + 1] = v.w;
         }
       }
-    }
-  }
-  (void)tiles_cap;
-}
-
-// ---- K = 256 layer: Y[row][64] = LayerNorm( bias + sum_k W[k][.] in[row][k] + RES[row][.] ) -------------------
-// wt: k-major [256][64] (packed image). Workgroup = 4 waves, each wave its own 32-row tile; weights in LDS
-// de-interleaved per 64-k chunk: ws[out][c*64 + h*32 + s] = W[64c + 2s + h][out]. A = weights (rows = features),
-// B = tokens (columns): a lane pair holds the 64 features of one token.
-#define EM_WS 260  // LDS row stride (floats) of a 256-float weight row
-__global__ __launch_bounds__(256) void em_proj256_ln_kernel(const float* __restrict__ wt, const float* __restrict__ bias,
-                                                            const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                                            const float* __restrict__ IN, const int* __restrict__ in_rows,
-                                                            const float* __restrict__ RES, const int* __restrict__ res_rows,
-                                                            const int* n_rows_ptr, int n_rows_fixed, float* Y) {
-  extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  float* ws = smem_f;                       // [64][EM_WS]
-  float* xin = smem_f + 64 * EM_WS;         // [4 waves][32 rows][EM_XS]: one 64-k chunk of the wave's tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, col = lane & 31;
-  const int n_rows = n_rows_ptr ? *n_rows_ptr : n_rows_fixed;
-  const int n_tiles = (n_rows + EM_TILE - 1) / EM_TILE;
-  if ((int)blockIdx.x * 4 >= n_tiles) return;
-  for (int i = tid; i < 64 * 256; i += 256) {
-    const int k = i >> 6, out = i & 63;  // coalesced read of W[k][out]
-    ws[out * EM_WS + (k >> 6) * 64 + (k & 1) * 32 + ((k & 63) >> 1)] = wt[i];
-  }
-  float bq[2][16], wq[2][16], cq[2][16];  // bias, LN weight, LN bias of my 32 features
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      bq[j][r] = bias[f];
-      wq[j][r] = lnw[f];
-      cq[j][r] = lnb[f];
-    }
-  __syncthreads();
-  float* xw = xin + wave * (EM_TILE * EM_XS);
-  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-    const int r0 = tile * EM_TILE;
-    floatx16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = bq[j][r];
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-      // stage chunk c (k = 64c .. 64c+63) of my 32 input rows, de-interleaved; wave-private: no workgroup barrier
-      __builtin_amdgcn_wave_barrier();
-      for (int i = lane; i < EM_TILE * 16; i += 64) {
-        const int row = i >> 4, k4 = (i & 15) * 4;
-        const int gr = r0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < n_rows) v = *reinterpret_cast<const float4*>(IN + (size_t)(in_rows ? in_rows[gr] : gr) * 256 + c * 64 + k4);
-        float* dst = xw + row * EM_XS + (k4 >> 1);
-        dst[0] = v.x;   // k4     (even -> half 0, s = k4/2)
-        dst[32] = v.y;  // k4 + 1 (odd  -> half 1)
-        dst[1] = v.z;   // k4 + 2
-        dst[33] = v.w;  // k4 + 3
+      if (SCAN && tid < EM_ST) {
+        tags[tid] = pre_tag;
+        pre_tag = r0 + step + tid < rb ? p.row_tag[r0 + step + tid] : 1;
       }
-      __builtin_amdgcn_wave_barrier();
-      float b[32];  // token `col`, chunk c, my half
-      {
-        const float* xr = xw + col * EM_XS + 32 * half;
+    }
+    EM_STAMP(2);
+    EM_BARRIER();
+    EM_STAMP(3);
+
+    if (HAS_A) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float a[32];  // token row t*32 + col, 32 de-interleaved values of my half
+        const float* xr = xs + (t * 32 + col) * EM_XS + 32 * half;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float4 v4 = *reinterpret_cast<const float4*>(xr + 4 * q);
-          b[4 * q + 0] = v4.x; b[4 * q + 1] = v4.y; b[4 * q + 2] = v4.z; b[4 * q + 3] = v4.w;
+          a[4 * q + 0] = v4.x; a[4 * q + 1] = v4.y; a[4 * q + 2] = v4.z; a[4 * q + 3] = v4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          floatx16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = bq[j];
+#pragma unroll
+          for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wq[j][s], acc, 0, 0, 0);
+          // D[token i][out]: lane = out column, register r = token (r&3) + 8*(r>>2) + 4*half
+          float* dst = ul + wave * 64 + (col & 1) * 32 + j * 16 + (col >> 1);  // em_pos((2*wave + j)*32 + col)
+#pragma unroll
+          for (int r8 = 0; r8 < 16; r8 += 8) {
+            float xin[8], val[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xin[i] = acc[r8 + i];
+            if (MODE == 1) {
+              em_gelu_tab12<8>(xin, val, erf_lds);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) val[i] = xin[i] * gq[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int r = r8 + i;
+              const int tok = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              dst[tok * EM_US] = val[i];
+            }
+          }
         }
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float* wr = ws + (j * 32 + col) * EM_WS + c * 64 + 32 * half;  // feature row j*32 + col
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * q);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, b[4 * q + 0], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, b[4 * q + 1], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, b[4 * q + 2], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, b[4 * q + 3], acc[j], 0, 0, 0);
-        }
-      }
+      EM_STAMP(4);
+      EM_BARRIER();
+      EM_STAMP(5);
     }
-    // D[feature i][token j]: lane = token `col`, acc[j][r] = feature j*32 + (r&3) + 8*(r>>2) + 4*half
-    const int gr = r0 + col;
-    const bool live = gr < n_rows;
-    float v[2][16];
-    {
-      const float* res = RES + (size_t)(live ? (res_rows ? res_rows[gr] : gr) : 0) * 64;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 r4 = live ? *reinterpret_cast<const float4*>(res + j * 32 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-          v[j][4 * g + 0] = acc[j][4 * g + 0] + r4.x;
-          v[j][4 * g + 1] = acc[j][4 * g + 1] + r4.y;
-          v[j][4 * g + 2] = acc[j][4 * g + 2] + r4.z;
-          v[j][4 * g + 3] = acc[j][4 * g + 3] + r4.w;
-        }
-    }
-    const float mean = em_butterfly64(v) * 0.015625f;
-    float d2[2][16];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        v[j][r] = v[j][r] - mean;
-        d2[j][r] = v[j][r] * v[j][r];
+
+    if (SCAN) {
+      // The 64 rows are cut at users' first rows into up to four segments (cuts at the first start at or after row 16,
+      // 32, 48); wave w walks segment w. Only segment 0 can continue a user of the previous super tile: its carry comes
+      // from the wave that walked row 63 there, through LDS.
+      const int tg_lane = tags[lane];
+      const unsigned long long firsts = __ballot(tg_lane & 1);
+      const unsigned long long lasts = __ballot(tg_lane & 2);
+      int sa = 0, sb = EM_ST;
+      if (wave > 0) {
+        const unsigned long long m = firsts & (~0ull << (16 * wave));
+        sa = m ? __builtin_ctzll(m) : EM_ST;
       }
-    const float var = em_butterfly64(d2) * 0.015625f;
-    const float rstd = 1.0f / sqrtf(var + LR_LN_EPS);
-    if (live) {
-      float* y = Y + (size_t)gr * 64;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float4 o;
-          o.x = lr_fma(v[j][4 * g + 0] * rstd, wq[j][4 * g + 0], cq[j][4 * g + 0]);
-          o.y = lr_fma(v[j][4 * g + 1] * rstd, wq[j][4 * g + 1], cq[j][4 * g + 1]);
-          o.z = lr_fma(v[j][4 * g + 2] * rstd, wq[j][4 * g + 2], cq[j][4 * g + 2]);
-          o.w = lr_fma(v[j][4 * g + 3] * rstd, wq[j][4 * g + 3], cq[j][4 * g + 3]);
-          *reinterpret_cast<float4*>(y + j * 32 + 8 * g + 4 * half) = o;
+      if (wave < 3) {
+        const unsigned long long m = firsts & (~0ull << (16 * (wave + 1)));
+        sb = m ? __builtin_ctzll(m) : EM_ST;
+      }
+      sa = __builtin_amdgcn_readfirstlane(sa);
+      sb = __builtin_amdgcn_readfirstlane(sb);
+      if (sa < sb) {
+        float h_r0, h_r1, h_i0, h_i1;
+        if (wave == 0) {
+          const float4 cv = *reinterpret_cast<const float4*>(carry + par * 256 + 4 * lane);
+          h_r0 = cv.x; h_r1 = cv.y; h_i0 = cv.z; h_i1 = cv.w;
+        } else {
+          h_r0 = h_r1 = h_i0 = h_i1 = 0.f;  // overwritten by the segment's first row
         }
+        float* base = ul + sc_pos;
+        for (int t0 = sa; t0 < sb; t0 += 4) {
+          float2 br[4], bi[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int t = min(t0 + i, sb - 1);
+            br[i] = *reinterpret_cast<const float2*>(base + t * EM_US);
+            bi[i] = *reinterpret_cast<const float2*>(base + t * EM_US + 128);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int t = t0 + i;
+            if (t < sb) {  // wave-uniform
+              if ((firsts >> t) & 1) {
+                h_r0 = br[i].x; h_r1 = br[i].y; h_i0 = bi[i].x; h_i1 = bi[i].y;
+              } else {
+                const float nr0 = lr_fma(lam_r0, h_r0, lr_fma(-lam_i0, h_i0, br[i].x));
+                const float ni0 = lr_fma(lam_r0, h_i0, lr_fma(lam_i0, h_r0, bi[i].x));
+                const float nr1 = lr_fma(lam_r1, h_r1, lr_fma(-lam_i1, h_i1, br[i].y));
+                const float ni1 = lr_fma(lam_r1, h_i1, lr_fma(lam_i1, h_r1, bi[i].y));
+                h_r0 = nr0; h_i0 = ni0; h_r1 = nr1; h_i1 = ni1;
+              }
+              if (MODE == 0) {
+                *reinterpret_cast<float2*>(base + t * EM_US) = make_float2(h_r0, h_r1);
+                *reinterpret_cast<float2*>(base + t * EM_US + 128) = make_float2(h_i0, h_i1);
+              } else if ((lasts >> t) & 1) {
+                float* o = p.OUT + (size_t)(tags[t] >> 2) * 256;
+                o[sc_k] = h_r0;
+                o[sc_k + 2] = h_r1;
+                o[128 + sc_k] = h_i0;
+                o[128 + sc_k + 2] = h_i1;
+              }
+            }
+          }
+        }
+        // (the other buffer: wave 0 may not have read this tile's carry-in yet)
+        if (sb == EM_ST) *reinterpret_cast<float4*>(carry + (par ^ 1) * 256 + 4 * lane) = make_float4(h_r0, h_r1, h_i0, h_i1);
+      }
+      par ^= 1;
+      EM_STAMP(6);
+      if (HAS_B) EM_BARRIER();
+      EM_STAMP(7);
+    }
+
+    if (HAS_B) {
+      // D[feature i][token]: lane = token rt*32 + col, acc[r] = feature jb*32 + (r&3) + 8*(r>>2) + 4*half
+      const int lrow = rt * 32 + col;
+      const bool live = lrow < nv;
+      const int gr = r0 + lrow;
+      float4 r4[4];  // residual, requested before the chain
+      {
+        const float* res = p.RES + (size_t)(live ? (p.res_rows ? p.res_rows[gr] : gr) : 0) * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          r4[g] = live ? *reinterpret_cast<const float4*>(res + jb * 32 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      floatx16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bb[r];
+      {
+        const float* wr = ws + (jb * 32 + col) * EM_WS + 32 * half;   // feature row jb*32 + col
+        const float* tr = ul + (rt * 32 + col) * EM_US + 32 * half;   // token row rt*32 + col
+        // operands of the next 8 steps are requested before the 8 MFMAs of the current ones (one wave per SIMD: nothing
+        // else hides the LDS latency)
+        float4 wc[2], bc[2], wn[2], bn[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          wc[i] = *reinterpret_cast<const float4*>(wr + 4 * i);
+          bc[i] = *reinterpret_cast<const float4*>(tr + 4 * i);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {  // 8 k steps each: k chunk g >> 2, float4 pairs 2*(g&3), 2*(g&3) + 1
+          if (g < 15) {
+            const int o = ((g + 1) >> 2) * 64 + ((g + 1) & 3) * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              wn[i] = *reinterpret_cast<const float4*>(wr + o + 4 * i);
+              bn[i] = *reinterpret_cast<const float4*>(tr + o + 4 * i);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them back otherwise)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].x, bc[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].y, bc[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].z, bc[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[i].w, bc[i].w, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            wc[i] = wn[i];
+            bc[i] = bn[i];
+          }
+        }
+      }
+      EM_STAMP(8);
+      float v[2][16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v[0][4 * g + 0] = acc[4 * g + 0] + r4[g].x;
+        v[0][4 * g + 1] = acc[4 * g + 1] + r4[g].y;
+        v[0][4 * g + 2] = acc[4 * g + 2] + r4[g].z;
+        v[0][4 * g + 3] = acc[4 * g + 3] + r4[g].w;
+      }
+      if (jb == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[(rt * 16 + r) * 64 + lane] = v[0][r];
+      }
+      EM_STAMP(9);
+      EM_BARRIER();
+      EM_STAMP(10);
+      if (jb == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[1][r] = ex[(rt * 16 + r) * 64 + lane];
+        const float mean = em_butterfly64(v) * 0.015625f;
+        float d2[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            v[j][r] = v[j][r] - mean;
+            d2[j][r] = v[j][r] * v[j][r];
+          }
+        const float var = em_butterfly64(d2) * 0.015625f;
+        const float rstd = 1.0f / sqrtf(var + LR_LN_EPS);
+        if (live) {
+          float* y = p.OUT + (size_t)gr * 64;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int f = j * 32 + 8 * g + 4 * half;
+              const float4 w4 = *reinterpret_cast<const float4*>(lnp + f);
+              const float4 c4 = *reinterpret_cast<const float4*>(lnp + 64 + f);
+              float4 o;
+              o.x = lr_fma(v[j][4 * g + 0] * rstd, w4.x, c4.x);
+              o.y = lr_fma(v[j][4 * g + 1] * rstd, w4.y, c4.y);
+              o.z = lr_fma(v[j][4 * g + 2] * rstd, w4.z, c4.z);
+              o.w = lr_fma(v[j][4 * g + 3] * rstd, w4.w, c4.w);
+              *reinterpret_cast<float4*>(y + f) = o;
+            }
+        }
+      }
+      EM_STAMP(11);
     }
   }
+#ifdef LR_EXPERIMENTS
+  if (p.stamp && tid == 0 && blockIdx.x < 16)
+    for (int k = 0; k < 12; ++k) g_em_stamps[MODE][blockIdx.x][k] = st_acc[k];
+#endif
 }
 
-// ---- the recurrence over each user's rows, in place on U (re | im) -------------------------------------------
-__global__ __launch_bounds__(128) void em_scan_kernel(EmChunk c, const float* lam_re, const float* lam_im, float* U) {
-  const int u = blockIdx.x, ch = threadIdx.x;
-  const int n = c.n[u];
-  float* base = U + (size_t)c.off[u] * 256;
-  const float lr_ = lam_re[ch], li = lam_im[ch];
-  float h_r = 0.f, h_i = 0.f;
-#pragma unroll 4
-  for (int t = 0; t < n; ++t) {
-    const float br = base[(size_t)t * 256 + ch], bi = base[(size_t)t * 256 + 128 + ch];
-    if (t == 0) {
-      h_r = br;
-      h_i = bi;
-    } else {
-      const float nr = lr_fma(lr_, h_r, lr_fma(-li, h_i, br));
-      const float ni = lr_fma(lr_, h_i, lr_fma(li, h_r, bi));
-      h_r = nr;
-      h_i = ni;
-    }
-    base[(size_t)t * 256 + ch] = h_r;
-    base[(size_t)t * 256 + 128 + ch] = h_i;
-  }
+#ifdef LR_EXPERIMENTS
+extern "C" int lr_debug_em_stamps(unsigned long long* out, int n) {
+  if (!out || n != 4 * 16 * 12) LR_FAIL(LR_EINVAL, "lr_debug_em_stamps: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_em_stamps), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
 }
+#endif
 
 // =============================================================================================
-#define EM_CHUNK_ROWS (1 << 21)  // rows per chunk of users (workspace: 1.5 KB per row, at most 3.2 GB; proportional to B*L below that)
+#define EM_CHUNK_ROWS (1 << 21)  // rows per chunk of users (workspace: 0.5 KB per row, at most 1.1 GB; proportional to B*L below that)
+#define EM_MAX_WGS 256           // layer workgroups: one per CU (156 KiB of LDS each)
 
 static size_t em_chunk_users(int L) {
   size_t u = EM_CHUNK_ROWS / (size_t)L;
@@ -359,12 +655,20 @@ size_t lr_encoder_mfma_workspace_bytes(int B, int L) {
   const size_t users = (size_t)B < em_chunk_users(L) ? (size_t)B : em_chunk_users(L);
   const size_t rows = users * L;
   size_t o = 0;
-  o += lr_align_up((2 * users + (users + 1)) * sizeof(int), 256);
+  o += lr_align_up((2 * users + (users + 1) + (EM_MAX_WGS + 1) + 2 * rows) * sizeof(int), 256);
   o += lr_align_up(rows * 64 * sizeof(float), 256) * 2;   // X, Y
-  o += lr_align_up(rows * 256 * sizeof(float), 256);      // U / A
+  o += lr_align_up(users * 256 * sizeof(float), 256);     // recurrence state of the last rows
   o += lr_align_up(users * 64 * sizeof(float), 256);      // Y of the last rows
-  o += lr_align_up(users * 256 * sizeof(float), 256);     // A of the last rows
   return o;
+}
+
+template <int MODE>
+static int em_launch_layer(int grid, size_t lds, hipStream_t st, const EmLayer& p) {
+  static bool lds_set[LR_MAX_DEVICES] = {};
+  if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(em_layer_kernel<MODE>), (int)lds, lds_set)) return rc;
+  hipLaunchKernelGGL(em_layer_kernel<MODE>, dim3(grid), dim3(256), lds, st, p);
+  LR_CHECK_LAUNCH("em_layer_kernel");
+  return LR_OK;
 }
 
 int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L, float* out_q, void* ws,
@@ -383,15 +687,12 @@ int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L,
     p += lr_align_up(bytes, 256);
     return at;
   };
-  int* ibuf = (int*)take((2 * users_cap + (users_cap + 1)) * sizeof(int));
+  int* ibuf = (int*)take((2 * users_cap + (users_cap + 1) + (EM_MAX_WGS + 1) + 2 * rows_cap) * sizeof(int));
   float* X = (float*)take(rows_cap * 64 * sizeof(float));
   float* Y = (float*)take(rows_cap * 64 * sizeof(float));
-  float* U = (float*)take(rows_cap * 256 * sizeof(float));
+  float* Ul = (float*)take(users_cap * 256 * sizeof(float));
   float* Yl = (float*)take(users_cap * 64 * sizeof(float));
-  float* Al = (float*)take(users_cap * 256 * sizeof(float));
-  static bool lds_set[LR_MAX_DEVICES] = {};
-  const size_t lds256 = (size_t)(64 * EM_WS + 4 * EM_TILE * EM_XS) * sizeof(float);
-  if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(em_proj256_ln_kernel), (int)lds256, lds_set)) return rc;
+  const size_t lds = (size_t)(64 * EM_WS + EM_ST * EM_US + EM_ST * EM_XS + 2 * 16 * 64 + 128 + EM_ST + LR_ERF_NINT * EM_ERF_ROW + 512) * sizeof(float);
   LrProfScope prof(LR_PROF_LRU_ENCODE, (double)B, st);
   const int nb = lay.num_blocks;
   for (size_t u0 = 0; u0 < (size_t)B; u0 += cu) {
@@ -402,48 +703,54 @@ int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L,
     c.ids = ids + u0 * L;
     c.n = ibuf;
     c.off = ibuf + users_cap;
-    c.last_row = ibuf + users_cap + (users_cap + 1);
-    const int* n_rows_ptr = c.off + c.users;
-    const int max_tiles = (int)(((size_t)c.users * L + EM_TILE - 1) / EM_TILE);
-    const int grid64 = max_tiles < 1024 ? max_tiles : 1024;
-    const int grid256 = (max_tiles + 3) / 4 < 256 ? (max_tiles + 3) / 4 : 256;  // one workgroup per CU stages the 64 KiB of weights once
-    const int last_tiles = (c.users + EM_TILE - 1) / EM_TILE;
+    c.last_row = c.off + (users_cap + 1);
+    c.wg_row = c.last_row + users_cap;
+    c.row_tag = c.wg_row + (EM_MAX_WGS + 1);
+    c.row_item = c.row_tag + rows_cap;
+    const size_t max_st = ((size_t)c.users * L + EM_ST - 1) / EM_ST;   // super tiles if every position were live
+    c.G = (int)(max_st < EM_MAX_WGS ? max_st : EM_MAX_WGS);
+    const int last_st = (c.users + EM_ST - 1) / EM_ST;
+    const int grid_last = last_st < EM_MAX_WGS ? last_st : EM_MAX_WGS;
     hipLaunchKernelGGL(em_live_kernel, dim3((c.users + 3) / 4), dim3(256), 0, st, c);
     LR_CHECK_LAUNCH("em_live_kernel");
     hipLaunchKernelGGL(em_offsets_kernel, dim3(1), dim3(1024), 0, st, c);
     LR_CHECK_LAUNCH("em_offsets_kernel");
-    hipLaunchKernelGGL(em_embed_kernel, dim3(c.users), dim3(256), 0, st, c, img, lay, X);
+    const long long cells = (long long)c.users * L;
+    hipLaunchKernelGGL(em_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, c);
+    LR_CHECK_LAUNCH("em_rows_kernel");
+    const long long embed_wgs = (cells + 15) / 16;  // upper bound of the live rows / 16
+    hipLaunchKernelGGL(em_embed_kernel, dim3((unsigned)(embed_wgs < 256 * 16 ? embed_wgs : 256 * 16)), dim3(256), 0, st, c, img, lay, X);
     LR_CHECK_LAUNCH("em_embed_kernel");
     for (int b = 0; b < nb; ++b) {
       const LrLruBlockLayout& BL = lay.blk[b];
-      const bool last = b == nb - 1;
-      hipLaunchKernelGGL(em_proj64_kernel<0>, dim3(grid64), dim3(256), 0, st, img + BL.in_wt, img + BL.in_b, img + BL.gamma, X,
-                         (const int*)nullptr, n_rows_ptr, 0, U, 0);
-      LR_CHECK_LAUNCH("em_proj64_kernel<in_proj>");
-      hipLaunchKernelGGL(em_scan_kernel, dim3(c.users), dim3(128), 0, st, c, img + BL.lam_re, img + BL.lam_im, U);
-      LR_CHECK_LAUNCH("em_scan_kernel");
-      if (!last) {
-        hipLaunchKernelGGL(em_proj256_ln_kernel, dim3(grid256), dim3(256), lds256, st, img + BL.out_wt, img + BL.out_b,
-                           img + BL.ln1_w, img + BL.ln1_b, U, (const int*)nullptr, X, (const int*)nullptr, n_rows_ptr, 0, Y);
-        LR_CHECK_LAUNCH("em_proj256_ln_kernel<out_proj>");
-        hipLaunchKernelGGL(em_proj64_kernel<1>, dim3(grid64), dim3(256), 0, st, img + BL.w1t, img + BL.b1, (const float*)nullptr,
-                           Y, (const int*)nullptr, n_rows_ptr, 0, U, 0);
-        LR_CHECK_LAUNCH("em_proj64_kernel<ffn1>");
-        hipLaunchKernelGGL(em_proj256_ln_kernel, dim3(grid256), dim3(256), lds256, st, img + BL.w2t, img + BL.b2, img + BL.ln2_w,
-                           img + BL.ln2_b, U, (const int*)nullptr, Y, (const int*)nullptr, n_rows_ptr, 0, X);
-        LR_CHECK_LAUNCH("em_proj256_ln_kernel<ffn2>");
+      EmLayer lru = {};
+#ifdef LR_EXPERIMENTS
+      static const int stamp = getenv("LR_EM_STAMPS") ? atoi(getenv("LR_EM_STAMPS")) : 0;
+      lru.stamp = stamp;
+#endif
+      lru.wa = img + BL.in_wt; lru.ba = img + BL.in_b; lru.gamma = img + BL.gamma;
+      lru.lam_re = img + BL.lam_re; lru.lam_im = img + BL.lam_im;
+      lru.wb = img + BL.out_wt; lru.bb = img + BL.out_b; lru.lnw = img + BL.ln1_w; lru.lnb = img + BL.ln1_b;
+      lru.IN = X; lru.RES = X; lru.row_tag = c.row_tag; lru.wg_row = c.wg_row;
+      EmLayer ffn = {};
+#ifdef LR_EXPERIMENTS
+      ffn.stamp = stamp;
+#endif
+      ffn.wa = img + BL.w1t; ffn.ba = img + BL.b1;
+      ffn.wb = img + BL.w2t; ffn.bb = img + BL.b2; ffn.lnw = img + BL.ln2_w; ffn.lnb = img + BL.ln2_b;
+      if (b < nb - 1) {
+        lru.OUT = Y;
+        if (int rc = em_launch_layer<0>(c.G, lds, st, lru)) return rc;
+        ffn.IN = Y; ffn.RES = Y; ffn.OUT = X; ffn.n_rows_ptr = c.off + c.users;  // no recurrence: super tiles strided over the rows
+        if (int rc = em_launch_layer<1>(c.G, lds, st, ffn)) return rc;
       } else {  // only each user's last row is consumed after the last block
-        hipLaunchKernelGGL(em_proj256_ln_kernel, dim3((last_tiles + 3) / 4), dim3(256), lds256, st, img + BL.out_wt, img + BL.out_b,
-                           img + BL.ln1_w, img + BL.ln1_b, U, (const int*)c.last_row, X, (const int*)c.last_row,
-                           (const int*)nullptr, c.users, Yl);
-        LR_CHECK_LAUNCH("em_proj256_ln_kernel<out_proj,last>");
-        hipLaunchKernelGGL(em_proj64_kernel<1>, dim3(last_tiles), dim3(256), 0, st, img + BL.w1t, img + BL.b1,
-                           (const float*)nullptr, Yl, (const int*)nullptr, (const int*)nullptr, c.users, Al, 0);
-        LR_CHECK_LAUNCH("em_proj64_kernel<ffn1,last>");
-        hipLaunchKernelGGL(em_proj256_ln_kernel, dim3((last_tiles + 3) / 4), dim3(256), lds256, st, img + BL.w2t, img + BL.b2,
-                           img + BL.ln2_w, img + BL.ln2_b, Al, (const int*)nullptr, Yl, (const int*)nullptr,
-                           (const int*)nullptr, c.users, out_q + u0 * 64);
-        LR_CHECK_LAUNCH("em_proj256_ln_kernel<ffn2,last>");
+        lru.OUT = Ul;
+        if (int rc = em_launch_layer<2>(c.G, lds, st, lru)) return rc;
+        EmLayer outp = lru;
+        outp.IN = Ul; outp.res_rows = c.last_row; outp.OUT = Yl; outp.wg_row = nullptr; outp.n_rows_fixed = c.users;
+        if (int rc = em_launch_layer<3>(grid_last, lds, st, outp)) return rc;
+        ffn.IN = Yl; ffn.RES = Yl; ffn.OUT = out_q + u0 * 64; ffn.n_rows_fixed = c.users;
+        if (int rc = em_launch_layer<1>(grid_last, lds, st, ffn)) return rc;
       }
     }
   }
