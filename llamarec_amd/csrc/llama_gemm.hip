@@ -48,15 +48,18 @@ struct RopeArgs {
 
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
 template <int EPI>
+// pre_rs / pre_pos: the row's folded-norm scale / token position when the caller fetched them ahead of the epilogue
+// (gemm256rb_kernel requests them before its K loop); nullptr: fetched here.
 __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off,
-                                           const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0) {
+                                           const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0,
+                                           const float* pre_rs = nullptr, const int* pre_pos = nullptr) {
   u16x4 o;
   if (EPI == LR_EPI_PARTIAL) {  // C is the fp32 partial plane of this split
     *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(C) + off) = v;
     return;
   }
   if ((EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale) {
-    const float rs = rope.row_scale[row];
+    const float rs = pre_rs ? *pre_rs : rope.row_scale[row];
     v *= rs;
     up *= rs;
   }
@@ -67,7 +70,8 @@ __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const 
     if (col < rope.rot_cols) {
       const int half = rope.head_dim >> 1;
       const int i0 = (col % rope.head_dim) >> 1;
-      const float4 t = *reinterpret_cast<const float4*>(rope.cs + ((size_t)rope.tok_pos[row] * half + i0) * 2);
+      const int pos = pre_pos ? *pre_pos : rope.tok_pos[row];
+      const float4 t = *reinterpret_cast<const float4*>(rope.cs + ((size_t)pos * half + i0) * 2);
       o[0] = f2bf(x[0] * t.x - x[1] * t.y);
       o[1] = f2bf(x[1] * t.x + x[0] * t.y);
       o[2] = f2bf(x[2] * t.z - x[3] * t.w);
@@ -317,6 +321,18 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+  // One per-row epilogue input of my 8 rows is requested now (at the end of the K loop nothing would hide its latency):
+  // the token position for the rotation (its cos / sin read depends on it), the folded-norm scale for SwiGLU.
+  float pre[8];
+  const bool has_rs = (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale != nullptr;
+  if (EPI == LR_EPI_ROPE || (EPI == LR_EPI_SWIGLU && has_rs)) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1);
+      pre[mt] = EPI == LR_EPI_ROPE ? __builtin_bit_cast(float, rope.tok_pos[row]) : rope.row_scale[row];
+    }
+  }
+
   bf16x8 afr[8], b0x[4], b0y[4], b1[4];
 
 #define RB_LOAD_A(buf, mh)                                                                            \
@@ -416,13 +432,14 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col, rope, row, col);
+          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col, rope, row, col, has_rs ? &pre[mt] : nullptr, nullptr);
         }
       } else {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col);
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col, nullptr,
+                          EPI == LR_EPI_ROPE ? reinterpret_cast<const int*>(&pre[mt]) : nullptr);
         }
       }
     }
