@@ -240,6 +240,8 @@ __device__ __forceinline__ void em_gelu_tab12(const float (&x)[N], float (&y)[N]
 //     feature f + feature f+32, exactly that hand-over) and stores the row.
 // Per row the arithmetic is that of lru_encoder.hip: which rows share a tile never changes a row's chain.
 #define EM_ST 64   // rows per super tile
+#define EM_THREADS 512  // 8 waves, two per SIMD: the epilogues, the recurrence and the staging are VALU / issue bound, and
+                        // one wave alone issues a vector instruction every 4 cycles, two waves one every 2
 #define EM_US 260  // LDS row stride (floats) of a 256-float row: 16-byte aligned, conflict-free ds_read_b128
 #define EM_WS 260  // same for the K = 256 weight rows
 
@@ -284,20 +286,19 @@ struct EmLayer {
 
 __device__ __forceinline__ int em_pos(int out) { return (out >> 6) * 64 + (out & 1) * 32 + ((out & 63) >> 1); }
 
-// floats [part*16, part*16 + 16) of row r0 + row of a [.][64] matrix; zeros past rb
-__device__ __forceinline__ void em_load_rows16(float4 (&v)[4], const float* M, int r0, int rb, int row, int part) {
+// floats [part*8, part*8 + 8) of row r0 + row of a [.][64] matrix; zeros past rb
+__device__ __forceinline__ void em_load_rows8(float4 (&v)[2], const float* M, int r0, int rb, int row, int part) {
   if (r0 + row < rb) {
-    const float* src = M + (size_t)(r0 + row) * 64 + part * 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(src + 4 * i);
+    const float* src = M + (size_t)(r0 + row) * 64 + part * 8;
+    v[0] = *reinterpret_cast<const float4*>(src);
+    v[1] = *reinterpret_cast<const float4*>(src + 4);
   } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[0] = v[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void em_layer_kernel(EmLayer p) {
+__global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void em_layer_kernel(EmLayer p) {
   constexpr bool HAS_A = MODE != 3, HAS_B = MODE != 2, SCAN = MODE == 0 || MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   float* ws = smem_f;                    // [64][EM_WS]   phase B weights, de-interleaved per 64-k chunk
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (ra >= rb) return;
 
   if (HAS_B) {
-    for (int i = tid; i < 64 * 256; i += 256) {
+    for (int i = tid; i < 64 * 256; i += EM_THREADS) {
       const int k = i >> 6, out = i & 63;  // coalesced read of W[k][out]
       ws[out * EM_WS + (k >> 6) * 64 + (k & 1) * 32 + ((k & 63) >> 1)] = p.wb[i];
     }
@@ -335,26 +336,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else if (tid < 128) lnp[tid] = p.lnb[tid - 64];
   }
   if (MODE == 1)
-    for (int i = tid; i < LR_ERF_NINT * EM_ERF_ROW; i += 256) {
+    for (int i = tid; i < LR_ERF_NINT * EM_ERF_ROW; i += EM_THREADS) {
       const int c = i % EM_ERF_ROW;
       erf_lds[i] = c <= LR_ERF_DEG ? em_erf_tab[(i / EM_ERF_ROW) * (LR_ERF_DEG + 1) + c] : 0.f;
     }
-  // phase A operand B: weights of my two output blocks, de-interleaved k: step s of half h uses k = 2s + h
-  float wq[2][32], bq[2], gq[2];
+  // phase A operand B: weights of my output block (wave w: outputs 32w .. 32w+31), de-interleaved k: step s of half h
+  // uses k = 2s + h
+  float wq[32], bq = 0.f, gq = 0.f;
   if (HAS_A) {
+    const int out = wave * 32 + col;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int out = (2 * wave + j) * 32 + col;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) wq[j][s] = p.wa[(size_t)(2 * s + half) * 256 + out];
-      bq[j] = p.ba[out];
-      gq[j] = MODE == 1 ? 0.f : p.gamma[out & 127];
-    }
+    for (int s = 0; s < 32; ++s) wq[s] = p.wa[(size_t)(2 * s + half) * 256 + out];
+    bq = p.ba[out];
+    gq = MODE == 1 ? 0.f : p.gamma[out & 127];
   }
-  // phase B: my chain = feature block jb of row tile rt
-  const int rt = wave >> 1, jb = wave & 1;
+  // phase B (waves 0..3, one per SIMD: the chains are MFMA bound): my chain = feature block jb of row tile rt
+  const int rt = (wave >> 1) & 1, jb = wave & 1;
   float bb[16];
-  if (HAS_B) {
+  if (HAS_B && wave < 4) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) bb[r] = p.bb[jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
   }
@@ -370,8 +369,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<float4*>(carry + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);  // every wave: same zeros
   }
 
-  float4 pre[4];  // my 16 floats of the NEXT super tile's phase A input: their latency hides behind this tile's MFMAs
-  if (HAS_A) em_load_rows16(pre, p.IN, ra, rb, tid >> 2, tid & 3);
+  float4 pre[2];  // my 8 floats of the NEXT super tile's phase A input: their latency hides behind this tile's MFMAs
+  if (HAS_A) em_load_rows8(pre, p.IN, ra, rb, tid >> 3, tid & 7);
   int par = 0;
   int pre_tag = 1;  // rows past the range restart the recurrence and are never a user's last row
   if (SCAN && tid < EM_ST && ra + tid < rb) pre_tag = p.row_tag[ra + tid];
@@ -382,19 +381,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     EM_BARRIER();  // the previous super tile is consumed
     EM_STAMP(1);
     {
-      const int row = tid >> 2, part = tid & 3;
-      if (HAS_A) {  // 16 floats of a 64-float row (loaded one super tile ahead), de-interleaved: xs[row][h*32 + s] = x[row][2s + h]
-        float* dst = xs + row * EM_XS + part * 8;  // even k -> [part*8, +8), odd k -> 32 + the same: four 16-byte stores
+      const int row = tid >> 3, part = tid & 7;
+      if (HAS_A) {  // 8 floats of a 64-float row (loaded one super tile ahead), de-interleaved: xs[row][h*32 + s] = x[row][2s + h]
+        float* dst = xs + row * EM_XS + part * 4;  // even k -> [part*4, +4), odd k -> 32 + the same: two 16-byte stores
         *reinterpret_cast<float4*>(dst) = make_float4(pre[0].x, pre[0].z, pre[1].x, pre[1].z);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(pre[2].x, pre[2].z, pre[3].x, pre[3].z);
         *reinterpret_cast<float4*>(dst + 32) = make_float4(pre[0].y, pre[0].w, pre[1].y, pre[1].w);
-        *reinterpret_cast<float4*>(dst + 36) = make_float4(pre[2].y, pre[2].w, pre[3].y, pre[3].w);
-        em_load_rows16(pre, p.IN, r0 + step, rb, row, part);
-      } else {  // MODE 3: one 64-k chunk of a 256-float row, de-interleaved inside the chunk
-        float* dst = ul + row * EM_US + part * 64;
-        const float* src = p.IN + (size_t)(r0 + (row < nv ? row : 0)) * 256 + part * 64;
+        em_load_rows8(pre, p.IN, r0 + step, rb, row, part);
+      } else {  // MODE 3: half of a 64-k chunk of a 256-float row, de-interleaved inside the chunk
+        float* dst = ul + row * EM_US + (part >> 1) * 64 + (part & 1) * 16;
+        const float* src = p.IN + (size_t)(r0 + (row < nv ? row : 0)) * 256 + part * 32;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 8; ++i) {
           float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
           if (row >= nv) v = make_float4(0.f, 0.f, 0.f, 0.f);
           dst[2 * i] = v.x;
@@ -422,15 +419,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const float4 v4 = *reinterpret_cast<const float4*>(xr + 4 * q);
           a[4 * q + 0] = v4.x; a[4 * q + 1] = v4.y; a[4 * q + 2] = v4.z; a[4 * q + 3] = v4.w;
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        {
           floatx16 acc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = bq[j];
+          for (int r = 0; r < 16; ++r) acc[r] = bq;
 #pragma unroll
-          for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wq[j][s], acc, 0, 0, 0);
+          for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wq[s], acc, 0, 0, 0);
           // D[token i][out]: lane = out column, register r = token (r&3) + 8*(r>>2) + 4*half
-          float* dst = ul + wave * 64 + (col & 1) * 32 + j * 16 + (col >> 1);  // em_pos((2*wave + j)*32 + col)
+          float* dst = ul + (wave >> 1) * 64 + (col & 1) * 32 + (wave & 1) * 16 + (col >> 1);  // em_pos(wave*32 + col)
 #pragma unroll
           for (int r8 = 0; r8 < 16; r8 += 8) {
             float xin[8], val[8];
@@ -440,7 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               em_gelu_tab12<8>(xin, val, erf_lds);
             } else {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) val[i] = xin[i] * gq[j];
+              for (int i = 0; i < 8; ++i) val[i] = xin[i] * gq;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -457,19 +453,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     if (SCAN) {
-      // The 64 rows are cut at users' first rows into up to four segments (cuts at the first start at or after row 16,
-      // 32, 48); wave w walks segment w. Only segment 0 can continue a user of the previous super tile: its carry comes
+      // The 64 rows are cut at users' first rows into up to eight segments (cuts at the first start at or after row 8,
+      // 16, .. 56); wave w walks segment w. Only segment 0 can continue a user of the previous super tile: its carry comes
       // from the wave that walked row 63 there, through LDS.
       const int tg_lane = tags[lane];
       const unsigned long long firsts = __ballot(tg_lane & 1);
       const unsigned long long lasts = __ballot(tg_lane & 2);
       int sa = 0, sb = EM_ST;
       if (wave > 0) {
-        const unsigned long long m = firsts & (~0ull << (16 * wave));
+        const unsigned long long m = firsts & (~0ull << (8 * wave));
         sa = m ? __builtin_ctzll(m) : EM_ST;
       }
-      if (wave < 3) {
-        const unsigned long long m = firsts & (~0ull << (16 * (wave + 1)));
+      if (wave < 7) {
+        const unsigned long long m = firsts & (~0ull << (8 * (wave + 1)));
         sb = m ? __builtin_ctzll(m) : EM_ST;
       }
       sa = __builtin_amdgcn_readfirstlane(sa);
@@ -531,6 +527,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int lrow = rt * 32 + col;
       const bool live = lrow < nv;
       const int gr = r0 + lrow;
+      float v[2][16];
+      if (wave < 4) {
       float4 r4[4];  // residual, requested before the chain
       {
         const float* res = p.RES + (size_t)(live ? (p.res_rows ? p.res_rows[gr] : gr) : 0) * 64;
@@ -544,8 +542,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       {
         const float* wr = ws + (jb * 32 + col) * EM_WS + 32 * half;   // feature row jb*32 + col
         const float* tr = ul + (rt * 32 + col) * EM_US + 32 * half;   // token row rt*32 + col
-        // operands of the next 8 steps are requested before the 8 MFMAs of the current ones (one wave per SIMD: nothing
-        // else hides the LDS latency)
+        // operands of the next 8 steps are requested before the 8 MFMAs of the current ones (the partner wave of the
+        // SIMD is idle here: nothing else hides the LDS latency)
         float4 wc[2], bc[2], wn[2], bn[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -578,7 +576,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
       EM_STAMP(8);
-      float v[2][16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         v[0][4 * g + 0] = acc[4 * g + 0] + r4[g].x;
@@ -590,10 +587,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) ex[(rt * 16 + r) * 64 + lane] = v[0][r];
       }
+      }  // wave < 4
       EM_STAMP(9);
       EM_BARRIER();
       EM_STAMP(10);
-      if (jb == 0) {
+      if (jb == 0 && wave < 4) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[1][r] = ex[(rt * 16 + r) * 64 + lane];
         const float mean = em_butterfly64(v) * 0.015625f;
@@ -666,7 +664,7 @@ template <int MODE>
 static int em_launch_layer(int grid, size_t lds, hipStream_t st, const EmLayer& p) {
   static bool lds_set[LR_MAX_DEVICES] = {};
   if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(em_layer_kernel<MODE>), (int)lds, lds_set)) return rc;
-  hipLaunchKernelGGL(em_layer_kernel<MODE>, dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(em_layer_kernel<MODE>, dim3(grid), dim3(EM_THREADS), lds, st, p);
   LR_CHECK_LAUNCH("em_layer_kernel");
   return LR_OK;
 }

@@ -228,3 +228,31 @@ def test_candidate_path_adversarial(variant):
     assert np.array_equal(_bits(sc.cpu().numpy()), _bits(os_))
     idx2, sc2 = model.retrieve_topk(ids[5:6], K, excl)      # alone in the call: same list
     assert np.array_equal(idx2.cpu().numpy(), oi[5:6]) and np.array_equal(_bits(sc2.cpu().numpy()), _bits(os_[5:6]))
+
+
+def test_encoder_chunks_segments_and_batch_independence():
+    """The batched encoder beyond one chunk of users (2^21 row slots: 8 160 users at L = 257), with users of 1 .. 257 live
+    rows so that super tiles hold anything from one slice of a long user (carry across tiles, no segment cut) to a
+    dozen short users (four-way segment cut): a spread sample equals the oracle bit for bit, and a user's state does not
+    depend on which other users share the call (row ranges, tiles and segments all move with the batch)."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from oracle import lru_oracle as O
+
+    V, L, B = 1500, 257, 9000
+    rng = np.random.default_rng(11)
+    sd = init_lru_state_dict(V, seed=9)
+    ids = np.zeros((B, L), np.int64)
+    n = rng.integers(1, L + 1, size=B)
+    short = rng.random(B) < 0.6
+    n[short] = rng.integers(1, 12, size=int(short.sum()))
+    n[:4] = (L, 1, 64, 65)
+    for b in range(B):
+        ids[b, L - n[b]:] = rng.integers(1, V + 1, size=n[b])
+    model = LRURec.from_state_dict(sd)
+    q = model.encode_last(ids).cpu().numpy()
+    sample = np.concatenate([np.arange(0, 6), np.arange(8150, 8170, 4), np.arange(B - 3, B)])
+    want = O.LruOracle(sd).encode_last(ids[sample])
+    assert np.array_equal(_bits(q[sample]), _bits(want))
+    sub = np.concatenate([np.arange(100, 400), np.arange(8000, 8300)])
+    q_sub = model.encode_last(ids[sub]).cpu().numpy()
+    assert np.array_equal(_bits(q_sub), _bits(q[sub]))
