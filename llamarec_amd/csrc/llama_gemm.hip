@@ -47,17 +47,12 @@ struct RopeArgs {
 };
 
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
-template <int EPI>
 // pre_rs / pre_pos: the row's folded-norm scale / token position when the caller fetched them ahead of the epilogue
-// (gemm256rb_kernel requests them before its K loop); nullptr: fetched here.
-__device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off,
-                                           const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0,
-                                           const float* pre_rs = nullptr, const int* pre_pos = nullptr) {
+// (gemm256rb_kernel requests them before its K loop); nullptr: fetched here. r: the residual's 4 values (RESIDUAL only).
+template <int EPI>
+__device__ __forceinline__ u16x4 epi_value4(floatx4 v, floatx4 up, u16x4 r, const RopeArgs& rope, int row, int col,
+                                            const float* pre_rs, const int* pre_pos) {
   u16x4 o;
-  if (EPI == LR_EPI_PARTIAL) {  // C is the fp32 partial plane of this split
-    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(C) + off) = v;
-    return;
-  }
   if ((EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale) {
     const float rs = pre_rs ? *pre_rs : rope.row_scale[row];
     v *= rs;
@@ -84,14 +79,26 @@ __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
   } else if (EPI == LR_EPI_RESIDUAL) {
-    u16x4 r = *reinterpret_cast<const u16x4*>(R + off);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(f2bf(v[j])) + bf2f(r[j]));
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = swiglu_bf16(bf2f(f2bf(v[j])), bf2f(f2bf(up[j])));
   }
-  *reinterpret_cast<u16x4*>(C + off) = o;
+  return o;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off,
+                                           const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0,
+                                           const float* pre_rs = nullptr, const int* pre_pos = nullptr) {
+  if (EPI == LR_EPI_PARTIAL) {  // C is the fp32 partial plane of this split
+    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(C) + off) = v;
+    return;
+  }
+  u16x4 r = u16x4{0, 0, 0, 0};
+  if (EPI == LR_EPI_RESIDUAL) r = *reinterpret_cast<const u16x4*>(R + off);
+  *reinterpret_cast<u16x4*>(C + off) = epi_value4<EPI>(v, up, r, rope, row, col, pre_rs, pre_pos);
 }
 
 // =============================================================================================
@@ -321,16 +328,14 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // One per-row epilogue input of my 8 rows is requested now (at the end of the K loop nothing would hide its latency):
-  // the token position for the rotation (its cos / sin read depends on it), the folded-norm scale for SwiGLU.
+  // Folded RMSNorm + SwiGLU: the scale of my 8 rows is requested now (at the end of the K loop nothing would hide its
+  // latency). The rotation's inputs are fetched in the epilogue: 8 more live registers spill that variant.
   float pre[8];
   const bool has_rs = (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale != nullptr;
-  if (EPI == LR_EPI_ROPE || (EPI == LR_EPI_SWIGLU && has_rs)) {
+  const bool pre_rs = EPI == LR_EPI_SWIGLU && has_rs;
+  if (pre_rs) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int row = min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1);
-      pre[mt] = EPI == LR_EPI_ROPE ? __builtin_bit_cast(float, rope.tok_pos[row]) : rope.row_scale[row];
-    }
+    for (int mt = 0; mt < 8; ++mt) pre[mt] = rope.row_scale[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
   }
 
   bf16x8 afr[8], b0x[4], b0y[4], b1[4];
@@ -423,24 +428,72 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #undef RB_WAIT
 #undef RB_TILE
 
+  // A lane holds 4 consecutive columns (8 bytes) of its row per 16-column tile. v_permlane16_swap on the packed pairs of
+  // neighbouring tiles leaves even lane quads with 8 consecutive columns of the first tile and odd quads with 8 of the
+  // second: 16-byte stores (and residual loads: the swap is its own inverse, so the 16 bytes read at the store position
+  // swap back into each lane's own columns). Partners share lane & 15, i.e. the row: the row guard never splits a pair.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
+  const int quad = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
-    if (row < M) {
-      if (EPI == LR_EPI_SWIGLU) {
+    const bool live = row < M;
+    const int rowc = live ? row : M - 1;
+    const float* prs = pre_rs ? &pre[mt] : nullptr;
+    const int* ppos = nullptr;
+    if (EPI == LR_EPI_PARTIAL) {
+      if (live) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = ((n0 + wn * 64) >> 1) + t * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][2 * t], acc[mt][2 * t + 1], C, R, (size_t)row * ldc + col, rope, row, col, has_rs ? &pre[mt] : nullptr, nullptr);
-        }
-      } else {
+        for (int nt = 0; nt < 4; ++nt)
+          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + n0 + wn * 64 + nt * 16 + quad * 4);
+      }
+    } else if (EPI == LR_EPI_SWIGLU) {
+      const int cbase = (n0 + wn * 64) >> 1;   // 32 output columns: tiles t = 0, 1 of 16
+      unsigned a[2], b[2];
+      {
+        const u16x4 oa = epi_value4<EPI>(acc[mt][0], acc[mt][1], u16x4{0, 0, 0, 0}, rope, rowc, cbase + quad * 4, prs, ppos);
+        const u16x4 ob = epi_value4<EPI>(acc[mt][2], acc[mt][3], u16x4{0, 0, 0, 0}, rope, rowc, cbase + 16 + quad * 4, prs, ppos);
+        a[0] = (unsigned)oa[0] | ((unsigned)oa[1] << 16); a[1] = (unsigned)oa[2] | ((unsigned)oa[3] << 16);
+        b[0] = (unsigned)ob[0] | ((unsigned)ob[1] << 16); b[1] = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
+      }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
-          epi_store4<EPI>(acc[mt][nt], acc[mt][nt], C, R, (size_t)row * ldc + col, rope, row, col, nullptr,
-                          EPI == LR_EPI_ROPE ? reinterpret_cast<const int*>(&pre[mt]) : nullptr);
+      for (int w = 0; w < 2; ++w) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(a[w], b[w], false, false);
+        a[w] = sw[0];
+        b[w] = sw[1];
+      }
+      if (live)
+        *reinterpret_cast<u32x4*>(C + (size_t)row * ldc + cbase + (quad & 1) * 16 + (quad >> 1) * 8) = u32x4{a[0], a[1], b[0], b[1]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {   // tiles 2k, 2k + 1
+        const int cpair = n0 + wn * 64 + k * 32;
+        const size_t wide = (size_t)rowc * ldc + cpair + (quad & 1) * 16 + (quad >> 1) * 8;   // my 8 columns after the swap
+        u16x4 ra = u16x4{0, 0, 0, 0}, rb = ra;
+        if (EPI == LR_EPI_RESIDUAL) {
+          const u32x4 r16 = *reinterpret_cast<const u32x4*>(R + wide);
+          unsigned x[2] = {r16[0], r16[1]}, y[2] = {r16[2], r16[3]};
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+            x[w] = sw[0];
+            y[w] = sw[1];
+          }
+          ra = u16x4{(u16)(x[0] & 0xffff), (u16)(x[0] >> 16), (u16)(x[1] & 0xffff), (u16)(x[1] >> 16)};
+          rb = u16x4{(u16)(y[0] & 0xffff), (u16)(y[0] >> 16), (u16)(y[1] & 0xffff), (u16)(y[1] >> 16)};
         }
+        const u16x4 oa = epi_value4<EPI>(acc[mt][2 * k], acc[mt][2 * k], ra, rope, rowc, cpair + quad * 4, prs, ppos);
+        const u16x4 ob = epi_value4<EPI>(acc[mt][2 * k + 1], acc[mt][2 * k + 1], rb, rope, rowc, cpair + 16 + quad * 4, prs, ppos);
+        unsigned a[2] = {(unsigned)oa[0] | ((unsigned)oa[1] << 16), (unsigned)oa[2] | ((unsigned)oa[3] << 16)};
+        unsigned b[2] = {(unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16)};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(a[w], b[w], false, false);
+          a[w] = sw[0];
+          b[w] = sw[1];
+        }
+        if (live) *reinterpret_cast<u32x4*>(C + wide) = u32x4{a[0], a[1], b[0], b[1]};
       }
     }
   }
