@@ -47,11 +47,11 @@ struct RopeArgs {
 };
 
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
-// pre_rs / pre_pos: the row's folded-norm scale / token position when the caller fetched them ahead of the epilogue
-// (gemm256rb_kernel requests them before its K loop); nullptr: fetched here. r: the residual's 4 values (RESIDUAL only).
+// pre_rs / pre_pos / pre_cs: the row's folded-norm scale, token position, (cos, sin) pairs when the caller fetched them
+// ahead (gemm256rb_kernel batches all reads of its epilogue in front of the stores); nullptr: fetched here. r: the residual's 4 values (RESIDUAL only).
 template <int EPI>
 __device__ __forceinline__ u16x4 epi_value4(floatx4 v, floatx4 up, u16x4 r, const RopeArgs& rope, int row, int col,
-                                            const float* pre_rs, const int* pre_pos) {
+                                            const float* pre_rs, const int* pre_pos, const float4* pre_cs = nullptr) {
   u16x4 o;
   if ((EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale) {
     const float rs = pre_rs ? *pre_rs : rope.row_scale[row];
@@ -65,8 +65,13 @@ __device__ __forceinline__ u16x4 epi_value4(floatx4 v, floatx4 up, u16x4 r, cons
     if (col < rope.rot_cols) {
       const int half = rope.head_dim >> 1;
       const int i0 = (col % rope.head_dim) >> 1;
-      const int pos = pre_pos ? *pre_pos : rope.tok_pos[row];
-      const float4 t = *reinterpret_cast<const float4*>(rope.cs + ((size_t)pos * half + i0) * 2);
+      float4 t;
+      if (pre_cs) {
+        t = *pre_cs;
+      } else {
+        const int pos = pre_pos ? *pre_pos : rope.tok_pos[row];
+        t = *reinterpret_cast<const float4*>(rope.cs + ((size_t)pos * half + i0) * 2);
+      }
       o[0] = f2bf(x[0] * t.x - x[1] * t.y);
       o[1] = f2bf(x[1] * t.x + x[0] * t.y);
       o[2] = f2bf(x[2] * t.z - x[3] * t.w);
@@ -328,16 +333,6 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // Folded RMSNorm + SwiGLU: the scale of my 8 rows is requested now (at the end of the K loop nothing would hide its
-  // latency). The rotation's inputs are fetched in the epilogue: 8 more live registers spill that variant.
-  float pre[8];
-  const bool has_rs = (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale != nullptr;
-  const bool pre_rs = EPI == LR_EPI_SWIGLU && has_rs;
-  if (pre_rs) {
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) pre[mt] = rope.row_scale[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
-  }
-
   bf16x8 afr[8], b0x[4], b0y[4], b1[4];
 
 #define RB_LOAD_A(buf, mh)                                                                            \
@@ -435,12 +430,51 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int ldc = (EPI == LR_EPI_SWIGLU) ? (N >> 1) : N;
   const int quad = lane >> 4;
+  // Residual: all 16 reads of the lane are requested before the first store. Written load -> use -> store per pair, hipcc
+  // keeps that order (R may alias C) and every read then waits, behind vmcnt(0), for the previous pair's store as well.
+  // A lane reads exactly the 16 bytes it later writes, so taking the reads first is safe for the in-place call too.
+  u32x4 rpre[8][2];
+  if (EPI == LR_EPI_RESIDUAL) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int rowc = min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        rpre[mt][k] = *reinterpret_cast<const u32x4*>(R + (size_t)rowc * ldc + n0 + wn * 64 + k * 32 + (quad & 1) * 16 + (quad >> 1) * 8);
+    }
+  }
+  // Rotation: the 8 token positions first, then the (cos, sin) pairs of four row groups at a time (16 reads in flight,
+  // 64 registers) ahead of their stores -- one exposed latency per half instead of one per read.
+  int ppre[8];
+  if (EPI == LR_EPI_ROPE) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) ppre[mt] = rope.tok_pos[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
+  }
+  float rspre[8];  // folded RMSNorm: the scale of my 8 rows (1 when the norm is not folded)
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) rspre[mt] = 1.0f;
+  const bool has_rs = (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale != nullptr;
+  if (has_rs) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) rspre[mt] = rope.row_scale[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
+  }
+  float4 tpre[4][4];
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
+    if (EPI == LR_EPI_ROPE && (mt & 3) == 0) {
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = n0 + wn * 64 + nt * 16 + quad * 4;
+          const int colc = col < rope.rot_cols ? col : 0;   // v columns: any valid entry, not used
+          tpre[m2][nt] = *reinterpret_cast<const float4*>(rope.cs + ((size_t)ppre[mt + m2] * (rope.head_dim >> 1) + ((colc % rope.head_dim) >> 1)) * 2);
+        }
+    }
     const int row = m0 + wm * 128 + mt * 16 + (lane & 15);
     const bool live = row < M;
     const int rowc = live ? row : M - 1;
-    const float* prs = pre_rs ? &pre[mt] : nullptr;
+    const float* prs = has_rs ? &rspre[mt] : nullptr;
     const int* ppos = nullptr;
     if (EPI == LR_EPI_PARTIAL) {
       if (live) {
@@ -472,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
         const size_t wide = (size_t)rowc * ldc + cpair + (quad & 1) * 16 + (quad >> 1) * 8;   // my 8 columns after the swap
         u16x4 ra = u16x4{0, 0, 0, 0}, rb = ra;
         if (EPI == LR_EPI_RESIDUAL) {
-          const u32x4 r16 = *reinterpret_cast<const u32x4*>(R + wide);
+          const u32x4 r16 = rpre[mt][k];
           unsigned x[2] = {r16[0], r16[1]}, y[2] = {r16[2], r16[3]};
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
@@ -483,8 +517,10 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
           ra = u16x4{(u16)(x[0] & 0xffff), (u16)(x[0] >> 16), (u16)(x[1] & 0xffff), (u16)(x[1] >> 16)};
           rb = u16x4{(u16)(y[0] & 0xffff), (u16)(y[0] >> 16), (u16)(y[1] & 0xffff), (u16)(y[1] >> 16)};
         }
-        const u16x4 oa = epi_value4<EPI>(acc[mt][2 * k], acc[mt][2 * k], ra, rope, rowc, cpair + quad * 4, prs, ppos);
-        const u16x4 ob = epi_value4<EPI>(acc[mt][2 * k + 1], acc[mt][2 * k + 1], rb, rope, rowc, cpair + 16 + quad * 4, prs, ppos);
+        const u16x4 oa = epi_value4<EPI>(acc[mt][2 * k], acc[mt][2 * k], ra, rope, rowc, cpair + quad * 4, prs, ppos,
+                                         EPI == LR_EPI_ROPE ? &tpre[mt & 3][2 * k] : nullptr);
+        const u16x4 ob = epi_value4<EPI>(acc[mt][2 * k + 1], acc[mt][2 * k + 1], rb, rope, rowc, cpair + 16 + quad * 4, prs, ppos,
+                                         EPI == LR_EPI_ROPE ? &tpre[mt & 3][2 * k + 1] : nullptr);
         unsigned a[2] = {(unsigned)oa[0] | ((unsigned)oa[1] << 16), (unsigned)oa[2] | ((unsigned)oa[3] << 16)};
         unsigned b[2] = {(unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16)};
 #pragma unroll
