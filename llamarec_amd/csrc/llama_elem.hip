@@ -68,6 +68,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* ids, const in
 }
 
 // ---- RMSNorm: out = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) ) --------------------------
+// One workgroup per row. Rows of up to 8192 features stay in registers between the square sum and the scaling (each
+// thread keeps its <= 4 pieces of 8, and requests the matching weights with them): the kernel is a chain of memory
+// latencies per row, not bandwidth, and re-reading the row after the reduction added one more link. Same arithmetic,
+// same order, as the two-pass form that longer rows still take.
+#define RMS_KEEP 4
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* x, const u16* w, u16* out, int d,
                                                       float eps, const int32_t* row_map) {
   __shared__ float red[4];
@@ -76,22 +81,58 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* x, const u16* w
   const u16x8* wr = reinterpret_cast<const u16x8*>(w);
   u16x8* orow = reinterpret_cast<u16x8*>(out + (size_t)blockIdx.x * d);
   const int nv = d / 8;
+  const bool keep = nv <= 256 * RMS_KEEP;
+  u16x8 vb[RMS_KEEP], wb[RMS_KEEP];
   float ss = 0.f;
-  for (int i = threadIdx.x; i < nv; i += 256) {
-    u16x8 v = xr[i];
+  if (keep) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f = bf2f(v[j]);
-      ss = __builtin_fmaf(f, f, ss);
+    for (int k = 0; k < RMS_KEEP; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < nv) {
+        vb[k] = xr[i];
+        wb[k] = wr[i];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RMS_KEEP; ++k) {
+      if (threadIdx.x + 256 * k < nv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f(vb[k][j]);
+          ss = __builtin_fmaf(f, f, ss);
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < nv; i += 256) {
+      u16x8 v = xr[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = bf2f(v[j]);
+        ss = __builtin_fmaf(f, f, ss);
+      }
     }
   }
   ss = block_sum_256(ss, red);
   const float rstd = 1.0f / sqrtf(ss / (float)d + eps);
-  for (int i = threadIdx.x; i < nv; i += 256) {
-    u16x8 v = xr[i], wv = wr[i], o;
+  if (keep) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(f2bf(bf2f(v[j]) * rstd)));
-    orow[i] = o;
+    for (int k = 0; k < RMS_KEEP; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < nv) {
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wb[k][j]) * bf2f(f2bf(bf2f(vb[k][j]) * rstd)));
+        orow[i] = o;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < nv; i += 256) {
+      u16x8 v = xr[i], wv = wr[i], o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(f2bf(bf2f(v[j]) * rstd)));
+      orow[i] = o;
+    }
   }
 }
 
