@@ -217,9 +217,12 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
         RUN(lr_launch_attention_rows(ws.qkv, ws.att_last, cu, B, ws.last_rows, B, nh, nkv, hd, st));
       }
       RUN(lr_launch_gather_rows(ws.x, ws.last_rows, B, d, ws.x_last, st));
-      // B-row products: the generic kernel, or -- latency mode -- split-K over the 256-column tiles (weight streaming
-      // spread over 64-128 CUs instead of N / 64 workgroups of the small-tile kernel)
-      const int pv = h->gemm_variant == 5 ? 5 : 1;
+      // B-row products: split-K over the 256-column tiles (weight streaming spread over 64-128 CUs instead of N / 64
+      // workgroups of the small-tile kernel: 23 rows x 4096 x 4096 took 134 us there). With B <= 256 rows there is one
+      // row tile, so the split count depends on the weight's shape only and a prompt's arithmetic stays the same whatever
+      // else is in the batch; more prompts than that take the small-tile kernel as before. (Shapes the 256-tile kernel
+      // does not take fall back to it inside lr_launch_gemm.)
+      const int pv = (h->gemm_variant == 5 || (h->gemm_variant == 0 && B <= 256)) ? 5 : 1;
       RUN(lr_launch_gemm(ws.att_last, w.wo, ws.x_last, ws.x_last, B, d, nh * hd, LR_EPI_RESIDUAL, pv, st, nullptr, nullptr,
                          0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
       RUN(lr_launch_rmsnorm(ws.x_last, w.post_norm, ws.xn_last, B, d, c.rms_eps, nullptr, st));
