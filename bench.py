@@ -13,8 +13,8 @@ Workload = BASELINE.json north_star's "synthetic sequences of the Beauty shape" 
 L = 50, D = 64, 2 blocks) retrieve top-50 with history masking, then ONE Llama-2-7b (32 layers, bf16, random
 weights) prefill over the templated prompts of the same users and the verbalizer gather over the 20 candidate
 letters. Synthetic data per BASELINE.md section 3. A step = one pass of the hot path over one batch of users; the
-batch is the reference's eval loop re-batched by TOKEN budget (llamarec_amd/packing.py: 16 384 prompt tokens,
-about 22 Beauty users, instead of 16 prompts of whatever length -- eval order is free, dataloader/llm.py:196-202,
+batch is the reference's eval loop re-batched by TOKEN budget (llamarec_amd/packing.py: 32 768 prompt tokens,
+about 46 Beauty users, instead of 16 prompts of whatever length -- eval order is free, dataloader/llm.py:196-202,
 and a prompt's scores do not depend on its batch). Inputs (history ids, labels, prompt token ids) are resident in
 HBM before the timed region. One process per GPU over RCCL; users are sharded, weights replicated; the only
 collective is the final all-reduce of the int64 rank histograms (inside the timed region).
@@ -416,7 +416,7 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
     out = {}
     other = "ml-100k" if args.workload != "ml-100k" else "beauty"
     wo = WORKLOADS[other]
-    so, _, _, _ = build_steps(other, 0, 6, args.token_budget or 16384, args.users_per_step, dev, shared)
+    so, _, _, _ = build_steps(other, 0, 6, args.token_budget or TOKEN_BUDGET, args.users_per_step, dev, shared)
     ro = LRURec.from_state_dict(init_lru_state_dict(wo["V"], seed=42), device=dev)
     po = TwoStagePipeline(ro, ranker, label_ids, device=dev, shared_prefix=shared)
     for s in so[:2]:

@@ -7,12 +7,14 @@ execution; tests/test_gpu_llama.py::test_full_width_batch_invariance). On MI355X
 of [sum(T), K] x [K, N] GEMMs on 256 x 256 output tiles over 256 CUs, so the batch that fills the chip is
 the one whose TOKEN count -- not prompt count -- is just under a multiple of 256 rows chosen so that
 ceil(sum(T) / 256) * (N / 256) is a whole number of 256-CU rounds for every Llama-2-7b projection:
-TOKEN_BUDGET = 16384 rows = 64 row tiles -> N = 4096: 1024 tiles = 4.0 rounds, N = 12288: 12.0, N = 22016: 21.5
-(against 58 row tiles = 3.6 rounds and a 74 % full last row tile for a 16-prompt Beauty batch).
+TOKEN_BUDGET = 32768 rows = 128 row tiles -> N = 4096: 2048 tiles = 8.0 rounds, N = 12288: 24.0, N = 22016: 43.0
+(16384 rows leave gate-up at 21.5 rounds; a 16-prompt Beauty batch is 58 row tiles = 3.6 rounds with a 74 % full last
+row tile). Same-box A/B 16384 vs 32768: +0.6 % users/s; pass budget=16384 where the step latency
+or the activation workspace (about 80 KB per row) matters more.
 
 `token_budget_steps` walks the prompts in dataset order; each step takes the oldest pending prompt plus the
 subset of the next `window - 1` whose lengths add up closest to (never above) the budget (an exact
-subset-sum over Python big-int bit sets: 63 shifts of a 16 k-bit integer per step), so no prompt is
+subset-sum over Python big-int bit sets: 127 shifts of a 32 k-bit integer per step), so no prompt is
 starved and a step's token count is normally the budget itself.
 
 `shard_by_tokens` is SURVEY.md section 8(e)'s partitioning: contiguous user blocks (user ids stay positional,
@@ -22,8 +24,8 @@ from __future__ import annotations
 
 import numpy as np
 
-TOKEN_BUDGET = 16384
-WINDOW = 64
+TOKEN_BUDGET = 32768
+WINDOW = 128
 
 
 def token_budget_steps(lengths, budget: int = TOKEN_BUDGET, window: int = WINDOW, max_prompts: int | None = None,

@@ -372,18 +372,18 @@ def test_shared_prefix_rejects_bad_lengths():
 
 
 def test_full_width_shared_prefix_and_token_budget_batch():
-    """Llama-2-7b layer shapes, 2 layers: a 16 384-token batch built by llamarec_amd.packing (the bench's step) with the
+    """Llama-2-7b layer shapes, 2 layers: a 32 768-token batch built by llamarec_amd.packing (the bench's step) with the
     36-token template prefix shared gives bit-identical scores to the same prompts run unshared in the reference's
     16-prompt batches."""
     from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
-    from llamarec_amd.packing import token_budget_steps
+    from llamarec_amd.packing import TOKEN_BUDGET, token_budget_steps
     from llamarec_amd.synth import synth_prompt_tokens, synth_users
 
     model = LlamaRanker.random_init(dict(LLAMA2_7B, num_hidden_layers=2), seed=5)
-    _, _, _, T = synth_users("beauty", 60)
+    _, _, _, T = synth_users("beauty", 100)
     step = token_budget_steps(T)[0]
     ids, cu = synth_prompt_tokens(T[step], seed=4)
-    assert cu[-1] == 16384
+    assert cu[-1] == TOKEN_BUDGET == 32768
     seqs = [ids[cu[i]:cu[i + 1]] for i in range(len(step))]
     label_ids = list(range(319, 339))
     shared = model.prefill_verbalize(seqs, label_ids, share_prefix=True)
