@@ -1,5 +1,5 @@
 """How far apart are the HIP prefill, the numpy oracle in bf16 mode and the oracle in fp32 mode at Llama-2-7b WIDTH as the
-depth grows? (The oracle needs ~1 s per layer per 1000 tokens, so depth stops at 8.) Prints max-abs differences of the 20
+depth grows? (The oracle needs ~2 s per layer for these four prompts: `parity_growth.py 16,32` runs the deep end.) Prints max-abs differences of the 20
 verbalizer scores: the bf16 oracle's own distance from exact arithmetic is the yardstick for the HIP path's distance
 from the bf16 oracle (tests/test_gpu_llama.py::test_full_width_parity_vs_oracle)."""
 import os, sys, time
