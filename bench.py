@@ -410,6 +410,7 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
     import torch
 
     from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.packing import TOKEN_BUDGET
     from llamarec_amd.pipeline import TwoStagePipeline
     from llamarec_amd.synth import WORKLOADS
 
