@@ -297,3 +297,69 @@ def test_lora_trainer_refuses_a_dataset_smaller_than_one_optimizer_step():
                           export_root=None, rank=0, world=2)
     LoraRankerTrainer(args, engine=None, train_samples=list(range(16)), val_items=[], verbalizer=None,
                       export_root=None, rank=0, world=2)       # exactly one step: fine
+
+
+def _undefined_names(path):
+    """Names a function loads that neither it, an enclosing function, the module's top level nor builtins bind (a poor
+    man's pyflakes: the entry-point scripts import inside functions, and a branch that only runs on the GPU box must not
+    hide a NameError)."""
+    import ast
+    import builtins
+
+    tree = ast.parse(open(path).read())
+    scopes = (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda, ast.ClassDef)
+
+    def own_nodes(scope):
+        """nodes of this scope's body, not descending into nested functions / classes (which are yielded themselves)"""
+        stack = list(ast.iter_child_nodes(scope))
+        while stack:
+            n = stack.pop()
+            yield n
+            if not isinstance(n, scopes):
+                stack.extend(ast.iter_child_nodes(n))
+
+    def bound(scope):
+        names = set()
+        if isinstance(scope, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+            a = scope.args
+            names.update(x.arg for x in a.posonlyargs + a.args + a.kwonlyargs)
+            names.update(x.arg for x in (a.vararg, a.kwarg) if x)
+        for n in own_nodes(scope):
+            if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                names.add(n.name)
+            elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                names.update((x.asname or x.name).split(".")[0] for x in n.names)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                names.add(n.id)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                names.add(n.name)
+            elif isinstance(n, (ast.Global, ast.Nonlocal)):
+                names.update(n.names)
+        return names
+
+    missing = []
+
+    def visit(scope, visible, label):
+        local = visible | bound(scope)
+        for n in own_nodes(scope):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in local:
+                missing.append((label, n.id, n.lineno))
+            elif isinstance(n, scopes):
+                # a class body does not lend its names to nested functions; functions and lambdas do
+                visit(n, visible if isinstance(scope, ast.ClassDef) else local, getattr(n, "name", "<lambda>"))
+
+    visit(tree, set(dir(builtins)) | {"__file__", "__name__", "__doc__"}, "<module>")
+    return missing
+
+
+def _python_sources():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = ["bench.py", "__graft_entry__.py", "train_ranker.py", "train_retriever.py"]
+    files += sorted(os.path.join("llamarec_amd", f) for f in os.listdir(os.path.join(root, "llamarec_amd")) if f.endswith(".py"))
+    files += sorted(os.path.join("tools", f) for f in os.listdir(os.path.join(root, "tools")) if f.endswith(".py"))
+    return root, files
+
+
+@pytest.mark.parametrize("script", _python_sources()[1])
+def test_sources_have_no_undefined_names(script):
+    assert _undefined_names(os.path.join(_python_sources()[0], script)) == []
