@@ -49,11 +49,14 @@ struct RopeArgs {
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
 // pre_rs / pre_pos / pre_cs: the row's folded-norm scale, token position, (cos, sin) pairs when the caller fetched them
 // ahead (gemm256rb_kernel batches all reads of its epilogue in front of the stores); nullptr: fetched here. r: the residual's 4 values (RESIDUAL only).
-template <int EPI>
+// FOLD: -1 = scale by the folded-norm rstd when rope.row_scale is set (run-time check), 0 = never, 1 = always (the
+// 256-tile kernel is instantiated per case: as a run-time select the scaling cost a multiply and a v_cndmask per value
+// on the un-folded default path too).
+template <int EPI, int FOLD = -1>
 __device__ __forceinline__ u16x4 epi_value4(floatx4 v, floatx4 up, u16x4 r, const RopeArgs& rope, int row, int col,
                                             const float* pre_rs, const int* pre_pos, const float4* pre_cs = nullptr) {
   u16x4 o;
-  if ((EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale) {
+  if ((EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && (FOLD == 1 || (FOLD == -1 && rope.row_scale))) {
     const float rs = pre_rs ? *pre_rs : rope.row_scale[row];
     v *= rs;
     up *= rs;
@@ -249,7 +252,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // Split-K (EPI == LR_EPI_PARTIAL): blockIdx.y = split s works on K tiles [s*T/S, (s+1)*T/S) and stores its
 // fp32 partial plane at ((float*)C)[s][M][N]; splitk_reduce_kernel sums the planes in order and applies the
 // real epilogue.
-template <int EPI>
+template <int EPI, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ A,
                                                         const u16* __restrict__ B, u16* C,
                                                         const u16* R, int M, int N, int K, int group_m,
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   float rspre[8];  // folded RMSNorm: the scale of my 8 rows (1 when the norm is not folded)
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) rspre[mt] = 1.0f;
-  const bool has_rs = (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) && rope.row_scale != nullptr;
+  constexpr bool has_rs = FOLD && (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU);
   if (has_rs) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) rspre[mt] = rope.row_scale[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
@@ -486,8 +489,8 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
       const int cbase = (n0 + wn * 64) >> 1;   // 32 output columns: tiles t = 0, 1 of 16
       unsigned a[2], b[2];
       {
-        const u16x4 oa = epi_value4<EPI>(acc[mt][0], acc[mt][1], u16x4{0, 0, 0, 0}, rope, rowc, cbase + quad * 4, prs, ppos);
-        const u16x4 ob = epi_value4<EPI>(acc[mt][2], acc[mt][3], u16x4{0, 0, 0, 0}, rope, rowc, cbase + 16 + quad * 4, prs, ppos);
+        const u16x4 oa = epi_value4<EPI, has_rs ? 1 : 0>(acc[mt][0], acc[mt][1], u16x4{0, 0, 0, 0}, rope, rowc, cbase + quad * 4, prs, ppos);
+        const u16x4 ob = epi_value4<EPI, has_rs ? 1 : 0>(acc[mt][2], acc[mt][3], u16x4{0, 0, 0, 0}, rope, rowc, cbase + 16 + quad * 4, prs, ppos);
         a[0] = (unsigned)oa[0] | ((unsigned)oa[1] << 16); a[1] = (unsigned)oa[2] | ((unsigned)oa[3] << 16);
         b[0] = (unsigned)ob[0] | ((unsigned)ob[1] << 16); b[1] = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
       }
@@ -517,9 +520,9 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
           ra = u16x4{(u16)(x[0] & 0xffff), (u16)(x[0] >> 16), (u16)(x[1] & 0xffff), (u16)(x[1] >> 16)};
           rb = u16x4{(u16)(y[0] & 0xffff), (u16)(y[0] >> 16), (u16)(y[1] & 0xffff), (u16)(y[1] >> 16)};
         }
-        const u16x4 oa = epi_value4<EPI>(acc[mt][2 * k], acc[mt][2 * k], ra, rope, rowc, cpair + quad * 4, prs, ppos,
+        const u16x4 oa = epi_value4<EPI, has_rs ? 1 : 0>(acc[mt][2 * k], acc[mt][2 * k], ra, rope, rowc, cpair + quad * 4, prs, ppos,
                                          EPI == LR_EPI_ROPE ? &tpre[mt & 3][2 * k] : nullptr);
-        const u16x4 ob = epi_value4<EPI>(acc[mt][2 * k + 1], acc[mt][2 * k + 1], rb, rope, rowc, cpair + 16 + quad * 4, prs, ppos,
+        const u16x4 ob = epi_value4<EPI, has_rs ? 1 : 0>(acc[mt][2 * k + 1], acc[mt][2 * k + 1], rb, rope, rowc, cpair + 16 + quad * 4, prs, ppos,
                                          EPI == LR_EPI_ROPE ? &tpre[mt & 3][2 * k + 1] : nullptr);
         unsigned a[2] = {(unsigned)oa[0] | ((unsigned)oa[1] << 16), (unsigned)oa[2] | ((unsigned)oa[3] << 16)};
         unsigned b[2] = {(unsigned)ob[0] | ((unsigned)ob[1] << 16), (unsigned)ob[2] | ((unsigned)ob[3] << 16)};
@@ -593,10 +596,10 @@ static int gemm256_group_m(int K) {
   return g ? g : (K >= 8192 ? 4 : G2_GROUP_M);
 }
 
-template <int EPI>
+template <int EPI, bool FOLD = false>
 static int gemm256_prepare() {
   static bool done[LR_MAX_DEVICES] = {};
-  return lr_ensure_dynamic_lds(reinterpret_cast<const void*>(gemm256rb_kernel<EPI>), 2 * G2_STAGE_BYTES, done);
+  return lr_ensure_dynamic_lds(reinterpret_cast<const void*>(gemm256rb_kernel<EPI, FOLD>), 2 * G2_STAGE_BYTES, done);
 }
 
 template <int EPI>
@@ -621,10 +624,21 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
                       RopeArgs rope, hipStream_t st) {
   LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
   if (variant == 4) {
-    if (int rc = gemm256_prepare<EPI>()) return rc;
     const int nwg = ((M + 255) / 256) * (N / 256);
-    hipLaunchKernelGGL(gemm256rb_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
-                       gemm256_group_m(K), rope);
+    bool launched = false;
+    if constexpr (EPI == LR_EPI_ROPE || EPI == LR_EPI_SWIGLU) {
+      if (rope.row_scale) {  // folded RMSNorm: the instantiation that scales its accumulator rows
+        if (int rc = gemm256_prepare<EPI, true>()) return rc;
+        hipLaunchKernelGGL((gemm256rb_kernel<EPI, true>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
+                           gemm256_group_m(K), rope);
+        launched = true;
+      }
+    }
+    if (!launched) {
+      if (int rc = gemm256_prepare<EPI>()) return rc;
+      hipLaunchKernelGGL(gemm256rb_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
+                         gemm256_group_m(K), rope);
+    }
     LR_CHECK_LAUNCH("gemm256rb_kernel");
   } else {
     dim3 grid((N + GG_BN - 1) / GG_BN, (M + GG_BM - 1) / GG_BM);
