@@ -88,10 +88,10 @@ extern "C" int lr_llama_set_folded_norms(lr_llama_t* h, const uint16_t* const* w
 }
 
 struct LlamaWs {
-  int32_t *tok_pos, *tok_src, *last_rows, *seg_start;
+  int32_t *tok_pos, *tok_src, *last_rows, *last_pos, *seg_start;
   float *rope, *rstd;
   u16 *x, *xn, *qkv, *att, *hmid;
-  u16 *x_last, *xn_last, *att_last, *h_last;  // compact [B][.] buffers of the pruned last layer
+  u16 *x_last, *xn_last, *att_last, *h_last, *q_last;  // compact [B][.] buffers of the pruned last layer
   float* splitk;                              // fp32 partial planes of the split-K GEMMs (gemm variant 5)
   bool compact;                               // ws.x_last (not ws.x) holds the final residual rows
   size_t total;
@@ -119,11 +119,13 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.hmid = (u16*)take(n * c.intermediate_size * 2);
   const size_t nb = (size_t)(max_seqs > 0 ? max_seqs : 1);
   w.last_rows = (int32_t*)take(nb * 4);
+  w.last_pos = (int32_t*)take(nb * 4);
   w.seg_start = (int32_t*)take((nb + 2) * 4);
   w.x_last = (u16*)take(nb * c.hidden_size * 2);
   w.xn_last = (u16*)take(nb * c.hidden_size * 2);
   w.att_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
   w.h_last = (u16*)take(nb * c.intermediate_size * 2);
+  w.q_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
   w.splitk = (float*)take(LR_SPLITK_WS_BYTES);
   w.total = o;
   return w;
@@ -186,7 +188,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     rc = (x);               \
     if (rc) return rc;      \
   } while (0)
-  RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st));
+  RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st, ws.last_pos));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
@@ -194,8 +196,23 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     // RMSNorm: either its own pass (read + write every row), or -- folded -- only the row statistic, with the norm
     // weight already inside the projection matrix and rstd applied to the accumulator rows in the GEMM epilogue
     const bool folded = h->wqkv_folded != nullptr;
-    // QKV projection with the rotary embedding applied in the epilogue (q/k rows pair-interleaved)
-    if (folded) {
+    const bool last_pruned = l == c.num_layers - 1 && h->prune_last;
+    // Pruned last layer, head_dim 128: only each prompt's last token is consumed after it (model/llm.py:131), so Q is
+    // needed for B rows only -- K and V for all of them. The projection runs on the K | V rows of wqkv (2/3 of the
+    // product) for every row and on its Q rows for the B last rows; the attention kernel then evaluates ONE query row
+    // per (prompt, head) over the prompt's keys instead of every tile.
+    const bool last_q_only = last_pruned && !folded && hd == 128 && h->attn_variant != 1 && h->gemm_variant != 1;
+    if (last_q_only) {
+      const int q_w = nh * hd, kv_w = 2 * nkv * hd;
+      const int pv = (h->gemm_variant == 5 || (h->gemm_variant == 0 && B <= 256)) ? 5 : 1;
+      RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+      RUN(lr_launch_gemm(ws.xn, w.wqkv + (size_t)q_w * d, ws.qkv, nullptr, n, kv_w, d, LR_EPI_ROPE, h->gemm_variant, st,
+                         ws.tok_pos, ws.rope, hd, nkv * hd, ws.splitk, LR_SPLITK_WS_BYTES));
+      RUN(lr_launch_gather_rows(ws.xn, ws.last_rows, B, d, ws.xn_last, st));
+      RUN(lr_launch_gemm(ws.xn_last, w.wqkv, ws.q_last, nullptr, B, q_w, d, LR_EPI_ROPE, pv, st, ws.last_pos, ws.rope, hd,
+                         q_w, ws.splitk, LR_SPLITK_WS_BYTES));
+      RUN(lr_launch_attention_last(ws.qkv, ws.q_last, ws.att_last, ws.seg_start, seg_host, S, n, nh, nkv, hd, st, P));
+    } else if (folded) {
       RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
       RUN(lr_launch_gemm(ws.x, h->wqkv_folded[l], ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
                          ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd));
@@ -204,10 +221,12 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
                          ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES));
     }
-    if (l == c.num_layers - 1 && h->prune_last) {
+    if (last_pruned) {
       // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
       // last layer needs K/V for every token but attention output, o_proj, and the MLP for B rows only.
-      if (hd == 128 && h->attn_variant != 1) {
+      if (last_q_only) {
+        // ws.att_last already holds the attention rows of the last tokens
+      } else if (hd == 128 && h->attn_variant != 1) {
         // the MFMA kernel over ALL rows (188 us for 14.8 k tokens, 16 us for one prompt) beats the scalar kernel over the
         // B last rows (459 / 295 us): attend everything, keep the last rows
         RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,

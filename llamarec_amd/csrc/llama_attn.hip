@@ -169,10 +169,16 @@ __device__ unsigned long long g_attn_stamps[64 * 8];
     t_prev = t_;                                                               \
   }
 
-template <bool STAMP>
+// LASTQ (the pruned last layer, api_llama.hip): only each prompt's LAST query row is evaluated. `qkv` is then the
+// [rows][2 * nkv * hd] K | V projection of every row, `q_last` holds one rotated query row per prompt ([prompt][nh * hd]),
+// a workgroup = one (prompt, head) walks all the prompt's key blocks with wave 0 computing (every lane of the wave holds
+// the same query row, so the tile arithmetic -- and with it the bits of that row -- is that of the full kernel) and all
+// four waves staging, and `out` receives one row per prompt ([prompt][nh * hd]).
+template <bool STAMP, bool LASTQ = false>
 __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
                                                               const int32_t* cu, int prefix_len, int nh, int nkv,
-                                                              int max_qblocks, int n_pairs, float* lse) {
+                                                              int max_qblocks, int n_pairs, float* lse,
+                                                              const u16* __restrict__ q_rows_last = nullptr) {
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   // [2 stages][K 16 KiB | V 16 KiB]; filled by LDS-DMA (lane-linear 1 KiB pieces = 4 rows x 256 B),
@@ -185,7 +191,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   // after pair, and the two lightest tiles of every pair are kept for the end, where they fill the tail of the launch
   // (a causal tile costs ~ its key-block count 2 qb + 2: launched last, a heavy tile would leave most CUs idle).
   int seg, h, qb;
-  {
+  if (LASTQ) {
+    const int id = blockIdx.x, stream = id & 7, pl = id >> 3;
+    const int pair = pl * 8 + stream;
+    if (pair >= n_pairs) return;
+    seg = __builtin_amdgcn_readfirstlane(pair / nh);
+    h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
+    if (prefix_len > 0 && seg == 0) return;   // segment 0 is the shared prefix, not a prompt
+    qb = 0;                                    // set below, once T is known
+  } else {
     const int id = blockIdx.x, stream = id & 7, j = id >> 3;
     const int ppx = (n_pairs + 7) >> 3;                  // pairs per stream
     const int n_light = min(max_qblocks, 2), n_heavy = max_qblocks - n_light;
@@ -209,26 +223,30 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   const int tok0 = cu[seg];
   const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;  // keys [0, P) live in segment 0's rows [0, P)
   const int T = P + cu[seg + 1] - tok0;                        // sequence length, prefix included
+  if (LASTQ) qb = (T - 1) / FA_QROWS;
   if (qb * FA_QROWS >= T || (qb + 1) * FA_QROWS <= P) return;  // no query row of this segment in the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int quad = lane >> 4, li = lane & 15;
   const int kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
-  const int stride = (nh + 2 * nkv) * hd;
+  const int stride = LASTQ ? 2 * nkv * hd : (nh + 2 * nkv) * hd;
+  const int koff0 = LASTQ ? kvh * hd : (nh + kvh) * hd, voff0 = koff0 + nkv * hd;
   const int vtok0 = tok0 - P;  // the row of position p >= P is vtok0 + p (tok0 >= P: segment 0 precedes it)
-  const u16* kbase = qkv + (size_t)vtok0 * stride + (nh + kvh) * hd;
-  const u16* vbase = qkv + (size_t)vtok0 * stride + (nh + nkv + kvh) * hd;
-  const u16* pkbase = qkv + (nh + kvh) * hd;        // prefix rows start at packed row 0
-  const u16* pvbase = qkv + (nh + nkv + kvh) * hd;
+  const u16* kbase = qkv + (size_t)vtok0 * stride + koff0;
+  const u16* vbase = qkv + (size_t)vtok0 * stride + voff0;
+  const u16* pkbase = qkv + koff0;        // prefix rows start at packed row 0
+  const u16* pvbase = qkv + voff0;
+  const int prompt = prefix_len > 0 ? seg - 1 : seg;   // LASTQ: row of q_last / out
 
   // ---- Q fragments (B operand of S^T = K Q^T): row q, d = 32*ks + 8*quad + 0..7
   bf16x8 qf[2][4];
   int qabs[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    qabs[qt] = qb * FA_QROWS + wave * 32 + qt * 16 + li;
+    qabs[qt] = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + qt * 16 + li;
     const int qr = min(max(qabs[qt], P), T - 1);
-    const u16* qp = qkv + (size_t)(vtok0 + qr) * stride + h * hd + quad * 8;
+    const u16* qp = LASTQ ? q_rows_last + (size_t)prompt * nh * hd + h * hd + quad * 8
+                          : qkv + (size_t)(vtok0 + qr) * stride + h * hd + quad * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
   }
@@ -241,9 +259,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
   float l_run[2] = {0.f, 0.f};
 
-  const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);
+  const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);   // (LASTQ: qb is the tile of row T - 1, so this is T - 1)
   const int kb_last = q_last / FA_KB;
-  const int wave_q_last = qb * FA_QROWS + wave * 32 + 31;  // last query row this wave owns
+  const int wave_q_last = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + 31;  // last query row this wave owns
   const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
 
   // ---- DMA staging: 16 pieces per tile (4 rows each); wave w moves pieces 4w..4w+3 of K and of V
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     if (kb < kb_last) stage(kb + 1, (kb + 1) & 1);
     FA_STAMP(1)  // DMA issue
 
-    if (kb * FA_KB <= wave_q_last && wave_q_last >= P) {  // otherwise every key of the block is masked for this wave
+    if (kb * FA_KB <= wave_q_last && wave_q_last >= P && (!LASTQ || wave == 0)) {  // otherwise every key of the block is masked for this wave
                                                           // (or all its rows belong to the prefix segment)
       // ---- S^T = K Q^T : st[qt][nt] rows = keys nt*16 + 4*quad + r, col = query li
       floatx4 st[2][4];
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       FA_STAMP(2)  // S^T = K Q^T
       // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
       bf16x8 pa[2][2];
-      const bool diag = (kb * FA_KB + FA_KB - 1) > (qb * FA_QROWS + wave * 32);  // block needs masking
+      const bool diag = (kb * FA_KB + FA_KB - 1) > (LASTQ ? T - 1 : qb * FA_QROWS + wave * 32);  // block needs masking
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         // raw-score row maximum (the scale is positive, so max commutes with it)
@@ -426,14 +444,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   for (int qt = 0; qt < 2; ++qt) {
     const float l = fa_sum_xor16_32(l_run[qt]);
     const float inv = 1.0f / l;
-    if (qabs[qt] < T && qabs[qt] >= P && lse && quad == 0)  // natural-log log-sum-exp of the scaled scores (backward pass)
+    if (!LASTQ && qabs[qt] < T && qabs[qt] >= P && lse && quad == 0)  // natural-log log-sum-exp of the scaled scores (backward pass)
       lse[(size_t)(vtok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
     // A lane holds d = 16 dt + 4 quad + r of its row: 8 bytes per tile. v_permlane16_swap (vdst rows 1 / 3 <-> src rows
     // 0 / 2 of 16 lanes) on the packed tiles (2k, 2k+1) leaves even quads with d = 8 (quad/2) .. +7 of tile 2k and odd
     // quads with the same of tile 2k + 1: 4 x 16-byte stores per row instead of 8 x 8 bytes (the tail is store-ISSUE
     // bound). Every lane takes part in the swaps; only rows of this segment store.
-    const bool live = qabs[qt] < T && qabs[qt] >= P;
-    u16* op = out + (size_t)(vtok0 + (live ? qabs[qt] : P)) * nh * hd + h * hd + (quad & 1) * 16 + (quad >> 1) * 8;
+    const bool live = LASTQ ? (wave == 0 && qt == 0 && li == 0) : (qabs[qt] < T && qabs[qt] >= P);
+    u16* op = out + (size_t)(LASTQ ? prompt : vtok0 + (live ? qabs[qt] : P)) * nh * hd + h * hd + (quad & 1) * 16 + (quad >> 1) * 8;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       unsigned a[2], b[2];
@@ -542,6 +560,33 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
   } else {
     LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA)", variant);
   }
+  return LR_OK;
+}
+
+// The pruned last layer: kv = [n_tok][2 * nkv * hd] (K | V of every row), q_last = [prompts][nh * hd] rotated query rows
+// of each prompt's last token, out_last = [prompts][nh * hd]. cu / cu_host / prefix_len as lr_launch_attention.
+int lr_launch_attention_last(const u16* kv, const u16* q_last, u16* out_last, const int32_t* cu, const int32_t* cu_host,
+                             int S, int n_tok, int nh, int nkv, int hd, hipStream_t st, int prefix_len) {
+  if (n_tok <= 0 || S <= 0) return LR_OK;
+  if (hd != 128 || nh % nkv != 0) LR_FAIL(LR_EUNSUPPORTED, "attention (last rows): head_dim 128 and nh %% nkv == 0 only");
+  if (prefix_len < 0 || (prefix_len > 0 && cu_host[1] - cu_host[0] != prefix_len))
+    LR_FAIL(LR_EINVAL, "attention (last rows): segment 0 must be the %d-token shared prefix", prefix_len);
+  double work = 0;
+  for (int b = (prefix_len > 0 ? 1 : 0); b < S; ++b) {
+    const double T = (prefix_len > 0 ? prefix_len : 0) + cu_host[b + 1] - cu_host[b];
+    work += 4.0 * nh * hd * T;
+  }
+  LrProfScope prof(LR_PROF_ATTN_MFMA, work, st);
+  const long long n_pairs_ll = (long long)S * nh, grid_ll = 8 * ((n_pairs_ll + 7) / 8);
+  if (grid_ll > 0x7fffffffLL) LR_FAIL(LR_EUNSUPPORTED, "attention: %lld workgroups exceed the grid limit", grid_ll);
+  if ((long long)n_tok * 2 * nkv * hd * 2 > 0x7fffffffLL * 2)
+    LR_FAIL(LR_EUNSUPPORTED, "attention: packed kv of %d tokens exceeds the 4 GiB a buffer descriptor addresses", n_tok);
+  static bool lds_set[LR_MAX_DEVICES] = {};
+  if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<false, true>), 2 * FA_STAGE_BYTES, lds_set))
+    return rc;
+  hipLaunchKernelGGL((attn_mfma128_kernel<false, true>), dim3((unsigned)grid_ll), dim3(256), 2 * FA_STAGE_BYTES, st, kv, out_last,
+                     cu, prefix_len, nh, nkv, 0, (int)n_pairs_ll, (float*)nullptr, q_last);
+  LR_CHECK_LAUNCH("attn_mfma128_kernel<last>");
   return LR_OK;
 }
 

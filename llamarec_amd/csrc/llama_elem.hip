@@ -32,7 +32,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // tok_pos = position inside the prompt (rotary embedding), tok_src = index into the caller's packed ids,
 // last_rows[b] = internal row of prompt b's last token, seg_start[0..S] = segment starts.
 __global__ void token_meta_kernel(const int32_t* cu, int B, int P, int32_t* seg_start, int32_t* tok_pos,
-                                  int32_t* tok_src, int32_t* last_rows) {
+                                  int32_t* tok_src, int32_t* last_rows, int32_t* last_pos) {
   const int seg = blockIdx.x;
   int start, len, pos0, src0;
   if (P > 0 && seg == 0) {
@@ -46,6 +46,7 @@ __global__ void token_meta_kernel(const int32_t* cu, int B, int P, int32_t* seg_
     src0 = s + P;
     if (threadIdx.x == 0) {
       if (last_rows) last_rows[b] = start + len - 1;
+      if (last_pos) last_pos[b] = pos0 + len - 1;   // position of the prompt's last token (rotary embedding of its query)
       if (seg_start && seg == (int)gridDim.x - 1) seg_start[seg + 1] = start + len;
     }
   }
@@ -258,10 +259,10 @@ int lr_launch_gather_rows(const u16* x, const int32_t* rows, int n_rows, int d, 
 
 // ---------------------------------------------------------------------------------------------
 int lr_launch_token_meta(const int32_t* cu, int B, int prefix_len, int32_t* seg_start, int32_t* tok_pos,
-                         int32_t* tok_src, int32_t* last_rows, hipStream_t st) {
+                         int32_t* tok_src, int32_t* last_rows, hipStream_t st, int32_t* last_pos) {
   const int S = prefix_len > 0 ? B + 1 : B;
   hipLaunchKernelGGL(token_meta_kernel, dim3(S), dim3(256), 0, st, cu, B, prefix_len, seg_start, tok_pos, tok_src,
-                     last_rows);
+                     last_rows, last_pos);
   LR_CHECK_LAUNCH("token_meta_kernel");
   return LR_OK;
 }

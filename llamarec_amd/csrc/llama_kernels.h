@@ -30,9 +30,10 @@ __device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
 
 // packed-layout metadata (llama_elem.hip): prefix_len = P > 0 lays the batch out as [P shared prefix rows][rest of
 // prompt 0]...[rest of prompt B-1]; seg_start (optional) receives the B + 1 (P = 0: B) + 1 segment starts, tok_src
-// (optional) the index of every internal row in the caller's packed ids, last_rows (optional) each prompt's last row
+// (optional) the index of every internal row in the caller's packed ids, last_rows (optional) each prompt's last row,
+// last_pos (optional) the position of that token inside its prompt
 int lr_launch_token_meta(const int32_t* cu, int B, int prefix_len, int32_t* seg_start, int32_t* tok_pos,
-                         int32_t* tok_src, int32_t* last_rows, hipStream_t st);
+                         int32_t* tok_src, int32_t* last_rows, hipStream_t st, int32_t* last_pos = nullptr);
 int lr_launch_gather_rows(const unsigned short* x, const int32_t* rows, int n_rows, int d, unsigned short* out,
                           hipStream_t st);
 int lr_launch_attention_rows(const unsigned short* qkv, unsigned short* out, const int32_t* cu, int B,
@@ -62,6 +63,9 @@ int lr_launch_fold_norm(const unsigned short* w, const unsigned short* norm_w, u
 
 // varlen causal attention over packed qkv (RoPE applied). variant: 0 auto, 1 generic, 2 MFMA hd=128.
 // cu / cu_host = segment starts; prefix_len > 0: segment 0 is the prefix the other segments continue (MFMA kernel only)
+int lr_launch_attention_last(const unsigned short* kv, const unsigned short* q_last, unsigned short* out_last,
+                             const int32_t* cu, const int32_t* cu_host, int S, int n_tok, int nh, int nkv, int hd,
+                             hipStream_t st, int prefix_len);
 int lr_launch_attention(const unsigned short* qkv, unsigned short* out, const int32_t* cu,
                         const int32_t* cu_host, const int32_t* tok_pos, const int32_t* tok_seq, int B,
                         int n_tok, int nh, int nkv, int hd, int variant, void* scratch, hipStream_t st,
