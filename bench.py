@@ -124,12 +124,18 @@ def ndcg_at_10(ranked, labels):
 
 
 def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retriever, dev):
-    """Oracle ("port") timed on the host: stage 1 over the resident users; stage 2 on 4 users x 2 of the 32
-    Llama-2-7b layers, extrapolated x16 (a full 7B prefill is ~10 TFLOP per Beauty user). The same oracle outputs
-    are then compared with the HIP path on the same inputs (never inside the timed region)."""
+    """Oracle ("port") timed on the host: stage 1 over the resident users; stage 2 on 4 users x 4 of the 32
+    Llama-2-7b layers, extrapolated x8 (a full 7B prefill is ~10 TFLOP per Beauty user); BASELINE.json configs[0]
+    (ML-100k shape, retriever only, CPU) is timed beside it. The same oracle outputs are then compared with the HIP path
+    on the same inputs (never inside the timed region): `labels` are the planted ones (plant_labels), so the metric
+    dicts both sides derive -- the oracle's float64 rank metrics of its own top-50 against the GPU's int64 histogram
+    -> lr_metrics_from_histogram path -- are non-zero and must be equal."""
     import torch
 
+    from llamarec_amd import metrics as M
     from llamarec_amd.llm import LlamaRanker
+    from llamarec_amd.lru import init_lru_state_dict
+    from llamarec_amd.synth import WORKLOADS, synth_users
     from oracle import llama_oracle as LO
     from oracle import lru_oracle as O
 
@@ -149,7 +155,16 @@ def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retrie
     t1 = time.perf_counter() - t0
     s1_per_user = t1 / len(hist_ids)
 
-    cfg, sd, seqs, label_ids = stage2_sample(T_sample)
+    # configs[0]: ML-100k LRURec retriever-only top-20 eval on CPU (every user of the shape: 610 x 200 positions)
+    w1 = WORKLOADS["ml-100k"]
+    h1 = synth_users("ml-100k", w1["U"])[0]
+    orc1 = O.LruOracle(init_lru_state_dict(w1["V"], seed=42))
+    t0 = time.perf_counter()
+    orc1.retrieve_topk(h1, 20, True)
+    t_c1 = time.perf_counter() - t0
+
+    S2_LAYERS = 4
+    cfg, sd, seqs, label_ids = stage2_sample(T_sample, layers=S2_LAYERS)
     t0 = time.perf_counter()
     o_scores = LO.prefill_verbalize(sd, cfg, seqs, label_ids, mode="bf16")
     t2 = time.perf_counter() - t0
@@ -164,13 +179,30 @@ def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retrie
                    f"{cfg['num_hidden_layers']} of 32 Llama-2-7b layers at full width = {t2:.2f} s, extrapolated x"
                    f"{32 // cfg['num_hidden_layers']}"),
         "stage1_users_per_s": 1.0 / s1_per_user, "stage2_users_per_s_extrapolated": 1.0 / s2_per_user,
+        "config1_ml100k_retriever_only": {
+            "users_per_s": len(h1) / t_c1, "users": int(len(h1)), "seconds": t_c1, "threads": omp_threads,
+            "what": (f"BASELINE.json configs[0]: LRURec(V={w1['V']}, L={w1['L']}) encode + item scores + history mask + ordered "
+                     f"top-20 for all {len(h1)} synthetic ML-100k users, C oracle on this host"),
+            "reference_code_users_per_s_build_container": REFERENCE_CODE_STAGE1_USERS_PER_S["ml-100k"]},
         "reference_code_stage1_users_per_s": REFERENCE_CODE_STAGE1_USERS_PER_S.get(workload),
         "reference_code_note": "the reference's own torch CPU path (stage 1 only), 8 cores, measured in the build "
                                "container (SURVEY.md section 6); not measured on this host",
     }
 
-    g_top, _ = retriever.retrieve_topk(torch.from_numpy(hist_ids).to(dev), 50, True)
+    hist_dev = torch.from_numpy(hist_ids).to(dev)
+    g_top, _ = retriever.retrieve_topk(hist_dev, 50, True)
+    # the GPU's metric path on the planted labels: rank histogram kernel -> float64 metrics of the histogram
+    ks = [1, 5, 10, 20, 50]
+    g_metrics = M.metrics_from_histogram(M.rank_histogram(g_top, torch.from_numpy(labels).to(dev)), ks)
     g_top = g_top.cpu().numpy()
+    # the oracle's: its own top-50 lists, the reference's formulas in float64 (oracle/lr_oracle.c rank metric sums)
+    o_sums = O.rank_metric_sums(o_top, labels, sorted(ks, reverse=True))
+    o_metrics = {}
+    for j, k in enumerate(sorted(ks, reverse=True)):
+        for c, name in enumerate(("Recall", "MRR", "NDCG")):
+            o_metrics[f"{name}@{k}"] = float(o_sums[j, c] / len(labels))
+    metrics_equal = all(abs(g_metrics[k] - o_metrics[k]) <= 1e-12 for k in o_metrics)
+
     small = LlamaRanker.from_state_dict(sd, cfg, device=dev)
     g_scores = small.prefill_verbalize(seqs, label_ids).cpu().numpy()
     del small
@@ -184,42 +216,97 @@ def cpu_baseline_and_parity(workload, hist_ids, labels, T_sample, lru_sd, retrie
     d_g = g_scores[:, :, None] - g_scores[:, None, :]
     decided = np.abs(d_o) > 2 * tol
     agree = float((np.sign(d_o[decided]) == np.sign(d_g[decided])).mean()) if decided.any() else 1.0
-    lab2 = np.arange(len(seqs)) % 20  # stand-in answer letters for an NDCG@10 of the two rankings
+    # planted answer letters for the two rankings' NDCG@10: prompt i's answer = the candidate the ORACLE ranks at 3 i
+    o_rank = np.argsort(-o_scores, axis=1, kind="stable")
+    g_rank = np.argsort(-g_scores, axis=1, kind="stable")
+    lab2 = np.array([o_rank[i, (3 * i) % 20] for i in range(len(seqs))])
     parity = {
         "stage1_users": int(len(hist_ids)), "stage1_top50_equal": bool(np.array_equal(g_top, o_top)),
-        "stage1_ndcg10_gpu": ndcg_at_10(g_top, labels), "stage1_ndcg10_oracle": ndcg_at_10(o_top, labels),
+        "stage1_labels": f"planted: user j's label = the retriever's rank-(j mod {PLANT_PERIOD}) item (none for ranks >= 50)",
+        "stage1_ndcg10_gpu": g_metrics["NDCG@10"], "stage1_ndcg10_oracle": o_metrics["NDCG@10"],
+        "stage1_metrics_gpu": g_metrics, "stage1_metrics_oracle": o_metrics, "stage1_metrics_equal": bool(metrics_equal),
         "stage2_prompts": len(seqs), "stage2_layers": cfg["num_hidden_layers"], "stage2_width": cfg["hidden_size"],
         "stage2_max_abs_err": err, "stage2_tolerance": tol, "stage2_oracle_bf16_vs_fp32_max_abs": gap,
         "stage2_max_abs_err_vs_fp32_oracle": float(np.abs(g_scores - o_exact).max()), "stage2_rank_agree": agree,
         "stage2_pairs_decided": int(decided.sum() // 2),
-        "stage2_ndcg10_gpu": ndcg_at_10(np.argsort(-g_scores, axis=1, kind="stable"), lab2),
-        "stage2_ndcg10_oracle": ndcg_at_10(np.argsort(-o_scores, axis=1, kind="stable"), lab2),
+        "stage2_ndcg10_gpu": ndcg_at_10(g_rank, lab2), "stage2_ndcg10_oracle": ndcg_at_10(o_rank, lab2),
     }
-    parity["ok"] = bool(parity["stage1_top50_equal"] and err <= tol and agree == 1.0)
+    parity["ok"] = bool(parity["stage1_top50_equal"] and metrics_equal and g_metrics["NDCG@10"] > 0 and err <= tol
+                        and agree == 1.0)
     return base, parity
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 PMC summary
-    (profiles/r*_pmc_summary.json, made by tools/summarize_pmc.py from separate --pmc passes of this command on a
-    2-layer slice: FETCH_SIZE x 2 + WRITE_SIZE). (None, None) if no summary is present."""
+EPI_NAMES = {0: "store", 1: "residual", 2: "swiglu", 3: "rope", 4: "partial"}
+
+
+def gemm_shapes(lib, d_model=4096, d_ff=11008):
+    """Per-launch records of the 256x256x64 GEMM over the timed region (lr_profile_records), grouped by
+    (epilogue, N, K): launches, mean duration, executed TFLOP/s -- the four projection shapes of a Llama-2-7b layer by
+    name, everything else (the pruned last layer's products) by its tag."""
+    n = lib.lr_profile_records(0, None, None, None, 0)
+    if n <= 0:
+        return {}
+    ms, work, tag = np.zeros(n), np.zeros(n), np.zeros(n, np.int64)
+    lib.lr_profile_records(0, ms.ctypes.data, work.ctypes.data, tag.ctypes.data, n)
+    names = {(3, 3 * d_model, d_model): "qkv_rope", (1, d_model, d_model): "o_residual",
+             (2, 2 * d_ff, d_model): "gate_up_swiglu", (1, d_model, d_ff): "down_residual"}
+    out = {}
+    for t in np.unique(tag):
+        sel = tag == t
+        epi, N, K = int(t >> 56), int((t >> 28) & ((1 << 28) - 1)), int(t & ((1 << 28) - 1))
+        key = names.get((epi, N, K), f"{EPI_NAMES.get(epi, epi)}_N{N}_K{K}")
+        out[key] = {"epilogue": EPI_NAMES.get(epi, str(epi)), "N": N, "K": K, "launches": int(sel.sum()),
+                    "avg_ms": float(ms[sel].mean()), "tflops": float(work[sel].sum() / (ms[sel].sum() * 1e-3) / 1e12),
+                    "mean_rows": float((work[sel] / (2.0 * N * K)).mean())}
+    return out
+
+
+def pmc_traffic(shapes):
+    """HBM-side bytes per launch of the dominant kernel: per-epilogue bytes from the NEWEST committed rocprofv3 PMC
+    summary (profiles/r*_pmc_summary.json, tools/summarize_pmc.py over separate --pmc passes of this command on a 2-layer
+    slice: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), scaled to each shape's rows and weighted by
+    THIS run's launch mix (round 2 averaged over the slice's own mix, where 8 of 18 launches were the small last-layer
+    products: 2.9 GB where a Beauty step's mix averages 5.3). Per-shape bytes and their ratio to the algorithmic bytes
+    (A + B + C once) ride along. (None, None, None) if no summary is present."""
     def round_no(p):
         m = re.search(r"r(\d+)[a-z]?_pmc_summary\.json$", p)
         return int(m.group(1)) if m else -1
 
     paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")), key=round_no)
     paths = [p for p in paths if "stage1" not in os.path.basename(p)]
-    if not paths:
-        return None, None
+    if not paths or not shapes:
+        return None, None, None
     path = paths[-1]
     d = json.load(open(path))
-    num = den = 0.0
+    per_epi = {}
     for k, e in d.items():
-        if k.startswith("gemm256") and "hbm_bytes_per_launch" in e:
-            num += e["hbm_bytes_per_launch"] * e["launches_profiled"]
-            den += e["launches_profiled"]
-    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on a 2-layer slice; not collected by this run)"
-    return (num / den if den else None), src
+        m = re.match(r"gemm256rb_kernel<(\d+),", k)
+        if m and "hbm_bytes_per_launch" in e:
+            per_epi[EPI_NAMES.get(int(m.group(1)))] = e
+    # the profiled slice ran the same token-budget step: bytes per launch of an epilogue class scale with the flops
+    # of the shapes that share it (o / down share the residual class: split by flops)
+    rows = max(v["mean_rows"] for v in shapes.values())
+    full = {k: v for k, v in shapes.items() if v["mean_rows"] > 0.5 * rows}
+    by_epi_flops = {}
+    for k, v in full.items():
+        by_epi_flops.setdefault(v["epilogue"], []).append(v["N"] * v["K"])
+    num = den = 0.0
+    per_shape = {}
+    for k, v in full.items():
+        e = per_epi.get(v["epilogue"])
+        if e is None:
+            continue
+        mean_nk = float(np.mean(by_epi_flops[v["epilogue"]]))
+        b = e["hbm_bytes_per_launch"] * (v["N"] * v["K"]) / mean_nk
+        n_out = v["N"] // 2 if v["epilogue"] == "swiglu" else v["N"]
+        alg = 2.0 * (v["mean_rows"] * v["K"] + v["N"] * v["K"] + v["mean_rows"] * n_out
+                     + (v["mean_rows"] * n_out if v["epilogue"] == "residual" else 0))
+        per_shape[k] = {"hbm_side_bytes_per_launch": b, "algorithmic_bytes_per_launch": alg, "ratio": b / alg}
+        num += b * v["launches"]
+        den += v["launches"]
+    src = (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on "
+           f"a 2-layer slice; per-epilogue bytes weighted by this run's launch mix of the full-row products; not collected by this run)")
+    return (num / den if den else None), src, per_shape
 
 
 def build_steps(workload, rank, n_steps, budget, users_per_step, dev, shared_prefix):
@@ -253,6 +340,51 @@ def build_steps(workload, rank, n_steps, budget, users_per_step, dev, shared_pre
                           prefix=common_prefix_len(pids, cu) if shared_prefix else 0))
     used = np.concatenate(groups)
     return steps, hist[used], labels[used], T[used]
+
+
+PLANT_PERIOD = 60   # label of the j-th resident user = the retriever's rank-(j mod 60) item; ranks >= 50 keep a random label
+
+
+def plant_labels(steps, retriever, dev):
+    """Uniform random labels over 12 086 items and random weights put < 1 expected hit into a whole run, so the
+    histogram -> metric -> all-reduce path would only ever carry zeros (round 2's driver line). Outside the timed region
+    the label of resident user j becomes the item the retriever itself ranks at position j mod 60 (no hit for >= 50):
+    Recall/MRR/NDCG are then known functions of the planted ranks, printed beside what the GPU path measured. Synthetic
+    labels are arbitrary by construction; the timed work does not depend on them.
+    Returns (labels of all resident users in step order, their planted 0-based ranks with -1 = absent)."""
+    import torch
+
+    j0, all_labels, all_ranks = 0, [], []
+    for s in steps:
+        top, _ = retriever.retrieve_topk(s["hist"], 50, True)
+        top = top.cpu().numpy()
+        lab = s["labels"].cpu().numpy().copy()
+        r = (j0 + np.arange(len(lab))) % PLANT_PERIOD
+        hit = r < 50
+        lab[hit] = top[np.nonzero(hit)[0], r[hit]]
+        # a kept random label may sit in the top-50 by chance: the expectation is computed from where labels REALLY are
+        pos = np.full(len(lab), -1, np.int64)
+        where = np.nonzero(top == lab[:, None])
+        pos[where[0]] = where[1]
+        s["labels"] = torch.from_numpy(lab).to(dev)
+        all_labels.append(lab)
+        all_ranks.append(pos)
+        j0 += len(lab)
+    return np.concatenate(all_labels), np.concatenate(all_ranks)
+
+
+def metrics_of_ranks(pos, ks, denom=None):
+    """trainer/utils.py:43-90 for one relevant item per row, from its 0-based rank (-1 = not retrieved), in float64 on
+    the host: the independent expectation for the GPU's histogram path."""
+    pos = np.asarray(pos)
+    n = len(pos) if denom is None else denom
+    out = {}
+    for k in ks:
+        hit = (pos >= 0) & (pos < k)
+        out["Recall@%d" % k] = float(hit.sum() / n)
+        out["MRR@%d" % k] = float((1.0 / (pos[hit] + 1)).sum() / n)
+        out["NDCG@%d" % k] = float((1.0 / np.log2(pos[hit] + 2)).sum() / n)
+    return out
 
 
 def main():
@@ -305,6 +437,8 @@ def main():
         ranker.set_fold_norms(True)
     label_ids = list(range(319, 339))  # stand-in ids of "A".."T" (taken from the tokenizer at run time in real use)
     pipe = TwoStagePipeline(retriever, ranker, label_ids, device=dev, shared_prefix=shared)
+    planted_labels, planted_ranks = plant_labels(steps, retriever, dev)   # untimed; labels of hist[...] in step order
+    labels = planted_labels
 
     def run(s):
         return pipe.step(s["hist"], s["labels"], s["ids"], s["cu_dev"], s["cu"], s["prefix"])
@@ -330,6 +464,16 @@ def main():
     elapsed = D.all_reduce_max_float(elapsed, device=dev)
 
     users_rank = sum(steps[i % nb]["users"] for i in range(args.steps))
+    # what the planted labels make the retrieve metrics: float64 on the host from the planted ranks of the timed steps'
+    # users, summed over ranks (outside the timed region)
+    first = np.concatenate([[0], np.cumsum([s["users"] for s in steps])])
+    timed_ranks = np.concatenate([planted_ranks[first[i % nb]: first[i % nb + 1]] for i in range(args.steps)])
+    exp_keys = ["Recall@10", "MRR@10", "NDCG@10", "NDCG@50"]
+    exp_local = metrics_of_ranks(timed_ranks, [10, 50], denom=1)
+    exp_t = torch.tensor([exp_local[k] for k in exp_keys], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(exp_t)
+    expected = {k: float(v) / max(1, total_users) for k, v in zip(exp_keys, exp_t.tolist())}
     tok_rank = sum(int(steps[i % nb]["cu"][-1]) for i in range(args.steps))
     # rows the prefill executes: the shared prefix once per step instead of once per prompt
     rows_rank = sum(int(steps[i % nb]["cu"][-1]) - (steps[i % nb]["users"] - 1) * steps[i % nb]["prefix"] for i in range(args.steps))
@@ -350,11 +494,13 @@ def main():
         k_ms, k_fl, k_n = collect(5)
         if g_n:
             ach = g_fl / (g_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic()
+            shapes = gemm_shapes(lib, cfg["hidden_size"], cfg["intermediate_size"])
+            traffic, traffic_src, traffic_shapes = pmc_traffic(shapes)
             roofline = {"bound": "mfma", "kernel": "gemm256rb_kernel (bf16 256x256x64 MFMA tile, ping-pong pipeline; QKV+RoPE/O/gate-up+SwiGLU/down)",
                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                         "traffic": traffic, "traffic_source": traffic_src, "launches": g_n, "avg_launch_ms": g_ms / g_n,
-                        "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed}
+                        "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed,
+                        "per_shape": shapes, "traffic_per_shape": traffic_shapes}
         extra = {"attention_tflops": (a_fl / (a_ms * 1e-3) / 1e12) if a_n else None,
                  "attention_share_of_step_time": a_ms * 1e-3 / elapsed if a_n else None,
                  "stage1_ms_per_step": (e_ms + k_ms) / max(1, args.steps),
@@ -391,7 +537,12 @@ def main():
             "roofline": roofline, "stage1_only_users_per_s": stage1_users_per_s,
             "prefill_algorithmic_tflops_per_gpu": alg_flops / elapsed / 1e12,
             "metrics": {"retrieve_NDCG@10": retr["NDCG@10"], "rerank_overall_NDCG@10": rer["NDCG@10"],
-                        "users_counted": total_users},
+                        "retrieve_Recall@10": retr["Recall@10"], "retrieve_MRR@10": retr["MRR@10"],
+                        "rerank_overall_Recall@10": rer["Recall@10"], "users_counted": total_users,
+                        "labels": (f"planted outside the timed region: user j's label = the retriever's rank-(j mod "
+                                   f"{PLANT_PERIOD}) item, none for ranks >= 50 (bench.py plant_labels)"),
+                        "expected_retrieve": expected,
+                        "retrieve_matches_expected": bool(all(abs(retr[k] - v) <= 1e-9 for k, v in expected.items()))},
         }
         out.update(extra)
         if world == 1 and not args.no_other_shapes and args.layers == LLAMA2_7B["num_hidden_layers"]:
@@ -448,9 +599,13 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
             sq[-1] = 2                                    # EOS closes a training sample
         labs = [np.where(np.arange(len(sq)) >= len(sq) - 2, sq, -100) for sq in seqs]
         mb.append((seqs, labs))
+    # one workspace for the largest micro-batch of the run, allocated BEFORE the clock starts: round 2 warmed mb[0] only
+    # and re-allocated the tens-of-GB workspace inside the timed loop whenever a larger micro-batch arrived (628 ms/step)
+    eng.reserve([(sum(len(sq) for sq in seqs), len(seqs), 2 * len(seqs)) for seqs, _ in mb])
     eng.loss_and_grads(*mb[0])
     eng.apply(2e-4, 1.0)
     torch.cuda.synchronize()
+    allocs_before = eng.ws_allocations
     tt = time.perf_counter()
     for seqs, labs in mb:
         eng.loss_and_grads(seqs, labs)
@@ -461,6 +616,9 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
     out["lora_train_shape"] = {"micro_batch_prompts": len(mb[0][0]), "optimizer_steps": len(mb),
                                "ms_per_step": tt / len(mb) * 1e3, "tokens_per_s": ntok / tt,
                                "samples_per_s": sum(len(sq) for sq, _ in mb) / tt,
+                               "tokens_per_step": ntok / len(mb),
+                               "workspace_allocations_in_timed_loop": eng.ws_allocations - allocs_before,
+                               "workspace_gb": eng._ws.numel() / 1e9,
                                "loss_finite": bool(np.isfinite(float(eng._out[0])))}
     del eng
     return out

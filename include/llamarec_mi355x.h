@@ -90,7 +90,9 @@ void lr_lru_destroy(lr_lru_t* h);
 
 /* Workspace (device) bytes needed by lr_lru_retrieve_topk / lr_lru_scores_last for up to
  * max_users histories of up to max_len ids per call (q rows, per-chunk partial top-K lists,
- * sorted history ids for the mask). */
+ * sorted history ids for the mask, the bound pre-pass's scratch for catalogs it serves). h must be a live handle
+ * (the size depends on the catalog; NULL returns 0 and sets lr_last_error). The size is monotone in every argument:
+ * a workspace sized for (max_users, max_k, max_len) serves every call with B <= max_users, K <= max_k, L <= max_len. */
 size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k, int32_t max_len);
 
 /* Encode B histories and return the hidden state of the LAST position, q[B][64] (fp32).
@@ -251,8 +253,10 @@ int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_ids, const i
  * and the attention kernel reads keys/values of positions < prefix_len from the prefix rows. Inputs are the caller's
  * ordinary packed prompts (prefix included in each). Scores are BIT-IDENTICAL to lr_llama_prefill_verbalize.
  * Preconditions: 0 <= prefix_len < the shortest prompt; ids[cu[b] + i] == ids[cu[0] + i] for all b, i < prefix_len
- * (lr_common_prefix_len computes the largest such value from host copies). prefix_len = 0, B = 1, head_dim != 128
- * or the generic attention variant run the plain path. */
+ * (lr_common_prefix_len computes the largest such value from host copies). The second precondition is VERIFIED on the
+ * device: if any prompt's first prefix_len ids differ from prompt 0's, every score of the call is NaN (prefix rows, keys
+ * and values come from prompt 0, so a stale prefix_len would otherwise score the other prompts silently wrong).
+ * prefix_len = 0, B = 1, head_dim != 128 or the generic attention variant run the plain path. */
 int lr_llama_prefill_verbalize_prefix(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
                                       const int32_t* cu_seqlens_host, int32_t B, int32_t prefix_len,
                                       const int32_t* label_token_ids, int32_t C, float* out_scores,
@@ -299,6 +303,18 @@ int lr_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M
 int lr_gemm_bf16_nt_ws(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_t M, int32_t N,
                        int32_t K, int32_t variant, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* The projection GEMM with each of the prefill's fused epilogues (exposed for parity tests and per-shape timing):
+ *   epilogue 0 store | 1 residual: C = bf16(bf16(acc) + R), R bf16 [M][N], may alias C | 2 SwiGLU over gate/up rows
+ *   interleaved in groups of 16 (lr_llama_pack_gate_up), C is [M][N/2] | 3 rotary embedding on columns
+ *   [0, rot_cols) of pair-interleaved q/k rows (lr_llama_pack_qkv), tok_pos int32 [M], rope_cs from lr_rope_table.
+ * These are the epilogues of HF LlamaAttention / LlamaMLP around the Linears of model/llm.py:89-100 (reference). */
+int lr_gemm_bf16_nt_epi(const uint16_t* A, const uint16_t* B, uint16_t* C, const uint16_t* R, int32_t M, int32_t N,
+                        int32_t K, int32_t epilogue, int32_t variant, const int32_t* tok_pos, const float* rope_cs,
+                        int32_t head_dim, int32_t rot_cols, void* workspace, size_t workspace_bytes, void* hip_stream);
+/* cs: DEVICE fp32 [max_positions][head_dim/2][2] = (cos, sin) of position * theta^(-2i/head_dim), rounded to bf16 values
+ * (HF LlamaRotaryEmbedding casts cos/sin to the activations' dtype). */
+int lr_rope_table(float* cs, int32_t max_positions, int32_t head_dim, float theta, void* hip_stream);
+
 /* Stand-alone varlen causal attention (exposed for parity tests):
  * qkv: DEVICE bf16 [total][(nh+2*nkv)*hd] (RoPE already applied; any consistent permutation of the
  * dims inside q and k heads), out: bf16 [total][nh*hd]. */
@@ -318,6 +334,10 @@ int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_se
 int lr_profile_start(int32_t max_records);
 int lr_profile_stop(void);
 int lr_profile_collect(int32_t kind, double* total_ms, double* total_work, int64_t* launches);
+/* Per-launch records of one kind, in launch order: ms[i], work[i], tag[i] for i < min(return value, max_records);
+ * returns the number of records of that kind (-1 on error). GEMM tags: (epilogue << 56) | (N << 28) | K, so a caller
+ * can report each projection shape separately. Pass max_records = 0 (arrays may be NULL) to count. */
+int64_t lr_profile_records(int32_t kind, double* ms, double* work, int64_t* tag, int64_t max_records);
 
 /* ===========================================================================================
  * Retriever training step

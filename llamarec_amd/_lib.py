@@ -9,7 +9,9 @@ import os
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libllamarec_mi355x.so")
+# LLAMAREC_LIB selects another BUILD of the same library (same-box A/B runs of two commits: tools/gpu_ab_lib.sh) without
+# overwriting the product file; it is never a fallback -- a missing file raises like the default one.
+LIB_PATH = os.environ.get("LLAMAREC_LIB") or os.path.join(_HERE, "lib", "libllamarec_mi355x.so")
 _lib = None
 
 
@@ -38,6 +40,11 @@ PROTOTYPES = {
     "lr_profile_stop": (C.c_int, []),
     "lr_profile_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64)]),
+    "lr_profile_records": (C.c_int64, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "lr_gemm_bf16_nt_epi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "lr_rope_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "lr_metrics_from_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "lr_lru_train_state_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "lr_lru_train_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

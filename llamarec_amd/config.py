@@ -59,6 +59,10 @@ def build_parser():
     p.add_argument("--data_root", type=str, default=RAW_DATASET_ROOT_FOLDER)
     p.add_argument("--export_root", type=str, default=None)
     p.add_argument("--llm_adapter_path", type=str, default=None, help="local PEFT adapter directory")
+    p.add_argument("--lora_token_budget", type=int, default=16384, help="tokens per forward/backward pass when an "
+                   "optimizer step's micro-batches are regrouped (same summed gradient; 0 = the reference's micro-batches)")
+    p.add_argument("--eval_token_budget", type=int, default=None, help="prompt tokens per evaluation prefill (default "
+                   "packing.TOKEN_BUDGET; 0 = fixed batches of --test_batch_size prompts like the reference's loader)")
     p.add_argument("--synthetic", action="store_true", help="fabricate dataset / weights (nothing exists offline)")
     # retriever training (config.py:166-202,216-217; defaults filled in set_template like config.py:103-134)
     p.add_argument("--train_batch_size", type=int, default=None)
@@ -89,6 +93,9 @@ def build_parser():
 def set_template(args):
     """Dataset / model dependent defaults (config.py:57-61,98,103-111,136-146)."""
     ml = args.dataset_code == "ml-100k"
+    # the ranker's evaluation batches by TOKEN budget by default (packing.py); an explicit --test_batch_size still caps the
+    # prompts per prefill (rerank.LLMEvaluator), a template default does not
+    args.test_batch_size_explicit = getattr(args, "test_batch_size", None) is not None
     if args.bert_max_len is None:
         args.bert_max_len = 200 if ml else 50
     if args.bert_num_blocks is None:

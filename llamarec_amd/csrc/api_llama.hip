@@ -93,6 +93,7 @@ struct LlamaWs {
   u16 *x, *xn, *qkv, *att, *hmid;
   u16 *x_last, *xn_last, *att_last, *h_last, *q_last;  // compact [B][.] buffers of the pruned last layer
   float* splitk;                              // fp32 partial planes of the split-K GEMMs (gemm variant 5)
+  int32_t* prefix_bad;                        // device word: a prompt broke the shared-prefix promise (token_meta_kernel)
   bool compact;                               // ws.x_last (not ws.x) holds the final residual rows
   size_t total;
 };
@@ -127,6 +128,7 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.h_last = (u16*)take(nb * c.intermediate_size * 2);
   w.q_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
   w.splitk = (float*)take(LR_SPLITK_WS_BYTES);
+  w.prefix_bad = (int32_t*)take(sizeof(int32_t));
   w.total = o;
   return w;
 }
@@ -188,7 +190,8 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     rc = (x);               \
     if (rc) return rc;      \
   } while (0)
-  RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st, ws.last_pos));
+  RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st, ws.last_pos, ids,
+                           ws.prefix_bad));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
@@ -280,7 +283,7 @@ static int prefill_head(lr_llama_t* h, const int32_t* packed_ids, const int32_t*
   int rc = run_body(h, packed_ids, cu_seqlens, cu_seqlens_host, B, prefix_len, workspace, workspace_bytes, st, &ws);
   if (rc) return rc;
   return lr_launch_head(ws.compact ? ws.x_last : ws.x, ws.compact ? nullptr : ws.last_rows, h->final_norm, h->lm_head,
-                        class_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out, h->cfg.vocab_size, st);
+                        class_ids, B, C, h->cfg.hidden_size, h->cfg.rms_eps, out, h->cfg.vocab_size, st, ws.prefix_bad);
 }
 
 extern "C" int lr_llama_prefill_verbalize(lr_llama_t* h, const int32_t* packed_ids, const int32_t* cu_seqlens,
@@ -371,6 +374,21 @@ extern "C" int lr_gemm_bf16_nt_ws(const uint16_t* A, const uint16_t* B, uint16_t
   if (!A || !B || !C) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_ws: null pointer");
   return lr_launch_gemm(A, B, C, nullptr, M, N, K, LR_EPI_STORE, variant, (hipStream_t)hip_stream, nullptr, nullptr, 0,
                         0, (float*)workspace, workspace_bytes);
+}
+
+extern "C" int lr_gemm_bf16_nt_epi(const uint16_t* A, const uint16_t* B, uint16_t* C, const uint16_t* R, int32_t M,
+                                   int32_t N, int32_t K, int32_t epilogue, int32_t variant, const int32_t* tok_pos,
+                                   const float* rope_cs, int32_t head_dim, int32_t rot_cols, void* workspace,
+                                   size_t workspace_bytes, void* hip_stream) {
+  if (!A || !B || !C) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_epi: null pointer");
+  if (epilogue < LR_EPI_STORE || epilogue > LR_EPI_ROPE) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_epi: epilogue %d", epilogue);
+  return lr_launch_gemm(A, B, C, R, M, N, K, epilogue, variant, (hipStream_t)hip_stream, tok_pos, rope_cs, head_dim,
+                        rot_cols, (float*)workspace, workspace_bytes);
+}
+
+extern "C" int lr_rope_table(float* cs, int32_t max_positions, int32_t head_dim, float theta, void* hip_stream) {
+  if (!cs || max_positions < 1 || head_dim < 2) LR_FAIL(LR_EINVAL, "lr_rope_table: bad argument");
+  return lr_launch_rope_table(cs, max_positions, head_dim, theta, (hipStream_t)hip_stream);
 }
 
 extern "C" int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,

@@ -138,12 +138,16 @@ static int encode(lr_lru_t* h, const int64_t* ids, int B, int L, float* q, void*
 }
 
 extern "C" size_t lr_lru_workspace_bytes(const lr_lru_t* h, int32_t max_users, int32_t max_k, int32_t max_len) {
+  if (!h) {  // the top-K scratch depends on the catalog's tile count: no handle, no size (0 = error, like the other *_bytes)
+    lr_set_error("lr_lru_workspace_bytes: the model handle is null");
+    return 0;
+  }
   if (max_users < 1) max_users = 1;
   if (max_k < 1) max_k = 1;
   if (max_len < 1) max_len = 1;
   // [q | encoder scratch or top-K scratch (never live together)]
   const size_t enc = lr_encoder_mfma_workspace_bytes(max_users, max_len),
-               tk = lr_topk_workspace_bytes(max_users, max_k, max_len, h ? h->lay.rows_padded / LR_ITEM_TILE : 0);
+               tk = lr_topk_workspace_bytes(max_users, max_k, max_len, h->lay.rows_padded / LR_ITEM_TILE);
   return q_bytes(max_users) + (enc > tk ? enc : tk);
 }
 

@@ -31,8 +31,13 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 //   segment b + 1  rows [P + cu[b] - b P, P + cu[b+1] - (b+1) P)   = prompt b's tokens at positions P..T_b-1
 // tok_pos = position inside the prompt (rotary embedding), tok_src = index into the caller's packed ids,
 // last_rows[b] = internal row of prompt b's last token, seg_start[0..S] = segment starts.
+// ids / prefix_bad (shared prefix only): the caller PROMISES that every prompt starts with prompt 0's first P tokens; the
+// promise is checked here -- a prompt whose first P ids differ sets *prefix_bad, and head_kernel then writes NaN scores
+// for the whole call (prefix rows, K and V come from prompt 0: a stale prefix_len would otherwise score prompts 1..B-1
+// silently wrong).
 __global__ void token_meta_kernel(const int32_t* cu, int B, int P, int32_t* seg_start, int32_t* tok_pos,
-                                  int32_t* tok_src, int32_t* last_rows, int32_t* last_pos) {
+                                  int32_t* tok_src, int32_t* last_rows, int32_t* last_pos, const int32_t* ids,
+                                  int32_t* prefix_bad) {
   const int seg = blockIdx.x;
   int start, len, pos0, src0;
   if (P > 0 && seg == 0) {
@@ -40,6 +45,12 @@ __global__ void token_meta_kernel(const int32_t* cu, int B, int P, int32_t* seg_
   } else {
     const int b = P > 0 ? seg - 1 : seg;
     const int s = cu[b], e = cu[b + 1];
+    if (P > 0 && b > 0 && ids && prefix_bad) {
+      const int s0 = cu[0];
+      bool bad = false;
+      for (int i = threadIdx.x; i < P; i += blockDim.x) bad |= ids[s + i] != ids[s0 + i];
+      if (bad) atomicOr(prefix_bad, 1);
+    }
     start = P > 0 ? P + s - b * P : s;
     len = e - s - P;
     pos0 = P;
@@ -203,11 +214,18 @@ __global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, flo
 // grid (B, ceil(C/32)); out[b][c] = float(bf16(sum_k xn[k] * W[row_c][k])), row_c = ids ? ids[c] : c
 __global__ __launch_bounds__(256) void head_kernel(const u16* x, const int32_t* rows, const u16* norm_w,
                                                    const u16* lm_head, const int32_t* class_ids, int C,
-                                                   int d, float eps, float* out, int vocab) {
+                                                   int d, float eps, float* out, int vocab, const int32_t* poison) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   u16* xn = reinterpret_cast<u16*>(smem_raw);  // [d]
   __shared__ float red[4];
   const int b = blockIdx.x;
+  if (poison && *poison) {  // the call's shared-prefix promise was broken (token_meta_kernel): no score is trustworthy
+    for (int cc = threadIdx.x; cc < 32; cc += 256) {
+      const int c = blockIdx.y * 32 + cc;
+      if (c < C) out[(size_t)b * C + c] = __builtin_nanf("");
+    }
+    return;
+  }
   const int row = rows ? rows[b] : b;  // rows == nullptr: x is already compact, one row per prompt
   const u16* xr = x + (size_t)row * d;
   float ss = 0.f;
@@ -259,10 +277,12 @@ int lr_launch_gather_rows(const u16* x, const int32_t* rows, int n_rows, int d, 
 
 // ---------------------------------------------------------------------------------------------
 int lr_launch_token_meta(const int32_t* cu, int B, int prefix_len, int32_t* seg_start, int32_t* tok_pos,
-                         int32_t* tok_src, int32_t* last_rows, hipStream_t st, int32_t* last_pos) {
+                         int32_t* tok_src, int32_t* last_rows, hipStream_t st, int32_t* last_pos, const int32_t* ids,
+                         int32_t* prefix_bad) {
   const int S = prefix_len > 0 ? B + 1 : B;
+  if (prefix_bad) LR_CHECK_HIP(hipMemsetAsync(prefix_bad, 0, sizeof(int32_t), st));
   hipLaunchKernelGGL(token_meta_kernel, dim3(S), dim3(256), 0, st, cu, B, prefix_len, seg_start, tok_pos, tok_src,
-                     last_rows, last_pos);
+                     last_rows, last_pos, ids, prefix_bad);
   LR_CHECK_LAUNCH("token_meta_kernel");
   return LR_OK;
 }
@@ -290,10 +310,10 @@ int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st) 
 
 int lr_launch_head(const u16* x, const int32_t* rows, const u16* norm_w, const u16* lm_head,
                    const int32_t* class_ids, int B, int C, int d, float eps, float* out, int vocab,
-                   hipStream_t st) {
+                   hipStream_t st, const int32_t* poison) {
   dim3 grid(B, (C + 31) / 32);
   hipLaunchKernelGGL(head_kernel, grid, dim3(256), (size_t)d * sizeof(u16), st, x, rows, norm_w, lm_head,
-                     class_ids, C, d, eps, out, vocab);
+                     class_ids, C, d, eps, out, vocab, poison);
   LR_CHECK_LAUNCH("head_kernel");
   return LR_OK;
 }

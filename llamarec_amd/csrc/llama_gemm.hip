@@ -252,7 +252,46 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // Split-K (EPI == LR_EPI_PARTIAL): blockIdx.y = split s works on K tiles [s*T/S, (s+1)*T/S) and stores its
 // fp32 partial plane at ((float*)C)[s][M][N]; splitk_reduce_kernel sums the planes in order and applies the
 // real epilogue.
-template <int EPI, bool FOLD = false>
+// Diagnostic stamps: STAMP = true is instantiated only in a -DLR_EXPERIMENTS build (make EXPERIMENTS=1, then
+// LR_GEMM_STAMPS=1 at run time; tools/gemm_stamps.py); the product library holds no stamping code. Per workgroup (wave 0
+// and wave 4 = one wave of each ping-pong group): s_memtime at kernel entry, after the prologue, after the K loop, after
+// the epilogue's last store is ISSUED, and after those stores have completed (vmcnt(0)); s_memrealtime (100 MHz) at
+// entry and exit for the clock; the XCC id.
+#define GEMM_STAMP_SLOTS 8
+#ifndef LR_EXPERIMENTS
+#define GEMM_STAMP(slot)
+#define GEMM_STAMP_REAL(slot)
+#define GEMM_STAMP_END()
+#else
+__device__ unsigned long long g_gemm_stamps[16384 * 2 * GEMM_STAMP_SLOTS];
+#define GEMM_STAMP(slot)                                                                \
+  if (STAMP && (wave & 3) == 0 && lane == 0 && blockIdx.x < 16384 && blockIdx.y == 0) { \
+    unsigned long long t_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    g_gemm_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * GEMM_STAMP_SLOTS + (slot)] = t_; \
+  }
+#define GEMM_STAMP_REAL(slot)                                                           \
+  if (STAMP && (wave & 3) == 0 && lane == 0 && blockIdx.x < 16384 && blockIdx.y == 0) { \
+    unsigned long long t_;                                                              \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+    g_gemm_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * GEMM_STAMP_SLOTS + (slot)] = t_; \
+  }
+#define GEMM_STAMP_END()                                                                       \
+  if (STAMP) {                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+    GEMM_STAMP(4)                                                                              \
+    GEMM_STAMP_REAL(6)                                                                         \
+    if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 16384 && blockIdx.y == 0) {              \
+      unsigned xcc;                                                                            \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                       \
+      g_gemm_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * GEMM_STAMP_SLOTS + 7] = xcc & 0xf; \
+    }                                                                                          \
+  }
+#endif
+
+template <int EPI, bool FOLD = false, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ A,
                                                         const u16* __restrict__ B, u16* C,
                                                         const u16* R, int M, int N, int K, int group_m,
@@ -261,6 +300,8 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  GEMM_STAMP(0)
+  GEMM_STAMP_REAL(5)
   int kt_first = 0, nkt = K >> 6;
   if (EPI == LR_EPI_PARTIAL) {
     const int s = blockIdx.y, S = gridDim.y, T = K >> 6;
@@ -412,6 +453,7 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   }
   PP_BARRIER();
   RB_LOAD_B(b0x, smem, 0)
+  GEMM_STAMP(1)
   if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
 
   for (int kt = 0; kt < nkt; kt += 2) {
@@ -419,6 +461,7 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
     if (kt + 1 < nkt) RB_TILE(kt + 1, b0y, b0x)
   }
   if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
+  GEMM_STAMP(2)
 #undef RB_DMA
 #undef RB_LOAD_A
 #undef RB_LOAD_B
@@ -536,6 +579,8 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
       }
     }
   }
+  GEMM_STAMP(3)
+  GEMM_STAMP_END()
 }
 
 // =============================================================================================
@@ -605,7 +650,7 @@ static int gemm256_prepare() {
 template <int EPI>
 static int launch_splitk(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int S, RopeArgs rope,
                          float* ws, hipStream_t st) {
-  LrProfScope prof(LR_PROF_GEMM256, 2.0 * M * (double)N * K, st);
+  LrProfScope prof(LR_PROF_GEMM256, 2.0 * M * (double)N * K, st, LR_PROF_GEMM_TAG(EPI, N, K));
   if (int rc = gemm256_prepare<LR_EPI_PARTIAL>()) return rc;
   const int nwg = ((M + 255) / 256) * (N / 256);
   hipLaunchKernelGGL(gemm256rb_kernel<LR_EPI_PARTIAL>, dim3(nwg, S), dim3(512), 2 * G2_STAGE_BYTES, st, A, B,
@@ -622,7 +667,8 @@ static int launch_splitk(const u16* A, const u16* B, u16* C, const u16* R, int M
 template <int EPI>
 static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int variant,
                       RopeArgs rope, hipStream_t st) {
-  LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st);
+  LrProfScope prof(variant >= 2 ? LR_PROF_GEMM256 : LR_PROF_GEMM_GENERIC, 2.0 * M * (double)N * K, st,
+                   LR_PROF_GEMM_TAG(EPI, N, K));
   if (variant == 4) {
     const int nwg = ((M + 255) / 256) * (N / 256);
     bool launched = false;
@@ -634,6 +680,20 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
         launched = true;
       }
     }
+#ifdef LR_EXPERIMENTS
+    if (!launched) {
+      const char* stamp_env = getenv("LR_GEMM_STAMPS");
+      if (stamp_env && stamp_env[0] == '1') {
+        static bool done[LR_MAX_DEVICES] = {};
+        if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(gemm256rb_kernel<EPI, false, true>),
+                                           2 * G2_STAGE_BYTES, done))
+          return rc;
+        hipLaunchKernelGGL((gemm256rb_kernel<EPI, false, true>), dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N,
+                           K, gemm256_group_m(K), rope);
+        launched = true;
+      }
+    }
+#endif
     if (!launched) {
       if (int rc = gemm256_prepare<EPI>()) return rc;
       hipLaunchKernelGGL(gemm256rb_kernel<EPI>, dim3(nwg), dim3(512), 2 * G2_STAGE_BYTES, st, A, B, C, R, M, N, K,
@@ -647,6 +707,15 @@ static int launch_epi(const u16* A, const u16* B, u16* C, const u16* R, int M, i
   }
   return LR_OK;
 }
+
+#ifdef LR_EXPERIMENTS
+extern "C" int lr_debug_gemm_stamps(unsigned long long* out, int n_workgroups) {
+  if (!out || n_workgroups < 1 || n_workgroups > 16384) LR_FAIL(LR_EINVAL, "lr_debug_gemm_stamps: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps),
+                                   (size_t)n_workgroups * 2 * GEMM_STAMP_SLOTS * sizeof(unsigned long long)));
+  return LR_OK;
+}
+#endif
 
 int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
                    int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs, int head_dim,

@@ -33,7 +33,9 @@ __device__ __forceinline__ unsigned short swiglu_bf16(float g, float u) {
 // (optional) the index of every internal row in the caller's packed ids, last_rows (optional) each prompt's last row,
 // last_pos (optional) the position of that token inside its prompt
 int lr_launch_token_meta(const int32_t* cu, int B, int prefix_len, int32_t* seg_start, int32_t* tok_pos,
-                         int32_t* tok_src, int32_t* last_rows, hipStream_t st, int32_t* last_pos = nullptr);
+                         int32_t* tok_src, int32_t* last_rows, hipStream_t st, int32_t* last_pos = nullptr,
+                         const int32_t* ids = nullptr /* with prefix_bad: verify the shared-prefix promise */,
+                         int32_t* prefix_bad = nullptr /* device word: zeroed, then set if a prompt's first P ids differ */);
 int lr_launch_gather_rows(const unsigned short* x, const int32_t* rows, int n_rows, int d, unsigned short* out,
                           hipStream_t st);
 int lr_launch_attention_rows(const unsigned short* qkv, unsigned short* out, const int32_t* cu, int B,
@@ -46,7 +48,8 @@ int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st);
 int lr_launch_head(const unsigned short* x, const int32_t* rows /*[B]; nullptr: x holds one row per prompt*/,
                    const unsigned short* norm_w,
                    const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
-                   float* out, int vocab, hipStream_t st);
+                   float* out, int vocab, hipStream_t st,
+                   const int32_t* poison = nullptr /* device word: non-zero -> every score of the call is NaN */);
 
 // C[M][N] (+epilogue) = A[M][K] * B[N][K]^T. variant: 0 auto, 1 generic, 4 = 256x256x64 MFMA tile,
 // 5 = variant 4 with split-K when the tiles alone would leave most CUs idle (needs splitk_ws).

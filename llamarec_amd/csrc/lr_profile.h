@@ -12,13 +12,16 @@
 #define LR_PROF_ITEM_TOPK 5
 #define LR_PROF_ELEMENTWISE 6
 
-bool lr_prof_begin(int kind, double work, hipStream_t st);
+// tag: free-form 64-bit label kept with the record (GEMMs: LR_PROF_GEMM_TAG(epi, N, K)) so a caller can split a
+// kind by shape (lr_profile_records)
+#define LR_PROF_GEMM_TAG(epi, N, K) (((long long)(epi) << 56) | ((long long)(N) << 28) | (long long)(K))
+bool lr_prof_begin(int kind, double work, hipStream_t st, long long tag = 0);
 void lr_prof_end(hipStream_t st);
 
 struct LrProfScope {
   hipStream_t st;
   bool on;
-  LrProfScope(int kind, double work, hipStream_t s) : st(s), on(lr_prof_begin(kind, work, s)) {}
+  LrProfScope(int kind, double work, hipStream_t s, long long tag = 0) : st(s), on(lr_prof_begin(kind, work, s, tag)) {}
   ~LrProfScope() {
     if (on) lr_prof_end(st);
   }

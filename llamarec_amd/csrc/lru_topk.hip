@@ -1084,9 +1084,13 @@ static size_t bound_bytes(int B, int n_tiles) {
          lr_align_up(((size_t)B + 1) * sizeof(int), 256) + lr_align_up((size_t)B * TK_CAND_CAP * sizeof(int32_t), 256);
 }
 
+// Sized for EVERY call of up to (B users, K, L): whether the bound pre-pass runs depends on K + L + 1 <= n_tiles, which a
+// later call with a smaller K or L can satisfy when the sizing call did not -- so its scratch is included whenever the
+// catalog's tile count is in the pre-pass's range, whatever K and L (the size is monotone in B, K and L).
 size_t lr_topk_workspace_bytes(int B, int K, int L, int n_tiles) {
+  const bool in_range = n_tiles >= TK_BOUND_MIN_TILES && n_tiles <= TK_BOUND_MAX_TILES;
   return partial_bytes_max(B, K) + lr_align_up((size_t)B * (L > 0 ? L : 1) * sizeof(int32_t), 256) +
-         (bound_enabled(n_tiles, K, L) ? bound_bytes(B, n_tiles) : 0);
+         (in_range ? bound_bytes(B, n_tiles) : 0);
 }
 
 int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int B, int L, int K,

@@ -11,17 +11,19 @@ struct Rec {
   hipEvent_t a, b;
   int kind;
   double work;
+  long long tag;
 };
 std::vector<Rec> g_pool;
 int g_used = 0;
 bool g_on = false;
 }  // namespace
 
-bool lr_prof_begin(int kind, double work, hipStream_t st) {
+bool lr_prof_begin(int kind, double work, hipStream_t st, long long tag) {
   if (!g_on || g_used >= (int)g_pool.size()) return false;
   Rec& r = g_pool[g_used];
   r.kind = kind;
   r.work = work;
+  r.tag = tag;
   return hipEventRecord(r.a, st) == hipSuccess;
 }
 
@@ -66,4 +68,27 @@ extern "C" int lr_profile_collect(int32_t kind, double* total_ms, double* total_
   *total_work = work;
   *launches = n;
   return LR_OK;
+}
+
+extern "C" int64_t lr_profile_records(int32_t kind, double* ms, double* work, int64_t* tag, int64_t max_records) {
+  if (g_on) {
+    lr_set_error("lr_profile_records: call lr_profile_stop() and synchronise the stream first");
+    return -1;
+  }
+  int64_t n = 0;
+  for (int i = 0; i < g_used; ++i) {
+    if (g_pool[i].kind != kind) continue;
+    if (n < max_records && ms && work && tag) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b) != hipSuccess) {
+        lr_set_error("lr_profile_records: hipEventElapsedTime failed (stream not synchronised?)");
+        return -1;
+      }
+      ms[n] = t;
+      work[n] = g_pool[i].work;
+      tag[n] = g_pool[i].tag;
+    }
+    ++n;
+  }
+  return n;
 }

@@ -17,10 +17,11 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment (no-op for a single process)."""
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from torchrun's environment (no-op for a single process unless `force`: a 1-rank
+    group still loads RCCL and runs its collectives -- tests/test_gpu_rccl.py rehearses the job's exchange that way)."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -38,7 +39,7 @@ def shard_range(n_users: int, rank: int, world: int):
 
 
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # a 1-rank group too: the collective is then RCCL's no-op path
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 

@@ -65,14 +65,70 @@ def truncate_title(title, tokenizer, max_title_len=LLM_MAX_TITLE_LEN):
     return tokenizer.convert_tokens_to_string(tokenizer.tokenize(title)[:max_title_len])
 
 
+class TitleCache:
+    """Per-ITEM memo of truncate_title. The reference truncates every title of every prompt by a tokenizer round trip
+    (dataloader/llm.py:67-70: 41 tokenizer calls per evaluation user); the result is a pure function of (title,
+    tokenizer, max_title_len), so one call per item of the catalog (12 k on Beauty against 22 k users x 41) builds the
+    same prompt strings. `ntok[item]` (the truncated title's token count) also gives a prompt-length estimate without
+    tokenising the prompt (estimate_prompt_tokens: what the data-parallel shards are balanced by BEFORE tokenisation)."""
+
+    def __init__(self, text_dict, tokenizer, max_title_len=LLM_MAX_TITLE_LEN):
+        self.text_dict, self.tokenizer, self.max_title_len = text_dict, tokenizer, max_title_len
+        self._text, self.ntok = {}, {}
+
+    def __call__(self, item):
+        t = self._text.get(item)
+        if t is None:
+            toks = self.tokenizer.tokenize(self.text_dict[item])[: self.max_title_len]
+            t = self._text[item] = self.tokenizer.convert_tokens_to_string(toks)
+            self.ntok[item] = len(toks)
+        return t
+
+    def estimate_prompt_tokens(self, seq, candidates, overhead=64, per_line=5):
+        """~ tokens of the prompt built from (seq, candidates): template text + per-line markers + title tokens."""
+        n = overhead + per_line * (len(seq) + len(candidates))
+        for item in list(seq) + list(candidates):
+            if item not in self.ntok:
+                self(item)
+            n += self.ntok[item]
+        return n
+
+
 def build_input_text(seq, candidates, text_dict, tokenizer, max_title_len=LLM_MAX_TITLE_LEN,
-                     input_template=DEFAULT_INPUT_TEMPLATE, truncate=True):
+                     input_template=DEFAULT_INPUT_TEMPLATE, truncate=True, title_cache=None):
     """History as "(1) title \\n (2) title", candidates as "(A) title \\n (B) title"
-    (dataloader/llm.py:72-83,92). truncate=False is the online demo's variant (demo/inference.py:79-109)."""
-    tt = (lambda t: truncate_title(t, tokenizer, max_title_len)) if truncate else (lambda t: t)
-    seq_t = " \n ".join("(" + str(i + 1) + ") " + tt(text_dict[item]) for i, item in enumerate(seq))
-    can_t = " \n ".join("(" + chr(ord("A") + i) + ") " + tt(text_dict[item]) for i, item in enumerate(candidates))
+    (dataloader/llm.py:72-83,92). truncate=False is the online demo's variant (demo/inference.py:79-109).
+    title_cache: a TitleCache over (text_dict, tokenizer, max_title_len) -- the same strings, one tokenizer call per item."""
+    if not truncate:
+        tt = lambda item: text_dict[item]
+    elif title_cache is not None:
+        tt = title_cache
+    else:
+        tt = lambda item: truncate_title(text_dict[item], tokenizer, max_title_len)
+    seq_t = " \n ".join("(" + str(i + 1) + ") " + tt(item) for i, item in enumerate(seq))
+    can_t = " \n ".join("(" + chr(ord("A") + i) + ") " + tt(item) for i, item in enumerate(candidates))
     return input_template.format(seq_t, can_t)
+
+
+def eval_prompt_text(seq, candidates, label, text_dict, tokenizer, prompter=None, max_title_len=LLM_MAX_TITLE_LEN,
+                     system_template=DEFAULT_SYSTEM_TEMPLATE, input_template=DEFAULT_INPUT_TEMPLATE, title_cache=None):
+    """The string seq_to_token_ids tokenises and the answer's class index (dataloader/llm.py:64-98, eval branch)."""
+    prompter = prompter or Prompter()
+    candidates = list(candidates)
+    text = build_input_text(seq, candidates, text_dict, tokenizer, max_title_len, input_template, title_cache=title_cache)
+    return prompter.generate_prompt(system_template, text), candidates.index(label)
+
+
+def tokenize_prompts(prompts, tokenizer, max_text_len=LLM_MAX_TEXT_LEN):
+    """input_ids of generate_and_tokenize_eval (dataloader/llm.py:19-30: truncation=True, max_length, no padding) for a
+    LIST of prompt strings. A HF fast tokenizer encodes the list in one call (its Rust encoder runs the prompts in
+    parallel and releases the GIL, so a producer thread overlaps it with the GPU loop); any other tokenizer is called
+    per prompt. Same ids either way (tests/test_host_logic.py)."""
+    if getattr(tokenizer, "is_fast", False) and len(prompts) > 1:
+        enc = tokenizer(list(prompts), truncation=True, max_length=max_text_len, padding=False, return_tensors=None)
+        return [list(x) for x in enc["input_ids"]]
+    return [list(tokenizer(p, truncation=True, max_length=max_text_len, padding=False, return_tensors=None)["input_ids"])
+            for p in prompts]
 
 
 def seq_to_token_ids(seq, candidates, label, text_dict, tokenizer, prompter=None,

@@ -45,7 +45,14 @@ class LLMEvaluator:
         self.export_root = export_root
         self.ks = list(getattr(args, "rerank_metric_ks", RERANK_METRIC_KS))
         self.batch_size = batch_size or getattr(args, "test_batch_size", 16)
-        self.token_budget = PK.TOKEN_BUDGET if token_budget == "auto" else token_budget
+        if token_budget == "auto":       # --eval_token_budget: None -> packing.TOKEN_BUDGET, 0 -> the reference's fixed batches
+            tb = getattr(args, "eval_token_budget", None)
+            token_budget = PK.TOKEN_BUDGET if tb is None else (tb or None)
+        self.token_budget = token_budget
+        # prompts per prefill in token-budget mode: the reference's batch knob (config.py:98) still applies when the user SET
+        # it (a caller's batch_size argument or an explicit --test_batch_size); the template's default (16 / 32) does not
+        # -- it would cut a 32 768-token step down to a third
+        self.max_prompts = batch_size or (self.batch_size if getattr(args, "test_batch_size_explicit", False) else None)
         self.max_text_len = getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN)
 
     def predict(self):
@@ -60,6 +67,20 @@ class LLMEvaluator:
         rank, world, _ = D.env_world()
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             rank, world = 0, 1
+        if isinstance(self.items, LazyEvalItems):
+            # shard FIRST (by the title-cache estimate of every prompt's tokens), tokenise only this rank's users, in a
+            # producer thread that stays ahead of the GPU loop
+            lo, hi = PK.shard_by_tokens(self.items.estimate_lengths(), world)[rank]
+            if self.token_budget:
+                stream = stream_token_budget_batches(self.items, lo, hi, self.token_budget, self.max_text_len,
+                                                     self.max_prompts)
+            else:
+                stream = (P.eval_pack(self.items.build(i, min(i + self.batch_size, hi)), self.max_text_len)
+                          for i in range(lo, hi, self.batch_size))
+            for seqs, labels in stream:
+                scores = self.model.prefill_verbalize(seqs, self.verbalizer.label_token_ids)
+                M.rank_histogram(M.rank_classes(scores), torch.from_numpy(labels).to(self.model.device), hist)
+            return self._finish(hist, t0)
         # contiguous shards balanced by prompt TOKENS, then token-budget batches inside the shard
         lens = np.array([min(len(it["input_ids"]), self.max_text_len) for it in self.items], dtype=np.int64)
         lo, hi = PK.shard_by_tokens(lens, world)[rank]
@@ -71,7 +92,7 @@ class LLMEvaluator:
             shared = common_prefix_len(*pack_prompts([np.asarray(it["input_ids"][-self.max_text_len:]) for it in mine])) \
                 if len(mine) > 1 else 0
             batches = PK.token_budget_steps(lens[lo:hi], max(self.token_budget, int(lens.max()) if len(lens) else 1),
-                                            shared_prefix=shared)
+                                            shared_prefix=shared, max_prompts=self.max_prompts)
         else:
             batches = [np.arange(i, min(i + self.batch_size, len(mine))) for i in range(0, len(mine), self.batch_size)]
         for idx in batches:
@@ -79,6 +100,11 @@ class LLMEvaluator:
             scores = self.model.prefill_verbalize(seqs, self.verbalizer.label_token_ids)
             ranked = M.rank_classes(scores)
             M.rank_histogram(ranked, torch.from_numpy(labels).to(self.model.device), hist)
+        return self._finish(hist, t0)
+
+    def _finish(self, hist, t0):
+        from . import dist as D
+
         D.all_reduce_sum_(hist)
         m = M.metrics_from_histogram(hist, self.ks) if len(self.items) else {}
         out = {"test_" + k: v for k, v in m.items()}
@@ -100,6 +126,131 @@ class LLMEvaluator:
                 json.dump(overall, f, indent=4)
         self.overall_metrics = overall
         return average_metrics
+
+
+class LazyEvalItems:
+    """The evaluation prompts of LLMValidDataset / LLMTestDataset (dataloader/llm.py:286-387) built ON DEMAND.
+
+    The reference (and round 2's build_test_items) tokenises every user's prompt serially on every rank before the first
+    prefill: 41 tokenizer calls per user, nothing overlapping the GPU -- at 146 users/s per GPU x 8 that, not the prefill,
+    bounds train_ranker.py on real data. Here
+      * `estimate_lengths()` prices every user's prompt from per-ITEM title token counts (prompt.TitleCache: one
+        tokenizer call per catalog item), so the data-parallel shards are cut BEFORE any prompt is tokenised;
+      * `build(lo, hi)` materialises users [lo, hi) only: prompt strings from the title cache, then ONE batched
+        tokenizer call (prompt.tokenize_prompts);
+      * LLMEvaluator.predict runs `build` for its own shard chunk by chunk in a producer thread feeding a bounded queue
+        ahead of the GPU loop.
+    Items are exactly prompt.seq_to_token_ids' (tests/test_host_logic.py compares them sample by sample)."""
+
+    def __init__(self, dataset, retrieved, tokenizer, args=None, split="test", prompter=None):
+        assert split in ("val", "test")
+        self.dataset, self.tokenizer, self.split = dataset, tokenizer, split
+        self.users = list(retrieved[f"{split}_users"])
+        self.cands = retrieved[f"{split}_candidates"]
+        self.max_hist = getattr(args, "llm_max_history", P.LLM_MAX_HISTORY)
+        self.max_title_len = getattr(args, "llm_max_title_len", P.LLM_MAX_TITLE_LEN)
+        self.max_text_len = getattr(args, "llm_max_text_len", P.LLM_MAX_TEXT_LEN)
+        self.system_template = getattr(args, "llm_system_template", None) or P.DEFAULT_SYSTEM_TEMPLATE
+        self.input_template = getattr(args, "llm_input_template", None) or P.DEFAULT_INPUT_TEMPLATE
+        self.prompter = prompter or P.Prompter()
+        self.titles = P.TitleCache(dataset["meta"], tokenizer, self.max_title_len)
+
+    def __len__(self):
+        return len(self.users)
+
+    def _sample(self, i):
+        user, cands = self.users[i], list(self.cands[i])
+        if self.split == "test":   # dataloader/llm.py:368-375
+            seq = (list(self.dataset["train"][user]) + list(self.dataset["val"][user]))[-self.max_hist:]
+            answer = self.dataset["test"][user][0]
+        else:                      # dataloader/llm.py:315-322
+            seq = list(self.dataset["train"][user])[-self.max_hist:]
+            answer = self.dataset["val"][user][0]
+        assert answer in cands
+        return seq, cands, answer
+
+    def estimate_lengths(self, calibrate=32):
+        """Prompt tokens of every user WITHOUT tokenising the prompts: a + b * lines + c * (sum of the cached title token
+        counts), with (a, b, c) fitted on `calibrate` users spread over the split whose prompts are really tokenised
+        (template text and per-line markers tokenise differently under different tokenizers). Every rank computes the
+        same numbers (same users, same arithmetic), so the shards cut from them agree across ranks."""
+        n = len(self)
+        feats = np.empty((n, 3), np.float64)
+        for i in range(n):
+            seq, cands, _ = self._sample(i)
+            feats[i] = (1.0, len(seq) + len(cands),
+                        self.titles.estimate_prompt_tokens(seq, cands, overhead=0, per_line=0))
+        if n == 0:
+            return np.zeros(0, np.int64)
+        pick = np.unique(np.linspace(0, n - 1, min(n, calibrate)).astype(np.int64))
+        args_long = self.max_text_len
+        self.max_text_len = 1 << 30                       # fit on untruncated lengths
+        try:
+            real = np.array([len(self.build(int(i), int(i) + 1)[0]["input_ids"]) for i in pick], np.float64)
+        finally:
+            self.max_text_len = args_long
+        coef, *_ = np.linalg.lstsq(feats[pick], real, rcond=None)
+        est = np.rint(feats @ coef).astype(np.int64)
+        return np.clip(est, 1, self.max_text_len)
+
+    def build(self, lo, hi):
+        prompts, labels = [], []
+        for i in range(lo, hi):
+            seq, cands, answer = self._sample(i)
+            text, lab = P.eval_prompt_text(seq, cands, answer, self.dataset["meta"], self.tokenizer, self.prompter,
+                                           self.max_title_len, self.system_template, self.input_template, self.titles)
+            prompts.append(text)
+            labels.append(lab)
+        ids = P.tokenize_prompts(prompts, self.tokenizer, self.max_text_len)
+        return [{"input_ids": x, "attention_mask": [1] * len(x), "labels": l} for x, l in zip(ids, labels)]
+
+
+def stream_token_budget_batches(items, lo, hi, token_budget, max_text_len, max_prompts=None, chunk=512, depth=4):
+    """Generator of (seqs, labels) batches over users [lo, hi) of a LazyEvalItems, produced by a background thread
+    `depth` batches ahead of the consumer: each chunk of users is built (tokenised), appended to the pending pool, and
+    the pool's full token-budget steps (packing.token_budget_steps; the last, possibly short step stays pending until
+    the final chunk) are queued. The template prefix every prompt shares is measured on the first chunk."""
+    import queue
+    import threading
+
+    from .llm import common_prefix_len, pack_prompts
+
+    q = queue.Queue(maxsize=depth)
+    END = object()
+
+    def produce():
+        try:
+            pending, shared = [], None
+            for c0 in range(lo, hi, chunk):
+                pending += items.build(c0, min(c0 + chunk, hi))
+                last = c0 + chunk >= hi
+                seqs_all = [np.asarray(it["input_ids"][-max_text_len:], dtype=np.int32) for it in pending]
+                if shared is None:
+                    shared = common_prefix_len(*pack_prompts(seqs_all)) if len(seqs_all) > 1 else 0
+                lens = np.array([len(s) for s in seqs_all], dtype=np.int64)
+                sp = shared if len(lens) and shared < int(lens.min()) else 0
+                steps = PK.token_budget_steps(lens, max(token_budget, int(lens.max())), shared_prefix=sp,
+                                              max_prompts=max_prompts)
+                emit = steps if last else steps[:-1]
+                taken = set()
+                for idx in emit:
+                    q.put(P.eval_pack([pending[int(i)] for i in idx], max_text_len))
+                    taken.update(int(i) for i in idx)
+                pending = [it for i, it in enumerate(pending) if i not in taken]
+            q.put(END)
+        except BaseException as e:  # surface producer failures in the consumer
+            q.put(e)
+
+    t = threading.Thread(target=produce, daemon=True, name="llamarec-tokenize")
+    t.start()
+    while True:
+        b = q.get()
+        if b is END:
+            break
+        if isinstance(b, BaseException):
+            raise b
+        yield b
+    t.join()
 
 
 def build_val_items(dataset, retrieved, tokenizer, args=None, prompter=None):

@@ -168,9 +168,10 @@ def average_gradients_(flat: torch.Tensor) -> torch.Tensor:
     single process."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # a 1-rank group too (rehearsal of the collective on one GPU)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / dist.get_world_size())
+        if dist.get_world_size() > 1:
+            flat.mul_(1.0 / dist.get_world_size())
     return flat
 
 

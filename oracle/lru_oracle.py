@@ -31,7 +31,8 @@ def build(force: bool = False) -> str:
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # LR_ORACLE_LIB: another build of the same oracle (the sanitizer build of tools/sanitize_cpu.sh)
+        _lib = C.CDLL(os.environ.get("LR_ORACLE_LIB") or build())
         _lib.lro_num_threads.restype = C.c_int
     return _lib
 

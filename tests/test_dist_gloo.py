@@ -170,12 +170,14 @@ class _FakeSamples:
         return {"input_ids": ids, "attention_mask": [1] * len(ids), "labels": [-100] * (len(ids) - 2) + ids[-2:]}
 
 
-def _lora_args(micro, batch):
+def _lora_args(micro, batch, token_budget=0):
+    """token_budget 0: the reference's micro-batches as they come (what the grouping assertions below describe)."""
     from types import SimpleNamespace
 
     return SimpleNamespace(lora_micro_batch_size=micro, train_batch_size=batch, lora_max_steps=5, lora_num_epochs=1,
                            warmup_steps=2, lora_lr=0.1, lora_val_iterations=100, lora_val_delay=0,
-                           lora_early_stopping_patience=20, rerank_best_metric="NDCG@10", seed=3, llm_max_text_len=64)
+                           lora_early_stopping_patience=20, rerank_best_metric="NDCG@10", seed=3, llm_max_text_len=64,
+                           lora_token_budget=token_budget)
 
 
 def _lora_worker(rank, world, port, q):
@@ -221,3 +223,33 @@ def test_two_rank_lora_training_shards_microbatches_and_averages_gradients():
             assert single.seen[4 * step + j] == got[j % 2][1][2 * step + j // 2]
     flat = [i for mb in single.seen[:4] for i in mb]
     assert len(set(flat)) == 16                                   # a step's samples are distinct
+
+
+def test_token_budget_repacking_of_an_optimizer_step_keeps_the_gradient():
+    """LoraRankerTrainer.repack: an optimizer step's micro-batches regrouped into token-budget passes reach the same
+    parameters (every labelled token keeps its weight 1 / (accum * m)) in fewer, larger passes; a budget too small for
+    two samples degenerates to one sample per pass and still agrees; unequal label counts keep the reference's grouping."""
+    sys.path.insert(0, REPO)
+    from llamarec_amd.rank_train import LoraRankerTrainer
+
+    ref = _FakeLoraEngine()
+    LoraRankerTrainer(_lora_args(4, 16, 0), ref, _FakeSamples(), [], None, None, 0, 1, log=lambda *a: None).train()
+    assert len(ref.seen) == 5 * 4
+    for budget, passes in ((16384, 5 * 1), (24, None), (9, 5 * 16)):
+        eng = _FakeLoraEngine()
+        tr = LoraRankerTrainer(_lora_args(4, 16, budget), eng, _FakeSamples(), [], None, None, 0, 1, log=lambda *a: None)
+        assert tr.train() == 5
+        assert np.allclose(eng.params.numpy(), ref.params.numpy(), rtol=0, atol=1e-12), budget
+        if passes is not None:
+            assert len(eng.seen) == passes, (budget, len(eng.seen))
+        else:
+            assert 5 * 4 < len(eng.seen) < 5 * 16
+        assert sorted(i for mb in eng.seen[: len(eng.seen) // 5] for i in mb) == sorted(i for mb in ref.seen[:4] for i in mb)
+    # unequal label counts between the micro-batches (train_on_inputs-like): the reference's grouping is kept
+    tr = LoraRankerTrainer(_lora_args(2, 4, 16384), _FakeLoraEngine(), _FakeSamples(), [], None, None, 0, 1, log=lambda *a: None)
+    a = ([np.array([1, 5, 6, 2])] * 2, [np.array([-100, -100, 6, 2])] * 2)
+    b = ([np.array([1, 5, 6, 2])] * 2, [np.array([-100, 5, 6, 2])] * 2)
+    out = tr.repack([a, b])
+    assert len(out) == 2 and out[0][2] == out[1][2] == 0.5
+    out = tr.repack([a, a])
+    assert len(out) == 1 and out[0][2] == 1.0 and len(out[0][0]) == 4

@@ -363,3 +363,67 @@ def _python_sources():
 @pytest.mark.parametrize("script", _python_sources()[1])
 def test_sources_have_no_undefined_names(script):
     assert _undefined_names(os.path.join(_python_sources()[0], script)) == []
+
+
+def test_lazy_eval_items_equal_the_eager_ones_and_stream_every_user_once(golden_dir):
+    """rerank.LazyEvalItems (shard first, per-item title cache, one batched tokenizer call per chunk) builds exactly the
+    items of build_val_items / build_test_items -- against the reference's golden samples with the FakeTokenizer and
+    against the eager builder with a REAL HF fast tokenizer (sub-word title truncation, batch encoding) -- and
+    stream_token_budget_batches hands every user of a shard to the GPU loop exactly once, in token-budget batches."""
+    from types import SimpleNamespace
+
+    from llamarec_amd import data as D
+    from llamarec_amd.rerank import LazyEvalItems, build_test_items, build_val_items, stream_token_budget_batches
+    from tests.local_tokenizer import build_llama_like_tokenizer
+
+    g = json.load(open(os.path.join(golden_dir, "llm_train_dataset.json")))
+    ev = g["eval_datasets"]
+    titles = {int(k): v for k, v in g["titles"].items()}
+    dataset = {"train": {int(k): v for k, v in ev["train"].items()}, "val": {int(k): v for k, v in ev["val"].items()},
+               "test": {int(k): v for k, v in ev["test"].items()}, "meta": titles}
+    retrieved = {k: ev[k] for k in ("val_users", "val_candidates", "test_users", "test_candidates")}
+    for c in ev["cases"]:
+        args = SimpleNamespace(llm_max_history=c["llm_max_history"], llm_max_title_len=c["llm_max_title_len"],
+                               llm_max_text_len=1536, llm_system_template=None, llm_input_template=None)
+        for split in ("val", "test"):
+            lazy = LazyEvalItems(dataset, retrieved, FakeTokenizer(), args, split=split)
+            got = lazy.build(0, len(lazy))
+            assert len(got) == len(c[split])
+            for a, b in zip(got, c[split]):
+                assert a["input_ids"] == b["input_ids"] and a["attention_mask"] == b["attention_mask"]
+                assert a["labels"] == b["labels"]
+
+    # a bigger fabricated dataset through a real fast tokenizer: titles long enough to be truncated at 6 sub-word tokens
+    tok = build_llama_like_tokenizer()
+    ds = D.synthetic_dataset(num_users=150, num_items=400, seed=3, title_words=7)
+    rng = np.random.default_rng(0)
+    users = sorted(ds["train"].keys())
+    cands = []
+    for u in users:
+        pool = [i for i in rng.choice(400, size=40, replace=False) + 1 if i != ds["test"][u][0]][:19]
+        cc = pool + [ds["test"][u][0]]
+        rng.shuffle(cc)
+        cands.append([int(x) for x in cc])
+    retrieved = {"test_users": users, "test_candidates": cands}
+    args = SimpleNamespace(llm_max_history=20, llm_max_title_len=6, llm_max_text_len=300, llm_system_template=None,
+                           llm_input_template=None)
+    eager = build_test_items(ds, retrieved, tok, args)
+    lazy = LazyEvalItems(ds, retrieved, tok, args, split="test")
+    got = lazy.build(0, len(lazy))
+    assert [a["input_ids"] for a in got] == [b["input_ids"] for b in eager]
+    assert [a["labels"] for a in got] == [b["labels"] for b in eager]
+    assert any(len(b["input_ids"]) == 300 for b in eager)            # left truncation happened somewhere
+    # the length estimate the shards are cut by is close to the real token count (balance, not exactness)
+    args_long = SimpleNamespace(**{**vars(args), "llm_max_text_len": 1536})
+    est = LazyEvalItems(ds, retrieved, tok, args_long, split="test").estimate_lengths().astype(np.float64)
+    real = np.array([len(b["input_ids"]) for b in build_test_items(ds, retrieved, tok, args_long)], np.float64)
+    assert abs(est.sum() / real.sum() - 1.0) < 0.25 and np.corrcoef(est, real)[0, 1] > 0.8, (est[:8], real[:8])
+    # streaming: users [20, 131) in chunks of 16, budget 2000 tokens
+    seen, n_batches = [], 0
+    for seqs, labels in stream_token_budget_batches(lazy, 20, 131, 2000, 300, chunk=16, depth=2):
+        assert sum(len(s) for s in seqs) <= 2000 + 300
+        for s, l in zip(seqs, labels):
+            seen.append((tuple(int(x) for x in s), int(l)))
+        n_batches += 1
+    want = [(tuple(b["input_ids"][-300:]), b["labels"]) for b in eager[20:131]]
+    assert sorted(seen) == sorted(want) and len(seen) == 111 and n_batches < 30

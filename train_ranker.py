@@ -27,7 +27,7 @@ def main(argv=None, export_root=None):
     from llamarec_amd import data as D
     from llamarec_amd.llm import LlamaRanker
     from llamarec_amd import dist as DD
-    from llamarec_amd.rerank import LLMEvaluator, build_test_items, build_val_items
+    from llamarec_amd.rerank import LazyEvalItems, LLMEvaluator, build_val_items
     from llamarec_amd.verb import ManualVerbalizer
 
     args = cfg.parse(argv, model_code="llm")
@@ -90,8 +90,11 @@ def main(argv=None, export_root=None):
         steps = trainer.train()
         print(f"LoRA fine-tuning: {steps} optimizer steps, best {args.rerank_best_metric} = {trainer.best_metric}")
         model = engine.merge_into_base_()       # the scoring path below now serves base + tuned adapter
-    items = build_test_items(dataset, retrieved, tokenizer, args)
-    ev = LLMEvaluator(args, model, items, verbalizer, export_root, batch_size=args.test_batch_size)
+    # lazily built test prompts: users are sharded over the ranks first, each rank tokenises only its own shard, in a
+    # producer thread ahead of its GPU loop (llamarec_amd/rerank.py, LazyEvalItems); --test_batch_size caps the prompts
+    # per prefill only when given explicitly (the evaluation batches by token budget, --eval_token_budget)
+    items = LazyEvalItems(dataset, retrieved, tokenizer, args, split="test")
+    ev = LLMEvaluator(args, model, items, verbalizer, export_root)
     metrics = ev.test(retrieved["test_retrieval"])
     print("Ranking Performance on Subset:", metrics)
     print("Overall Performance of Our Framework:", ev.overall_metrics)
