@@ -23,6 +23,8 @@
 //    aligned to ABSOLUTE positions, so every row executes exactly the instruction sequence of the unshared run.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "llama_kernels.h"
 #include "lr_profile.h"
 
@@ -139,11 +141,23 @@ __device__ __forceinline__ void fa_swap32(float v, float& a, float& b) {
   a = __builtin_bit_cast(float, r0);
   b = __builtin_bit_cast(float, r1);
 }
+// v_max3_f32 on raw MFMA outputs: fmaxf() makes hipcc canonicalise every input first (a v_max_f32 x, x per score);
+// the scores are finite or -inf here, where max is exact whatever the association
+__device__ __forceinline__ float fa_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fa_max2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float fa_max_xor16_32(float v) {
   float a, b;
   fa_swap16(v, a, b);
-  fa_swap32(fmaxf(a, b), a, b);
-  return fmaxf(a, b);
+  fa_swap32(fa_max2(a, b), a, b);
+  return fa_max2(a, b);
 }
 __device__ __forceinline__ float fa_sum_xor16_32(float v) {
   float a, b;
@@ -311,6 +325,20 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     }
   };
 
+  // LDS read addresses: everything lane-dependent is computed ONCE (4 K bases, 8 V bases); stage buffer, key sub-tile
+  // and k-step are compile-time immediates of the ds_read (the key-block loop is unrolled by two so that the stage
+  // buffer is one of them): no vector ALU between the MFMAs for addressing (was ~38 v_add / v_add3 per key block).
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lds = (lds_char*)smem;
+  lds_char *kb_off[4], *vb_off[8];   // pointers, so that the LDS base is added here and not at every read
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kb_off[ks] = lds + (li * 256 + (((ks * 4 + quad) ^ li) << 4));   // row nt*16 + li: (row & 15) = li
+  {
+    const int qp = li >> 2, p4 = li & 3;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) vb_off[dt] = lds + (v_off(quad * 4 + qp, dt * 2 + (p4 >> 1)) + 8 * (p4 & 1));   // + 8192 ks2 + 4096 half
+  }
+
   stage(0, 0);
   // Q must be resident before the loop: otherwise hipcc carries its pending-load state into the loop
   // and waits for the in-loop DMA prefetch (vmcnt is in-order) in front of the first MFMAs.
@@ -321,10 +349,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   __syncthreads();
   FA_STAMP(0)  // prologue: Q fragments + first K/V tile landed
 
-  for (int kb = 0; kb <= kb_last; ++kb) {
-    const char* Ks = smem + (kb & 1) * FA_STAGE_BYTES;
-    const char* Vs = Ks + FA_TILE_BYTES;
-    if (kb < kb_last) stage(kb + 1, (kb + 1) & 1);
+  auto block = [&](const int kb, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr int KS = BUF * FA_STAGE_BYTES, VS = KS + FA_TILE_BYTES;   // LDS byte offsets of this block's K and V tiles
+    if (kb < kb_last) stage(kb + 1, BUF ^ 1);
     FA_STAMP(1)  // DMA issue
 
     if (kb * FA_KB <= wave_q_last && wave_q_last >= P && (!LASTQ || wave == 0)) {  // otherwise every key of the block is masked for this wave
@@ -335,21 +363,16 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
       bf16x8 kf[2][4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int row = nt * 16 + li;
-        kf[0][nt] = *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((quad ^ (row & 15)) << 4));
-      }
+      for (int nt = 0; nt < 4; ++nt) kf[0][nt] = *reinterpret_cast<lds_bf16x8*>(kb_off[0] + (KS + nt * 4096));
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < 3) {
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int row = nt * 16 + li;
-            kf[(ks + 1) & 1][nt] =
-                *reinterpret_cast<const bf16x8*>(Ks + row * 256 + ((((ks + 1) * 4 + quad) ^ (row & 15)) << 4));
-          }
+          for (int nt = 0; nt < 4; ++nt)
+            kf[(ks + 1) & 1][nt] = *reinterpret_cast<lds_bf16x8*>(kb_off[ks + 1] + (KS + nt * 4096));
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -378,12 +401,16 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
             }
           __builtin_amdgcn_sched_barrier(0);
         }
+        mx = fa_max3(st[qt][0][0], st[qt][0][1], st[qt][0][2]);
+        mx = fa_max3(mx, st[qt][0][3], st[qt][1][0]);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][nt][r]);
+        for (int nt = 1; nt < 4; ++nt) {
+          mx = fa_max3(mx, st[qt][nt][1], st[qt][nt][2]);
+          if (nt < 3) mx = fa_max3(mx, st[qt][nt][3], st[qt][nt + 1][0]);
+        }
+        mx = fa_max2(mx, st[qt][3][3]);
         mx = fa_max_xor16_32(mx);
-        const float m_new = fmaxf(m_run[qt], mx * sl2);  // running max in the exp2 domain
+        const float m_new = fa_max2(m_run[qt], mx * sl2);  // running max in the exp2 domain
         const bool grew = m_new > m_run[qt];
         const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
         m_run[qt] = m_new;
@@ -409,17 +436,16 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       if (STAMP) asm volatile("" ::"v"(pa[0][0]), "v"(pa[1][1]));
       FA_STAMP(3)  // softmax
       // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads
-      const int qp = li >> 2, p4 = li & 3;
+      // V^T fragment rows: keys ks2*32 + quad*4 + qp (+16); their swizzle term ((row & 3) << 2 | (row >> 2) & 3) does not
+      // depend on ks2 or the +16, so row0's address differs from vb_off[dt] by the immediate 8192 ks2 (+ 4096)
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-          const int row0 = ks2 * 32 + quad * 4 + qp;
-          const int ch = dt * 2 + (p4 >> 1);
           const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0, ch) + 8 * (p4 & 1)));
+              (__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + ks2 * 8192)));
           const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) short4v*)(Vs + v_off(row0 + 16, ch) + 8 * (p4 & 1)));
+              (__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + ks2 * 8192 + 4096)));
           bf16x8 vf;
           const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
 #pragma unroll
@@ -437,6 +463,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     FA_STAMP(4)  // O^T += V^T P^T
     __syncthreads();  // DMA of block kb+1 landed (vmcnt(0)) and every wave is done with block kb
     FA_STAMP(5)  // barrier + DMA wait
+  };
+  for (int kb = 0; kb <= kb_last; kb += 2) {
+    block(kb, std::integral_constant<int, 0>{});
+    if (kb + 1 <= kb_last) block(kb + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
