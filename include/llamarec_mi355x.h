@@ -306,13 +306,17 @@ int lr_gemm_bf16_nt_ws(const uint16_t* A, const uint16_t* B, uint16_t* C, int32_
 /* The projection GEMM with each of the prefill's fused epilogues (exposed for parity tests and per-shape timing):
  *   epilogue 0 store | 1 residual: C = bf16(bf16(acc) + R), R bf16 [M][N], may alias C | 2 SwiGLU over gate/up rows
  *   interleaved in groups of 16 (lr_llama_pack_gate_up), C is [M][N/2] | 3 rotary embedding on columns
- *   [0, rot_cols) of pair-interleaved q/k rows (lr_llama_pack_qkv), tok_pos int32 [M], rope_cs from lr_rope_table.
+ *   [0, rot_cols) of pair-interleaved q/k rows (lr_llama_pack_qkv), tok_pos int32 [M] (every entry < rope_positions),
+ *   rope_cs / rope_positions = the buffer lr_rope_table filled and its max_positions.
  * These are the epilogues of HF LlamaAttention / LlamaMLP around the Linears of model/llm.py:89-100 (reference). */
 int lr_gemm_bf16_nt_epi(const uint16_t* A, const uint16_t* B, uint16_t* C, const uint16_t* R, int32_t M, int32_t N,
                         int32_t K, int32_t epilogue, int32_t variant, const int32_t* tok_pos, const float* rope_cs,
-                        int32_t head_dim, int32_t rot_cols, void* workspace, size_t workspace_bytes, void* hip_stream);
-/* cs: DEVICE fp32 [max_positions][head_dim/2][2] = (cos, sin) of position * theta^(-2i/head_dim), rounded to bf16 values
- * (HF LlamaRotaryEmbedding casts cos/sin to the activations' dtype). */
+                        int32_t rope_positions, int32_t head_dim, int32_t rot_cols, void* workspace, size_t workspace_bytes,
+                        void* hip_stream);
+/* cs: DEVICE buffer of lr_rope_table_bytes(max_positions, head_dim) bytes: fp32 [max_positions][head_dim/2][2] = (cos, sin)
+ * of position * theta^(-2i/head_dim), rounded to bf16 values (HF LlamaRotaryEmbedding casts cos/sin to the activations'
+ * dtype), followed by the same values packed as bf16 pairs, uint32 [max_positions][head_dim/2] = cos | sin << 16. */
+size_t lr_rope_table_bytes(int32_t max_positions, int32_t head_dim);
 int lr_rope_table(float* cs, int32_t max_positions, int32_t head_dim, float theta, void* hip_stream);
 
 /* Stand-alone varlen causal attention (exposed for parity tests):

@@ -93,6 +93,7 @@ struct LlamaWs {
   u16 *x, *xn, *qkv, *att, *hmid;
   u16 *x_last, *xn_last, *att_last, *h_last, *q_last;  // compact [B][.] buffers of the pruned last layer
   float* splitk;                              // fp32 partial planes of the split-K GEMMs (gemm variant 5)
+  unsigned* rope16;                           // the rope table as packed bf16 (cos | sin << 16) pairs
   int32_t* prefix_bad;                        // device word: a prompt broke the shared-prefix promise (token_meta_kernel)
   bool compact;                               // ws.x_last (not ws.x) holds the final residual rows
   size_t total;
@@ -112,6 +113,7 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.tok_pos = (int32_t*)take(n * 4);
   w.tok_src = (int32_t*)take(n * 4);
   w.rope = (float*)take((size_t)c.max_positions * (c.head_dim / 2) * 2 * sizeof(float));
+  w.rope16 = (unsigned*)take((size_t)c.max_positions * (c.head_dim / 2) * sizeof(unsigned));
   w.rstd = (float*)take(n * sizeof(float));
   w.x = (u16*)take(n * c.hidden_size * 2);
   w.xn = (u16*)take(n * c.hidden_size * 2);
@@ -192,7 +194,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   } while (0)
   RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st, ws.last_pos, ids,
                            ws.prefix_bad));
-  RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st));
+  RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st, ws.rope16));
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->layers[l];
@@ -210,19 +212,19 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       const int pv = (h->gemm_variant == 5 || (h->gemm_variant == 0 && B <= 256)) ? 5 : 1;
       RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
       RUN(lr_launch_gemm(ws.xn, w.wqkv + (size_t)q_w * d, ws.qkv, nullptr, n, kv_w, d, LR_EPI_ROPE, h->gemm_variant, st,
-                         ws.tok_pos, ws.rope, hd, nkv * hd, ws.splitk, LR_SPLITK_WS_BYTES));
+                         ws.tok_pos, ws.rope, hd, nkv * hd, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, ws.rope16));
       RUN(lr_launch_gather_rows(ws.xn, ws.last_rows, B, d, ws.xn_last, st));
       RUN(lr_launch_gemm(ws.xn_last, w.wqkv, ws.q_last, nullptr, B, q_w, d, LR_EPI_ROPE, pv, st, ws.last_pos, ws.rope, hd,
-                         q_w, ws.splitk, LR_SPLITK_WS_BYTES));
+                         q_w, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, ws.rope16));
       RUN(lr_launch_attention_last(ws.qkv, ws.q_last, ws.att_last, ws.seg_start, seg_host, S, n, nh, nkv, hd, st, P));
     } else if (folded) {
       RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
       RUN(lr_launch_gemm(ws.x, h->wqkv_folded[l], ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
-                         ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd));
+                         ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd, ws.rope16));
     } else {
       RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
       RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
-                         ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES));
+                         ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, ws.rope16));
     }
     if (last_pruned) {
       // Only each prompt's LAST token is consumed after the final layer (model/llm.py:131), so the
@@ -378,17 +380,26 @@ extern "C" int lr_gemm_bf16_nt_ws(const uint16_t* A, const uint16_t* B, uint16_t
 
 extern "C" int lr_gemm_bf16_nt_epi(const uint16_t* A, const uint16_t* B, uint16_t* C, const uint16_t* R, int32_t M,
                                    int32_t N, int32_t K, int32_t epilogue, int32_t variant, const int32_t* tok_pos,
-                                   const float* rope_cs, int32_t head_dim, int32_t rot_cols, void* workspace,
-                                   size_t workspace_bytes, void* hip_stream) {
+                                   const float* rope_cs, int32_t rope_positions, int32_t head_dim, int32_t rot_cols,
+                                   void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!A || !B || !C) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_epi: null pointer");
   if (epilogue < LR_EPI_STORE || epilogue > LR_EPI_ROPE) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_epi: epilogue %d", epilogue);
+  // the packed half of lr_rope_table's buffer sits behind the fp32 half
+  const unsigned* cs16 = (rope_cs && rope_positions > 0 && head_dim >= 2)
+                             ? reinterpret_cast<const unsigned*>(rope_cs + (size_t)rope_positions * head_dim) : nullptr;
   return lr_launch_gemm(A, B, C, R, M, N, K, epilogue, variant, (hipStream_t)hip_stream, tok_pos, rope_cs, head_dim,
-                        rot_cols, (float*)workspace, workspace_bytes);
+                        rot_cols, (float*)workspace, workspace_bytes, nullptr, cs16);
+}
+
+extern "C" size_t lr_rope_table_bytes(int32_t max_positions, int32_t head_dim) {
+  if (max_positions < 1 || head_dim < 2) return 0;
+  return (size_t)max_positions * (head_dim / 2) * (2 * sizeof(float) + sizeof(unsigned));
 }
 
 extern "C" int lr_rope_table(float* cs, int32_t max_positions, int32_t head_dim, float theta, void* hip_stream) {
   if (!cs || max_positions < 1 || head_dim < 2) LR_FAIL(LR_EINVAL, "lr_rope_table: bad argument");
-  return lr_launch_rope_table(cs, max_positions, head_dim, theta, (hipStream_t)hip_stream);
+  return lr_launch_rope_table(cs, max_positions, head_dim, theta, (hipStream_t)hip_stream,
+                              reinterpret_cast<unsigned*>(cs + (size_t)max_positions * head_dim));
 }
 
 extern "C" int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,

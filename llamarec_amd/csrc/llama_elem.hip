@@ -199,15 +199,19 @@ int lr_launch_fold_norm(const u16* w, const u16* norm_w, u16* out, size_t rows, 
 }
 
 // ---- RoPE table: cos/sin(pos * theta^(-2i/hd)) rounded to bf16 like HF's bf16 rotary ---------
-__global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, int T, int hd, float theta) {
+// cs16 (optional): the same values packed as bf16 pairs, cos in the low half-word and sin in the high one -- lossless (the
+// fp32 table holds bf16-representable values); the 256-tile GEMM's rotary epilogue stages these 4-byte entries through LDS.
+__global__ void rope_table_kernel(float* cs /*[T][hd/2][2]*/, unsigned* cs16 /*[T][hd/2]*/, int T, int hd, float theta) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int half = hd / 2;
   if (i >= T * half) return;
   int pos = i / half, j = i % half;
   float inv = 1.0f / powf(theta, (float)(2 * j) / (float)hd);
   float ang = (float)pos * inv;
-  cs[2 * i + 0] = bf2f(f2bf(cosf(ang)));
-  cs[2 * i + 1] = bf2f(f2bf(sinf(ang)));
+  const u16 c = f2bf(cosf(ang)), sn = f2bf(sinf(ang));
+  cs[2 * i + 0] = bf2f(c);
+  cs[2 * i + 1] = bf2f(sn);
+  if (cs16) cs16[i] = (unsigned)c | ((unsigned)sn << 16);
 }
 
 // ---- final RMSNorm on each prompt's last token + dot with selected lm_head rows -------------
@@ -301,9 +305,9 @@ int lr_launch_rmsnorm(const u16* x, const u16* w, u16* out, int rows, int d, flo
   return LR_OK;
 }
 
-int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st) {
+int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st, unsigned* cs16) {
   int n = T * (hd / 2);
-  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cs, T, hd, theta);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cs, cs16, T, hd, theta);
   LR_CHECK_LAUNCH("rope_table_kernel");
   return LR_OK;
 }

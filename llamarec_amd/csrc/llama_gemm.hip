@@ -44,6 +44,11 @@ struct RopeArgs {
   // the norm weight multiplied in (lr_fold_norm_bf16), and the accumulator of row m is scaled by rstd[m] =
   // 1 / sqrt(mean(x_m^2) + eps) here:  (x_m * rstd_m * w) . W_j  ==  rstd_m * (x_m . (W_j * w)).  nullptr: no scaling.
   const float* row_scale;
+  // The same table as packed bf16 pairs [max_T][head_dim/2] (cos | sin << 16), or nullptr. With it (head_dim 128, rot_cols a
+  // multiple of 256) the 256-tile kernel stages the tile's 256 x 64 entries through LDS after its K loop: 64 KB of
+  // whole-row DMA instead of 262 KB of 64-byte-per-row register loads (16 rows x 64 B per wave-instruction cost a CU
+  // three times a full-line access: tools/diag/store_rate.hip; the rotary epilogue took 20-24 k cycles of a 186 k-cycle tile).
+  const unsigned* cs16;
 };
 
 // ---- shared epilogue: lane holds 4 consecutive columns of one row ----------------------------
@@ -98,7 +103,7 @@ __device__ __forceinline__ u16x4 epi_value4(floatx4 v, floatx4 up, u16x4 r, cons
 
 template <int EPI>
 __device__ __forceinline__ void epi_store4(floatx4 v, floatx4 up, u16* C, const u16* R, size_t off,
-                                           const RopeArgs& rope = RopeArgs{}, int row = 0, int col = 0,
+                                           const RopeArgs& rope = RopeArgs{nullptr, nullptr, 0, 0, nullptr, nullptr}, int row = 0, int col = 0,
                                            const float* pre_rs = nullptr, const int* pre_pos = nullptr) {
   if (EPI == LR_EPI_PARTIAL) {  // C is the fp32 partial plane of this split
     *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(C) + off) = v;
@@ -479,23 +484,73 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   // Residual: all 16 reads of the lane are requested before the first store. Written load -> use -> store per pair, hipcc
   // keeps that order (R may alias C) and every read then waits, behind vmcnt(0), for the previous pair's store as well.
   // A lane reads exactly the 16 bytes it later writes, so taking the reads first is safe for the in-place call too.
+  // Whole cache lines per wave-instruction. After the swap a lane holds, per 16-row tile, two 16-byte pieces of ITS row:
+  // bytes k*64 + (quad&1)*32 + (quad>>1)*16 of the wave's 128-byte strip, k = 0, 1 -- a store of piece k writes 16 rows x
+  // 64 B, half lines, which a CU moves at 13-15 B/clk against 41-44 B/clk for 8 rows x 128 B (tools/diag/store_rate.hip:
+  // 8.8-9.9 k cycles per 128 KB tile against 3.0-3.2 k; loads 8.6 k against 5.8 k). So lanes li and li ^ 8 of a 16-lane row
+  // trade one piece (DPP row_ror:8): instruction j then carries rows 8 j + (li & 7) in full -- the lower eight lanes hold
+  // bytes 0..63 (k = 0), the upper eight bytes 64..127 (k = 1). The residual is READ in that layout and traded back.
+  const bool lo8 = (lane & 8) == 0;
+  const int hrow = lane & 7;                                            // row of the 8-row half this lane stores / loads
+  const int hcol = (lo8 ? 0 : 32) + (quad & 1) * 16 + (quad >> 1) * 8;  // its first column inside the wave's 64
+  auto trade = [&](u32x4& p0, u32x4& p1) {   // (own row: k = 0, k = 1)  <->  (row hrow: my half, row 8 + hrow: my half)
+    u32x4 z, w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[i] = lo8 ? p1[i] : p0[i];
+      w[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)z[i], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned a_ = lo8 ? p0[i] : w[i], b_ = lo8 ? w[i] : p1[i];
+      p0[i] = a_;
+      p1[i] = b_;
+    }
+  };
   u32x4 rpre[8][2];
   if (EPI == LR_EPI_RESIDUAL) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
-      const int rowc = min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1);
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        rpre[mt][k] = *reinterpret_cast<const u32x4*>(R + (size_t)rowc * ldc + n0 + wn * 64 + k * 32 + (quad & 1) * 16 + (quad >> 1) * 8);
+      for (int j = 0; j < 2; ++j) {
+        const int rowc = min(m0 + wm * 128 + mt * 16 + j * 8 + hrow, M - 1);
+        rpre[mt][j] = *reinterpret_cast<const u32x4*>(R + (size_t)rowc * ldc + n0 + wn * 64 + hcol);
+      }
     }
   }
   // Rotation: the 8 token positions first, then the (cos, sin) pairs of four row groups at a time (16 reads in flight,
   // 64 registers) ahead of their stores -- one exposed latency per half instead of one per read.
   int ppre[8];
-  if (EPI == LR_EPI_ROPE) {
+  // LDS-staged table (see RopeArgs::cs16): wave w fetches rows 32 w .. 32 w + 31 of the tile, 4 rows (1 KiB) per DMA
+  // piece, into the stage buffer the last K tile did not use; the 16-byte chunk a lane FETCHES is XOR-permuted by the
+  // row (chunk ^ (row & 15)) so that the ds_read_b64 of 16 rows x 2 quads below touch 64 different banks.
+  const bool cs_lds = EPI == LR_EPI_ROPE && rope.cs16 != nullptr && rope.head_dim == 128 && (rope.rot_cols & 255) == 0;
+  const bool rot_tile = n0 < rope.rot_cols;          // cs_lds: tile-uniform (rot_cols is a multiple of the tile width)
+  const char* cs_stage = smem + (nkt & 1) * G2_STAGE_BYTES;
+  if (EPI == LR_EPI_ROPE && cs_lds) {
+    if (rot_tile) {
+      int prow[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) prow[j] = rope.tok_pos[min(m0 + (wave * 8 + j) * 4 + (lane >> 4), M - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = (wave * 8 + j) * 4 + (lane >> 4);
+        glds16(reinterpret_cast<const char*>(rope.cs16) + (size_t)prow[j] * 256 + (((lane & 15) ^ (row & 15)) << 4),
+               const_cast<char*>(cs_stage) + (wave * 8 + j) * 1024);
+      }
+      PP_WAIT_VM(0);
+    }
+    PP_BARRIER();
+  } else if (EPI == LR_EPI_ROPE) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) ppre[mt] = rope.tok_pos[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
   }
+  // LDS addresses of this lane's entries: row (wm 128 + mt 16 + li), pairs (wn & 1) 32 + nt 8 + 2 quad, + 1 = 8 bytes at
+  // chunk ((wn & 1) 8 + 2 nt + (quad >> 1)) ^ li; the row tile mt is an immediate (4096 mt)
+  int cs_off[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+    cs_off[nt] = (wm * 128 + (lane & 15)) * 256 + (((((wn & 1) * 8 + 2 * nt + (quad >> 1)) ^ (lane & 15))) << 4) + (quad & 1) * 8;
   float rspre[8];  // folded RMSNorm: the scale of my 8 rows (1 when the norm is not folded)
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) rspre[mt] = 1.0f;
@@ -507,7 +562,17 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   float4 tpre[4][4];
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
-    if (EPI == LR_EPI_ROPE && (mt & 3) == 0) {
+    if (EPI == LR_EPI_ROPE && cs_lds) {
+      if (rot_tile) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const u32x2 e = *reinterpret_cast<const u32x2*>(cs_stage + cs_off[nt] + mt * 4096);
+          tpre[mt & 3][nt] = float4{__builtin_bit_cast(float, e[0] << 16), __builtin_bit_cast(float, e[0] & 0xffff0000u),
+                                    __builtin_bit_cast(float, e[1] << 16), __builtin_bit_cast(float, e[1] & 0xffff0000u)};
+        }
+      }
+    } else if (EPI == LR_EPI_ROPE && (mt & 3) == 0) {
 #pragma unroll
       for (int m2 = 0; m2 < 4; ++m2)
 #pragma unroll
@@ -546,10 +611,11 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
       if (live)
         *reinterpret_cast<u32x4*>(C + (size_t)row * ldc + cbase + (quad & 1) * 16 + (quad >> 1) * 8) = u32x4{a[0], a[1], b[0], b[1]};
     } else {
+      u32x4 outp[2];
+      if (EPI == LR_EPI_RESIDUAL) trade(rpre[mt][0], rpre[mt][1]);   // back to (own row: k = 0, k = 1)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {   // tiles 2k, 2k + 1
         const int cpair = n0 + wn * 64 + k * 32;
-        const size_t wide = (size_t)rowc * ldc + cpair + (quad & 1) * 16 + (quad >> 1) * 8;   // my 8 columns after the swap
         u16x4 ra = u16x4{0, 0, 0, 0}, rb = ra;
         if (EPI == LR_EPI_RESIDUAL) {
           const u32x4 r16 = rpre[mt][k];
@@ -575,7 +641,13 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
           a[w] = sw[0];
           b[w] = sw[1];
         }
-        if (live) *reinterpret_cast<u32x4*>(C + wide) = u32x4{a[0], a[1], b[0], b[1]};
+        outp[k] = u32x4{a[0], a[1], b[0], b[1]};   // my 8 columns of tile pair k after the swap
+      }
+      trade(outp[0], outp[1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int srow = m0 + wm * 128 + mt * 16 + j * 8 + hrow;
+        if (srow < M) *reinterpret_cast<u32x4*>(C + (size_t)srow * ldc + n0 + wn * 64 + hcol) = outp[j];
       }
     }
   }
@@ -719,7 +791,8 @@ extern "C" int lr_debug_gemm_stamps(unsigned long long* out, int n_workgroups) {
 
 int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
                    int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs, int head_dim,
-                   int rot_cols, float* splitk_ws, size_t splitk_ws_bytes, const float* row_scale) {
+                   int rot_cols, float* splitk_ws, size_t splitk_ws_bytes, const float* row_scale,
+                   const unsigned* rope_cs16) {
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
@@ -731,7 +804,7 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
     LR_FAIL(LR_EUNSUPPORTED, "gemm variant 4 needs N%%256==0 and K%%64==0 (N=%d K=%d)", N, K);
   if (epi == LR_EPI_SWIGLU && (N % 32 != 0)) LR_FAIL(LR_EINVAL, "swiglu epilogue needs N%%32==0 (N=%d)", N);
   if (epi == LR_EPI_RESIDUAL && !R) LR_FAIL(LR_EINVAL, "residual epilogue without residual pointer");
-  RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols, row_scale};
+  RopeArgs rope{tok_pos, rope_cs, head_dim, rot_cols, row_scale, rope_cs16};
   if (row_scale && epi != LR_EPI_ROPE && epi != LR_EPI_SWIGLU)
     LR_FAIL(LR_EINVAL, "gemm: a row scale (folded RMSNorm) is only applied by the rope and swiglu epilogues");
   if (epi == LR_EPI_ROPE) {

@@ -44,7 +44,8 @@ int lr_launch_embed(const int32_t* ids, const int32_t* tok_src /*nullptr: identi
                     int vocab, int d, unsigned short* out, int n, hipStream_t st);
 int lr_launch_rmsnorm(const unsigned short* x, const unsigned short* w, unsigned short* out, int rows, int d,
                       float eps, const int32_t* row_map, hipStream_t st);
-int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st);
+int lr_launch_rope_table(float* cs, int T, int hd, float theta, hipStream_t st,
+                         unsigned* cs16 = nullptr /* [T][hd/2] (cos | sin << 16) as bf16 pairs, optional */);
 int lr_launch_head(const unsigned short* x, const int32_t* rows /*[B]; nullptr: x holds one row per prompt*/,
                    const unsigned short* norm_w,
                    const unsigned short* lm_head, const int32_t* class_ids, int B, int C, int d, float eps,
@@ -57,7 +58,9 @@ int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned sh
                    const unsigned short* R, int M, int N, int K, int epi, int variant, hipStream_t st,
                    const int32_t* tok_pos = nullptr, const float* rope_cs = nullptr, int head_dim = 0,
                    int rot_cols = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0,
-                   const float* row_scale = nullptr /* rope / swiglu epilogues: accumulator row m times row_scale[m] */);
+                   const float* row_scale = nullptr /* rope / swiglu epilogues: accumulator row m times row_scale[m] */,
+                   const unsigned* rope_cs16 = nullptr /* the rope table as packed bf16 pairs (lr_launch_rope_table): lets
+                   the 256-tile kernel stage a tile's (cos, sin) rows through LDS instead of 262 KB of half-line loads */);
 // rstd[m] = 1 / sqrt(mean(x[m][:]^2) + eps), fp32 (the statistic of HF's LlamaRMSNorm)
 int lr_launch_rms_rstd(const unsigned short* x, float* rstd, int rows, int d, float eps, hipStream_t st);
 // out[j][k] = bf16(w[j][k] * norm_w[k]): an RMSNorm weight folded into the following projection's [out][in] matrix

@@ -536,3 +536,41 @@ def test_shared_prefix_promise_is_verified_on_the_device():
     assert torch.isfinite(ok).all()
     again = model.prefill_verbalize_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), cu, lab, prefix_len=8)
     assert torch.equal(again, good)                                 # the flag is per call
+
+
+@pytest.mark.parametrize("M", [1000, 517, 256])
+def test_gemm_epilogues_fast_kernel_equals_generic_kernel_bit_for_bit(M):
+    """Every fused epilogue of the 256x256 ping-pong GEMM -- whole-line stores through the DPP row trade, the residual
+    read in that layout, the rotary table staged through LDS as packed bf16 pairs (and the plain float-load path),
+    SwiGLU -- against the generic 64x64 kernel on the same operands, including a ragged last row tile: same fp32 sums
+    (ascending 32-wide MFMA chunks over K), same rounding points -> identical bits."""
+    from llamarec_amd._lib import check, lib, stream_ptr
+
+    L = lib()
+    g = torch.Generator(device="cuda").manual_seed(M)
+    K, N, hd = 512, 768, 128
+    A = (torch.randn(M, K, generator=g, device="cuda")).to(torch.bfloat16)
+    B = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    R = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    T = 700
+    cs = torch.empty(L.lr_rope_table_bytes(T, hd) // 4, dtype=torch.float32, device="cuda")
+    check(L.lr_rope_table(cs.data_ptr(), T, hd, 10000.0, stream_ptr()), "rope table")
+    pos = torch.randint(0, T, (M,), generator=g, device="cuda", dtype=torch.int32)
+
+    def run(epi, variant, rope_positions=T, in_place=False):
+        n_out = N // 2 if epi == 2 else N
+        C = R.clone() if in_place else torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device="cuda")
+        r = C if in_place else R
+        check(L.lr_gemm_bf16_nt_epi(A.data_ptr(), B.data_ptr(), C.data_ptr(), r.data_ptr() if epi == 1 else None, M, N, K, epi,
+                                    variant, pos.data_ptr(), cs.data_ptr(), rope_positions, hd, 512 if epi == 3 else 0, None, 0,
+                                    stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        return C.view(torch.int16)
+
+    for epi in (0, 1, 2, 3):
+        ref = run(epi, 1)
+        fast = run(epi, 4)
+        assert torch.equal(ref, fast), (epi, M)
+    assert torch.equal(run(1, 4, in_place=True), run(1, 1))          # residual in place (R aliases C)
+    assert torch.equal(run(3, 4, rope_positions=0), run(3, 1))       # rotary epilogue without the packed table
+    assert not torch.isnan(run(3, 4).view(torch.bfloat16).float()).any()

@@ -24,7 +24,7 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(0)
     L = lib()
-    cs = torch.empty((4096, 64, 2), dtype=torch.float32, device="cuda")
+    cs = torch.empty(L.lr_rope_table_bytes(4096, 128) // 4, dtype=torch.float32, device="cuda")
     check(L.lr_rope_table(cs.data_ptr(), 4096, 128, 10000.0, stream_ptr()), "rope table")
     # token positions of packed Beauty-like prompts (~740 tokens each)
     pos = torch.cat([torch.arange(740, dtype=torch.int32)] * (M // 740 + 1))[:M].cuda()
@@ -41,7 +41,7 @@ def main():
                 e0.record()
                 for _ in range(3):
                     check(L.lr_gemm_bf16_nt_epi(A.data_ptr(), B.data_ptr(), C.data_ptr(), R.data_ptr() if (R is not None and e == "residual") else None,
-                                                M, N, K, EPI[e], 4, pos.data_ptr(), cs.data_ptr(), 128, 8192 if e == "rope" else 0,
+                                                M, N, K, EPI[e], 4, pos.data_ptr(), cs.data_ptr(), 4096, 128, 8192 if e == "rope" else 0,
                                                 None, 0, stream_ptr()), "gemm")
                 e1.record()
                 torch.cuda.synchronize()

@@ -27,7 +27,7 @@ def main():
     L.lr_debug_gemm_stamps.argtypes = [C.c_void_p, C.c_int]
     g = torch.Generator(device="cuda")
     g.manual_seed(0)
-    cs = torch.empty((4096, 64, 2), dtype=torch.float32, device="cuda")
+    cs = torch.empty(L.lr_rope_table_bytes(4096, 128) // 4, dtype=torch.float32, device="cuda")
     check(L.lr_rope_table(cs.data_ptr(), 4096, 128, 10000.0, stream_ptr()), "rope table")
     pos = torch.cat([torch.arange(740, dtype=torch.int32)] * (M // 740 + 1))[:M].cuda()
     np.set_printoptions(precision=0, suppress=True, linewidth=220)
@@ -41,7 +41,7 @@ def main():
 
         def run():
             check(L.lr_gemm_bf16_nt_epi(A.data_ptr(), B.data_ptr(), Cc.data_ptr(), R.data_ptr() if R is not None else None, M, N, K,
-                                        EPI[epi], 4, pos.data_ptr(), cs.data_ptr(), 128, 8192 if epi == "rope" else 0, None, 0,
+                                        EPI[epi], 4, pos.data_ptr(), cs.data_ptr(), 4096, 128, 8192 if epi == "rope" else 0, None, 0,
                                         stream_ptr()), "gemm")
 
         for _ in range(12):                      # settle the clock under load first
