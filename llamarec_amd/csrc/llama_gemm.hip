@@ -384,27 +384,6 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 
   bf16x8 afr[8], b0x[4], b0y[4], b1[4];
 
-  // Rotary epilogue, LDS-staged table (see RopeArgs::cs16): wave w fetches the (cos, sin) rows of tile rows 32 w .. 32 w + 31,
-  // 4 rows (1 KiB) per DMA piece, into the stage buffer the LAST K tile does not use; the 16-byte chunk a lane FETCHES is
-  // XOR-permuted by the row (chunk ^ (row & 15)) so that the epilogue's ds_read_b64 of 16 rows x 2 quads touch 64
-  // different banks. The fetch is issued INSIDE the last K tile (positions in its LOAD_0, the DMA pieces in LOAD_1, where
-  // a tile without successor issues nothing else) and lands behind that tile's MFMAs; the tile's remaining phases then
-  // skip their vmcnt wait -- nothing they read is in flight any more (the two last tiles drain with vmcnt(0) in LOAD_0).
-  const bool cs_lds = EPI == LR_EPI_ROPE && rope.cs16 != nullptr && rope.head_dim == 128 && (rope.rot_cols & 255) == 0;
-  const bool rot_tile = n0 < rope.rot_cols;          // cs_lds: tile-uniform (rot_cols is a multiple of the tile width)
-  const bool cs_pre = cs_lds && rot_tile && nkt >= 2;
-  const char* cs_stage = smem + (nkt & 1) * G2_STAGE_BYTES;
-  int prow[8];
-#define RB_CS_POS()                                                                                             \
-  _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
-      prow[j] = rope.tok_pos[min(m0 + (wave * 8 + j) * 4 + (lane >> 4), M - 1)];
-#define RB_CS_DMA()                                                                                             \
-  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
-    const int row_ = (wave * 8 + j) * 4 + (lane >> 4);                                                          \
-    glds16(reinterpret_cast<const char*>(rope.cs16) + (size_t)prow[j] * 256 + (((lane & 15) ^ (row_ & 15)) << 4), \
-           const_cast<char*>(cs_stage) + (wave * 8 + j) * 1024);                                                \
-  }
-
 #define RB_LOAD_A(buf, mh)                                                                            \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                  \
     afr[mt] = *reinterpret_cast<const bf16x8*>((buf) + a_base + ((mh)*64 + mt * 16) * 128 + fo0);     \
@@ -482,43 +461,11 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   GEMM_STAMP(1)
   if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
 
-  // The LAST K tile is peeled: it issues no DMA and reads no successor fragments (16 registers the shared tile body must
-  // keep), every byte it reads landed behind the vmcnt(0) of the tile before it, and the rotary epilogue's table rows are
-  // fetched behind its MFMAs (positions in LOAD_0, the eight DMA pieces in LOAD_1; nothing in the tile waits for them).
-#define RB_LAST(kt, b0cur)                                                                            \
-  {                                                                                                   \
-    const char* cur = smem + ((kt)&1) * G2_STAGE_BYTES;                                               \
-    RB_LOAD_A(cur, 0)                                                                                 \
-    if (EPI == LR_EPI_ROPE && cs_pre) { RB_CS_POS() }                                                 \
-    PP_WAIT_VM(0);                                                                                    \
-    PP_BARRIER();                                                                                     \
-    RB_MFMA(b0cur, 0, 0)                                                                              \
-    PP_BARRIER();                                                                                     \
-    RB_LOAD_B(b1, cur, 1)                                                                             \
-    if (EPI == LR_EPI_ROPE && cs_pre) { RB_CS_DMA() }                                                 \
-    PP_BARRIER();                                                                                     \
-    RB_MFMA(b1, 0, 1)                                                                                 \
-    PP_BARRIER();                                                                                     \
-    RB_LOAD_A(cur, 1)                                                                                 \
-    PP_BARRIER();                                                                                     \
-    RB_MFMA(b1, 1, 1)                                                                                 \
-    PP_BARRIER();                                                                                     \
-    PP_BARRIER();                                                                                     \
-    RB_MFMA(b0cur, 1, 0)                                                                              \
-    PP_BARRIER();                                                                                     \
-  }
-  const int nmain = nkt - 1;
-  for (int kt = 0; kt < nmain; kt += 2) {
+  for (int kt = 0; kt < nkt; kt += 2) {
     RB_TILE(kt, b0x, b0y)
-    if (kt + 1 < nmain) RB_TILE(kt + 1, b0y, b0x)
+    if (kt + 1 < nkt) RB_TILE(kt + 1, b0y, b0x)
   }
-  if (nmain & 1) {   // an odd number of tiles before the last: its B(nh0) fragments sit in the second register set
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b0x[i] = b0y[i];
-  }
-  RB_LAST(nkt - 1, b0x)
   if (wm == 0) PP_BARRIER();  // balance group 1's extra barrier
-#undef RB_LAST
   GEMM_STAMP(2)
 #undef RB_DMA
 #undef RB_LOAD_A
@@ -574,17 +521,26 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   // Rotation: the 8 token positions first, then the (cos, sin) pairs of four row groups at a time (16 reads in flight,
   // 64 registers) ahead of their stores -- one exposed latency per half instead of one per read.
   int ppre[8];
+  // LDS-staged table (see RopeArgs::cs16): wave w fetches rows 32 w .. 32 w + 31 of the tile, 4 rows (1 KiB) per DMA
+  // piece, into the stage buffer the last K tile did not use; the 16-byte chunk a lane FETCHES is XOR-permuted by the
+  // row (chunk ^ (row & 15)) so that the ds_read_b64 of 16 rows x 2 quads below touch 64 different banks.
+  const bool cs_lds = EPI == LR_EPI_ROPE && rope.cs16 != nullptr && rope.head_dim == 128 && (rope.rot_cols & 255) == 0;
+  const bool rot_tile = n0 < rope.rot_cols;          // cs_lds: tile-uniform (rot_cols is a multiple of the tile width)
+  const char* cs_stage = smem + (nkt & 1) * G2_STAGE_BYTES;
   if (EPI == LR_EPI_ROPE && cs_lds) {
     if (rot_tile) {
-      if (!cs_pre) {   // a one-K-tile product: nothing was staged inside the loop
-        RB_CS_POS()
-        RB_CS_DMA()
+      int prow[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) prow[j] = rope.tok_pos[min(m0 + (wave * 8 + j) * 4 + (lane >> 4), M - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = (wave * 8 + j) * 4 + (lane >> 4);
+        glds16(reinterpret_cast<const char*>(rope.cs16) + (size_t)prow[j] * 256 + (((lane & 15) ^ (row & 15)) << 4),
+               const_cast<char*>(cs_stage) + (wave * 8 + j) * 1024);
       }
       PP_WAIT_VM(0);
     }
     PP_BARRIER();
-#undef RB_CS_POS
-#undef RB_CS_DMA
   } else if (EPI == LR_EPI_ROPE) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) ppre[mt] = rope.tok_pos[min(m0 + wm * 128 + mt * 16 + (lane & 15), M - 1)];
