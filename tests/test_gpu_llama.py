@@ -574,3 +574,59 @@ def test_gemm_epilogues_fast_kernel_equals_generic_kernel_bit_for_bit(M):
     assert torch.equal(run(1, 4, in_place=True), run(1, 1))          # residual in place (R aliases C)
     assert torch.equal(run(3, 4, rope_positions=0), run(3, 1))       # rotary epilogue without the packed table
     assert not torch.isnan(run(3, 4).view(torch.bfloat16).float()).any()
+
+
+def test_attention_online_softmax_with_forced_maximum_jumps():
+    """The online softmax rescales O only when some row's running maximum moved (`__any(grew)`), a data-dependent
+    branch that bounded random data exercises in the first blocks only (cdna_hip_programming.md, rule 26). Inputs that
+    force it late and hard: keys far into the prompt that are large multiples of some queries, so a block's maximum
+    jumps by 2^8 .. 2^60 over the running one at chosen off-diagonal blocks, for some rows of a tile only; small jumps;
+    a jump in the very first and in a diagonal block. Full-tensor comparison with a float64 reference; every output row
+    must stay finite and within bf16 rounding of it. (Round 3 built a deferred-maximum variant of the kernel -- exp2
+    against the stale maximum, interleaved with the score MFMAs, exact redo past 2^8 -- which this test was written
+    for; it measured 484-492 against 489-495 TF/s in a same-box A/B and was not kept: DESIGN.md section 4.)"""
+    nh = nkv = 2
+    hd = 128
+    lens = [700, 333]
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    rng = np.random.default_rng(3)
+    n = int(cu[-1])
+    qkv = (rng.standard_normal((n, 3 * nh * hd)) * 0.3).astype(np.float32)
+    q = qkv[:, : nh * hd].reshape(n, nh, hd)
+    k = qkv[:, nh * hd: 2 * nh * hd].reshape(n, nh, hd)
+    # (key row, queries whose direction it copies, gain): block = key // 64; rows of tiles 3..5 see key 200 off the diagonal
+    spikes = [(200, [450, 460, 699], 9.0), (330, [600, 601], 25.0), (70, [500], 3.0), (5, [40, 300], 12.0),
+              (640, [650, 690], 14.0), (700 + 100, [700 + 250, 700 + 332], 20.0)]
+    for key, qs, gain in spikes:
+        for h in range(nh):
+            k[key, h] = gain * np.mean([q[j, h] for j in qs], axis=0)
+    qkv = bf16_round(qkv)
+    got = attention(qkv, cu, nh, nkv, hd, 2)
+    # float64 reference with bf16 probabilities (the kernel's rounding point)
+    ref = np.zeros((n, nh * hd))
+    qq = qkv[:, : nh * hd].reshape(n, nh, hd).astype(np.float64)
+    kk = qkv[:, nh * hd: 2 * nh * hd].reshape(n, nh, hd).astype(np.float64)
+    vv = qkv[:, 2 * nh * hd:].reshape(n, nh, hd).astype(np.float64)
+    jumps = 0
+    for b in range(len(lens)):
+        s, e = cu[b], cu[b + 1]
+        T = e - s
+        mask = np.tril(np.ones((T, T), bool))
+        for h in range(nh):
+            sc = (qq[s:e, h] @ kk[s:e, h].T) / np.sqrt(hd)
+            sc = np.where(mask, sc, -np.inf)
+            # how far a later 64-key block's maximum exceeds everything before it (log2 domain), per row
+            for blk in range(1, (T + 63) // 64):
+                before = sc[:, : blk * 64].max(-1)
+                here = sc[:, blk * 64: (blk + 1) * 64].max(-1)
+                jumps += int((((here - before) * 1.4426950408889634) > 8.0).sum())
+            p = np.exp(sc - sc.max(-1, keepdims=True))
+            ref[s:e, h * hd:(h + 1) * hd] = (p @ vv[s:e, h]) / p.sum(-1, keepdims=True)
+    assert jumps > 10                                   # the redo branch is really exercised
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    scale = np.abs(ref).max()
+    assert err.max() < 2.0e-2 * max(1.0, scale), (err.max(), scale)
+    # and the generic kernel (plain online softmax) agrees on the same input
+    gen = attention(qkv, cu, nh, nkv, hd, 1)
+    assert np.abs(gen - ref).max() < 2.0e-2 * max(1.0, scale)
