@@ -495,9 +495,10 @@ struct BoundParams {
   int n_rows, n_tiles;
   const float* q;               // [B][64]
   int B;
-  float* tmax;                  // [B][ld]
-  int ld;                       // n_tiles rounded up to 4
-  int tiles_per_chunk;          // multiple of 4
+  float* tmax;                  // [B][ld]: maxima of GROUPS of 2^gshift consecutive tiles
+  int ld;                       // number of groups rounded up to 4
+  int tiles_per_chunk;          // multiple of max(4, 2^gshift)
+  int gshift;                   // 0: one maximum per tile (catalogs up to 65 536 items); >= 2: per 4, 8, 16 .. tiles
 };
 
 __global__ __launch_bounds__(256) void item_bound_kernel(BoundParams p) {
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(256) void item_bound_kernel(BoundParams p) {
     }
   }
   const tk_bf16x8* frag = reinterpret_cast<const tk_bf16x8*>(p.emb16) + lane;
+  float gm[2] = {-__builtin_inff(), -__builtin_inff()};   // running maximum of the current tile group (gshift >= 2)
   for (int t4 = tile_begin; t4 < tile_end; t4 += 4) {
     float m4[2][4];
 #pragma unroll
@@ -556,14 +558,31 @@ __global__ __launch_bounds__(256) void item_bound_kernel(BoundParams p) {
         m4[c][u] = fmaxf(m, __shfl_xor(m, 32, 64));   // the other lane half holds the tile's other 16 items
       }
     }
+    if (p.gshift == 0) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-      if (user[c] < p.B && half == 0)
-        *reinterpret_cast<float4*>(p.tmax + (size_t)user[c] * p.ld + t4) = make_float4(m4[c][0], m4[c][1], m4[c][2], m4[c][3]);
+      for (int c = 0; c < 2; ++c)
+        if (user[c] < p.B && half == 0)
+          *reinterpret_cast<float4*>(p.tmax + (size_t)user[c] * p.ld + t4) = make_float4(m4[c][0], m4[c][1], m4[c][2], m4[c][3]);
+    } else {   // groups of 2^gshift >= 4 tiles (chunks start on group boundaries): one maximum per group
+      const bool last_of_group = (((t4 + 4) >> p.gshift) != (t4 >> p.gshift)) || t4 + 4 >= tile_end;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        gm[c] = fmaxf(gm[c], fmaxf(fmaxf(m4[c][0], m4[c][1]), fmaxf(m4[c][2], m4[c][3])));
+        if (last_of_group) {
+          if (user[c] < p.B && half == 0) p.tmax[(size_t)user[c] * p.ld + (t4 >> p.gshift)] = gm[c];
+          gm[c] = -__builtin_inff();
+        }
+      }
+    }
   }
 }
 
-#define TK_BOUND_MAX_TILES 2048  // 32 tile maxima per lane in bound_select_kernel (catalogs up to 65 536 items)
+#define TK_BOUND_MAX_TILES 2048  // 32 maxima per lane in bound_select_kernel: one per tile for catalogs up to 65 536 items,
+                                 // one per group of 2^gshift tiles beyond (bound_group_shift): the R-th largest GROUP maximum
+                                 // still certifies R different items at or above it, so the bound's proof is unchanged; a
+                                 // group of 512 items at rank R of 1 954 (1 M items, R = 251) sits at the same item quantile
+                                 // (2.7e-4, ~270 items + the 2 delta band) as a 32-item tile at the same rank fraction
+#define TK_BOUND_MAX_GSHIFT 6
 
 // One wave per user: T[user] = (R-th largest of tmax[user][0..n_tiles)) - delta, R = K + masked ids; -inf if there are
 // fewer than R tiles (no bound: the exact pass then starts from -inf as it does without the pre-pass).
@@ -635,7 +654,7 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const float* tmax, in
 // those EXACTLY -- lr_item_score's fmaf chain, the bits of the oracle and of item_topk_kernel -- drops masked ids and
 // ranks them. If any user's list overflows TK_CAND_CAP (degenerate data: thousands of near-equal scores) a device flag
 // turns on the exact full pass (item_topk_kernel + merge, launched behind it with run_flag) for the whole call.
-#define TK_CAND_CAP 512  // candidate slots per user
+#define TK_CAND_CAP 1024  // candidate slots per user (1 M items: ~270 above the bound + ~40 % in the 2 delta band)
 
 struct CandParams {
   const unsigned short* emb16;
@@ -1069,17 +1088,29 @@ static size_t partial_bytes_max(int B, int K) {
 #define TK_BOUND_MIN_TILES 64
 // ... and only where EVERY user is sure to get a bound: rank R = K + masked ids <= K + L + 1 must not exceed the tile count
 // (ML-100k: L = 200 against 115 tiles -- its users keep the exact full pass)
+// tiles per maximum = 2^shift: the smallest shift (0, or >= 2 so that a group is whole float4 iterations of the kernel)
+// that leaves at most TK_BOUND_MAX_TILES maxima per user; -1: the catalog is beyond 2^TK_BOUND_MAX_GSHIFT x that
+static int bound_group_shift(int n_tiles) {
+  int gs = 0;
+  while (((n_tiles + (1 << gs) - 1) >> gs) > TK_BOUND_MAX_TILES) ++gs;
+  if (gs == 1) gs = 2;
+  return gs <= TK_BOUND_MAX_GSHIFT ? gs : -1;
+}
+static int bound_groups(int n_tiles) {
+  const int gs = bound_group_shift(n_tiles);
+  return gs < 0 ? 0 : (n_tiles + (1 << gs) - 1) >> gs;
+}
 static bool bound_enabled(int n_tiles, int K, int L) {
   static int env = -1;
   if (env < 0) {
     const char* e = getenv("LR_TOPK_BOUND");
     env = (e && e[0] == '0') ? 0 : 1;
   }
-  return env && n_tiles >= TK_BOUND_MIN_TILES && n_tiles <= TK_BOUND_MAX_TILES && K + L + 1 <= n_tiles;
+  return env && n_tiles >= TK_BOUND_MIN_TILES && bound_group_shift(n_tiles) >= 0 && K + L + 1 <= bound_groups(n_tiles);
 }
 // tmax [B][ld] | thresh [B] | cand_thresh [B] | cand_count [B] + overflow flag | cand [B][TK_CAND_CAP]
 static size_t bound_bytes(int B, int n_tiles) {
-  const size_t ld = lr_align_up((size_t)n_tiles, 4);
+  const size_t ld = lr_align_up((size_t)bound_groups(n_tiles), 4);
   return lr_align_up((size_t)B * ld * sizeof(float), 256) + 2 * lr_align_up((size_t)B * sizeof(float), 256) +
          lr_align_up(((size_t)B + 1) * sizeof(int), 256) + lr_align_up((size_t)B * TK_CAND_CAP * sizeof(int32_t), 256);
 }
@@ -1088,7 +1119,7 @@ static size_t bound_bytes(int B, int n_tiles) {
 // later call with a smaller K or L can satisfy when the sizing call did not -- so its scratch is included whenever the
 // catalog's tile count is in the pre-pass's range, whatever K and L (the size is monotone in B, K and L).
 size_t lr_topk_workspace_bytes(int B, int K, int L, int n_tiles) {
-  const bool in_range = n_tiles >= TK_BOUND_MIN_TILES && n_tiles <= TK_BOUND_MAX_TILES;
+  const bool in_range = n_tiles >= TK_BOUND_MIN_TILES && bound_group_shift(n_tiles) >= 0;
   return partial_bytes_max(B, K) + lr_align_up((size_t)B * (L > 0 ? L : 1) * sizeof(int32_t), 256) +
          (in_range ? bound_bytes(B, n_tiles) : 0);
 }
@@ -1143,7 +1174,9 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     bp.n_tiles = p.n_tiles;
     bp.q = q;
     bp.B = B;
-    bp.ld = (int)lr_align_up((size_t)p.n_tiles, 4);
+    bp.gshift = bound_group_shift(p.n_tiles);
+    const int n_groups = bound_groups(p.n_tiles);
+    bp.ld = (int)lr_align_up((size_t)n_groups, 4);
     char* bw = reinterpret_cast<char*>(ws) + need_partial + need_hist;
     bp.tmax = reinterpret_cast<float*>(bw);
     bw += lr_align_up((size_t)B * bp.ld * sizeof(float), 256);
@@ -1157,17 +1190,18 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     int32_t* cand = reinterpret_cast<int32_t*>(bw);
     const int n_ut = (B + TK_BUSERS - 1) / TK_BUSERS;
     int chunks = (2048 + n_ut - 1) / n_ut;                 // ~8 light workgroups per CU
-    const int groups = bp.ld / 4;
-    if (chunks > groups) chunks = groups;
-    bp.tiles_per_chunk = 4 * ((groups + chunks - 1) / chunks);
+    const int unit = bp.gshift > 2 ? (1 << bp.gshift) : 4;   // a chunk is whole float4 iterations AND whole tile groups
+    const int units = (p.n_tiles + unit - 1) / unit;
+    if (chunks > units) chunks = units;
+    bp.tiles_per_chunk = unit * ((units + chunks - 1) / chunks);
     chunks = (p.n_tiles + bp.tiles_per_chunk - 1) / bp.tiles_per_chunk;
     hipLaunchKernelGGL(item_bound_kernel, dim3(chunks, n_ut), dim3(256), 0, st, bp);
     LR_CHECK_LAUNCH("item_bound_kernel");
 #define TK_SELECT(NS_)                                                                                               \
-  hipLaunchKernelGGL(bound_select_kernel<NS_>, dim3((B + 3) / 4), dim3(256), 0, st, bp.tmax, bp.ld, p.n_tiles, q, ids, L, \
+  hipLaunchKernelGGL(bound_select_kernel<NS_>, dim3((B + 3) / 4), dim3(256), 0, st, bp.tmax, bp.ld, n_groups, q, ids, L, \
                      p.n_rows, p.exclude, B, K, h->img + h->lay.item_stats, thresh, cand_thresh, cand_count, overflow_flag)
-    if (p.n_tiles <= 128) TK_SELECT(2);
-    else if (p.n_tiles <= 512) TK_SELECT(8);
+    if (n_groups <= 128) TK_SELECT(2);
+    else if (n_groups <= 512) TK_SELECT(8);
     else TK_SELECT(TK_BOUND_MAX_TILES / 64);
 #undef TK_SELECT
     LR_CHECK_LAUNCH("bound_select_kernel");

@@ -176,9 +176,45 @@ def test_full_size_catalog_properties():
     assert torch.equal(alone_i[0], i50[7]) and torch.equal(alone_s[0], s50[7])
     half_i, _ = model.retrieve_topk(ids[100:229], 50, True)
     assert torch.equal(half_i, i50[100:229])
-    # and the oracle on two users (about a second each on the CPU)
-    oi, osc = O.LruOracle(sd).retrieve_topk(hist[[3, 211]], 50, True)
-    assert np.array_equal(oi, i50n[[3, 211]]) and np.array_equal(osc, s50n[[3, 211]])
+    # and the oracle on four users (about a second each on the CPU): since round 3 the 1 M-item catalog takes the bf16
+    # bound -> candidates -> exact rescoring path with one maximum per GROUP of 16 tiles (lru_topk.hip, bound_group_shift)
+    pick = [3, 211, 77, 298]
+    oi, osc = O.LruOracle(sd).retrieve_topk(hist[pick], 50, True)
+    assert np.array_equal(oi, i50n[pick]) and np.array_equal(osc, s50n[pick])
+
+
+@pytest.mark.parametrize("V,L", [(100_000, 50), (70_003, 200), (262_144, 20)])
+def test_grouped_bound_catalogs_vs_oracle(V, L):
+    """Catalogs beyond 65 536 items (2 048 tiles) keep one approximate maximum per group of 4 / 8 / 16 tiles; the proof of
+    the bound is unchanged (the R-th largest GROUP maximum certifies R different items at or above it), so the ordered
+    top-50 and its score bits must equal the C oracle's for every user: 3 125 tiles -> groups of 4 (the last group
+    ragged), 2 188 -> groups of 4 with L = 200 masked ids, 8 193 tiles -> groups of 8 with one tile in the last group.
+    Includes users whose whole history sits in their own top-50 and a block of exactly tied items."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from oracle import lru_oracle as O
+
+    B = 96
+    rng = np.random.default_rng(V)
+    sd = init_lru_state_dict(V, seed=V % 1000)
+    ids = np.zeros((B, L), np.int64)
+    for b in range(B):
+        n = int(rng.integers(1, L + 1))
+        ids[b, L - n:] = rng.choice(V, size=n, replace=False) + 1
+    model = LRURec.from_state_dict(sd)
+    orc = O.LruOracle(sd)
+    first, _ = orc.retrieve_topk(ids, 50, False)
+    for b in range(0, B, 7):                         # history = the user's own unmasked top-(up to L) items
+        m = min(L, 50)
+        ids[b] = 0
+        ids[b, L - m:] = first[b, :m]
+    got_i, got_s = model.retrieve_topk(torch.from_numpy(ids).cuda(), 50, True)
+    oi, osc = orc.retrieve_topk(ids, 50, True)
+    assert np.array_equal(got_i.cpu().numpy(), oi)
+    assert np.array_equal(got_s.cpu().numpy(), osc)
+    # validation mode (no masking) and a small K through the same path
+    got_i, got_s = model.retrieve_topk(torch.from_numpy(ids).cuda(), 7, False)
+    oi, osc = orc.retrieve_topk(ids, 7, False)
+    assert np.array_equal(got_i.cpu().numpy(), oi) and np.array_equal(got_s.cpu().numpy(), osc)
 
 
 @pytest.mark.parametrize("variant", ["norms_and_bias", "history_is_the_top", "tie_blocks", "all_equal", "no_exclude_k7"])
