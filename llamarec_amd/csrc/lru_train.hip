@@ -138,103 +138,158 @@ struct lr_lru_train {
 //   A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
 // 64 x 64 tile, BK = 32, 4 waves (2 x 2) of one 32 x 32 MFMA block each.
 // =============================================================================================
-#define TG_BM 64
-#define TG_BN 64
 #define TG_BK 32
-#define TG_LD 68
 
 // gridDim.z > 1 splits K: every split ADDS its partial product with fp32 atomics (C must hold the value to
 // accumulate onto, e.g. zero). rowsum (optional): rowsum[m] += sum_k A(m,k), taken from the A tiles by the
 // workgroups of column block 0 -- the bias gradient that goes with a weight gradient dW = dY^T X.
+// Tile BM x BN (64 or 128 each), 4 waves (2 x 2) of (BM/64) x (BN/64) MFMA blocks of 32 x 32: the three V-sized products
+// of a step (scores, d hidden, d table: 4.95 GFLOP each on Beauty = 31 us at the f32 MFMA peak) run on 128-row tiles --
+// on 64 x 64 a K step is 16 MFMAs per wave between two barriers and 16 LDS stores per thread, and they took 82-110 us.
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, long long sam, long long sak,
                                                          const float* __restrict__ B, long long sbk, long long sbn,
                                                          float* C, long long ldc, const float* bias, int M, int N,
                                                          int K, int accumulate, float* rowsum) {
-  __shared__ float As[TG_BK][TG_LD];
-  __shared__ float Bs[TG_BK][TG_LD];
+  constexpr int MI = BM / 64, NI = BN / 64, LDA = BM + 4, LDB = BN + 4;
+  constexpr int NA = BM * TG_BK / 256, NB = BN * TG_BK / 256;   // tile elements per thread
+  __shared__ float As[TG_BK][LDA];
+  __shared__ float Bs[TG_BK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
-  floatx16 acc;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  floatx16 acc[MI][NI];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
   const int ksteps = (K + TG_BK - 1) / TG_BK;
   const int ks0 = (int)((long long)blockIdx.z * ksteps / gridDim.z), ks1 = (int)((long long)(blockIdx.z + 1) * ksteps / gridDim.z);
   const bool want_rowsum = rowsum != nullptr && blockIdx.x == 0;
-  float rs = 0.f;
+  float rs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) rs[i] = 0.f;
   // register double buffer: the global loads of K step k+1 are issued before the MFMAs of step k
-  float va[8], vb[8];
+  float va[NA], vb[NB];
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
-      {
-        const int kk = a_kfast ? (e & 31) : (e >> 6), mm = a_kfast ? (e >> 5) : (e & 63);
-        const int gm = m0 + mm, gk = k0 + kk;
-        va[i] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
-      }
-      {
-        const int kk = b_kfast ? (e & 31) : (e >> 6), nn = b_kfast ? (e >> 5) : (e & 63);
-        const int gn = n0 + nn, gk = k0 + kk;
-        vb[i] = (gn < N && gk < K) ? B[gk * sbk + gn * sbn] : 0.f;
-      }
+      const int kk = a_kfast ? (e & 31) : (e / BM), mm = a_kfast ? (e >> 5) : (e % BM);
+      const int gm = m0 + mm, gk = k0 + kk;
+      va[i] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + 256 * i;
+      const int kk = b_kfast ? (e & 31) : (e / BN), nn = b_kfast ? (e >> 5) : (e % BN);
+      const int gn = n0 + nn, gk = k0 + kk;
+      vb[i] = (gn < N && gk < K) ? B[gk * sbk + gn * sbn] : 0.f;
     }
   };
   if (ks0 < ks1) load_tile(ks0 * TG_BK);
   for (int k0 = ks0 * TG_BK; k0 < ks1 * TG_BK; k0 += TG_BK) {
     __syncthreads();  // previous tile consumed
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
-      As[a_kfast ? (e & 31) : (e >> 6)][a_kfast ? (e >> 5) : (e & 63)] = va[i];
-      Bs[b_kfast ? (e & 31) : (e >> 6)][b_kfast ? (e >> 5) : (e & 63)] = vb[i];
+      As[a_kfast ? (e & 31) : (e / BM)][a_kfast ? (e >> 5) : (e % BM)] = va[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + 256 * i;
+      Bs[b_kfast ? (e & 31) : (e / BN)][b_kfast ? (e >> 5) : (e % BN)] = vb[i];
     }
     __syncthreads();
     if (k0 + TG_BK < ks1 * TG_BK) load_tile(k0 + TG_BK);
-    if (want_rowsum && tid < TG_BM) {
+    if (want_rowsum) {   // thread = (row tid & 63 (+ 64 i), k quarter tid >> 6): 8 independent LDS reads per K step and row.
+                         // (One thread per row walking all 32 k of the step was a chain of 32 dependent reads, ~2 us per K
+                         // step, with the other three waves parked at the next barrier: the eight weight-gradient
+                         // products of a step took 22 us each for 105 MFLOP.)
 #pragma unroll
-      for (int kk = 0; kk < TG_BK; ++kk) rs += As[kk][tid];
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int kk = 0; kk < TG_BK / 4; ++kk) rs[i] += As[(tid >> 6) * (TG_BK / 4) + kk][(tid & 63) + 64 * i];
     }
 #pragma unroll
     for (int s = 0; s < TG_BK / 2; ++s) {
-      const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = As[2 * s + (lane >> 5)][wm * (BM / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Bs[2 * s + (lane >> 5)][wn * (BN / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  if (want_rowsum && tid < TG_BM && m0 + tid < M) atomicAdd(rowsum + m0 + tid, rs);
-  const int col = n0 + wn * 32 + (lane & 31);
-  if (col < N) {
+  if (want_rowsum) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      if (m0 + (tid & 63) + 64 * i < M) atomicAdd(rowsum + m0 + (tid & 63) + 64 * i, rs[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    if (col >= N) continue;
     const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M) {
-        float v = acc[r] + bv;
-        float* c = C + row * ldc + col;
-        if (gridDim.z > 1) atomicAdd(c, v);
-        else *c = accumulate ? (*c + v) : v;
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          float* c = C + row * ldc + col;
+          if (gridDim.z > 1) atomicAdd(c, v);
+          else *c = accumulate ? (*c + v) : v;
+        }
       }
-    }
   }
 }
 
 // accumulate: 0 = overwrite, 1 = add to C. split_ok: the caller guarantees that C already holds the value to add to
 // (zero for a fresh result), so K may be split over workgroups with atomic adds when the tiles alone are too few.
+// Tile: the largest of 128 x 128, 128 x 64, 64 x 64 that still gives the launch >= 512 workgroups (K splits counted
+// where they are allowed) -- the V-sized products; everything else stays on 64 x 64 (a 3200 x 256 x 64 linear has 200
+// tiles of 64 x 64 and would have 50 of 128 x 128).
+template <int BM, int BN>
+static void tr_gemm_launch(dim3 grid, hipStream_t st, const float* A, long long sam, long long sak, const float* B,
+                           long long sbk, long long sbn, float* C, long long ldc, const float* bias, int M, int N, int K,
+                           int accumulate, float* rowsum) {
+  hipLaunchKernelGGL((train_gemm_kernel<BM, BN>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K,
+                     accumulate, rowsum);
+}
 static int tr_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
                    long long ldc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st,
                    bool split_ok = false, float* rowsum = nullptr) {
   if (M <= 0 || N <= 0) return LR_OK;
-  dim3 grid((N + TG_BN - 1) / TG_BN, (M + TG_BM - 1) / TG_BM, 1);
-  if (split_ok) {
-    const int tiles = grid.x * grid.y, ksteps = (K + TG_BK - 1) / TG_BK;
-    int S = 1024 / tiles;          // ~4 workgroups per CU
+  const int ksteps = (K + TG_BK - 1) / TG_BK;
+  auto splits = [&](int tiles) {
+    if (!split_ok) return 1;
+    int S = 1024 / tiles;                // ~4 workgroups per CU
     if (S > ksteps / 8) S = ksteps / 8;  // >= 8 K steps per split
-    if (S > 1) grid.z = S;
+    return S > 1 ? S : 1;
+  };
+  int bm = 64, bn = 64;
+  const int cand[2][2] = {{128, 128}, {128, 64}};
+  for (int c = 0; c < 2; ++c) {
+    const int tiles = ((M + cand[c][0] - 1) / cand[c][0]) * ((N + cand[c][1] - 1) / cand[c][1]);
+    if (N > cand[c][1] / 2 && tiles * splits(tiles) >= 512) {
+      bm = cand[c][0];
+      bn = cand[c][1];
+      break;
+    }
   }
-  hipLaunchKernelGGL(train_gemm_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K,
-                     accumulate, rowsum);
+  dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, 1);
+  grid.z = splits(grid.x * grid.y);
+  if (bm == 128 && bn == 128) tr_gemm_launch<128, 128>(grid, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, accumulate, rowsum);
+  else if (bm == 128) tr_gemm_launch<128, 64>(grid, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, accumulate, rowsum);
+  else tr_gemm_launch<64, 64>(grid, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, accumulate, rowsum);
   LR_CHECK_LAUNCH("train_gemm_kernel");
   return LR_OK;
 }
