@@ -371,8 +371,12 @@ __global__ __launch_bounds__(256) void tr_res_ln_fwd(const float* o, const float
 // LN backward for y = LN(e): de (pre-LN gradient); dw/db: each wave sums its 8 rows in registers, the workgroup
 // adds once per column (32 rows per workgroup keeps the atomics on the 64 shared addresses few)
 #define TR_LNB_ROWS 32
+// res (optional) / seedp / site / p: the two consumers of a block's pre-LN gradient -- the residual path takes it as it is
+// (res, may alias dy: a lane reads dy[i] before it writes res[i]), the branch behind it through its dropout mask (de);
+// one kernel instead of LN backward + copy + dropout backward.
 __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* w,
-                                                 float* de, float* dw, float* db, int R) {
+                                                 float* de, float* dw, float* db, int R, float* res = nullptr,
+                                                 const unsigned long long* seedp = nullptr, unsigned site = 0, float p = 0.f) {
   __shared__ float sw[4][64], sb[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float wl = w[lane];
@@ -388,7 +392,13 @@ __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* x
       const float dxh = g * wl;
       const float m1 = tr_wave_sum(dxh) * (1.0f / 64);
       const float m2 = tr_wave_sum(dxh * xh) * (1.0f / 64);
-      de[i] = rstd[row] * (dxh - m1 - xh * m2);
+      const float d = rstd[row] * (dxh - m1 - xh * m2);
+      if (res) {
+        res[i] = d;
+        de[i] = d * tr_drop_scale(*seedp, site, i, p);
+      } else {
+        de[i] = d;
+      }
     }
   }
   sw[wave][lane] = gw;
@@ -1004,12 +1014,10 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     const float* xin = b ? ws.blk[b - 1].xout : ws.x0;
     float* dz0 = ws.d64a;
     // LN2: dx -> dz0 (gradient of W2 g + b2 (dropped) + y)
+    // dy (residual branch, written back into dx) = the LN gradient; the W2 branch sees dropout(that) in dz0
     hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, W.xhat2, W.rstd2, P + o.ln2_w, dz0, G + o.ln2_w,
-                       G + o.ln2_b, R);
+                       G + o.ln2_b, R, dx, seed, 12u + 4u * b, pd);
     LR_CHECK_LAUNCH("tr_ln_bwd");
-    // dy (residual branch) = dz0; the W2 branch sees dropout(dz0)
-    TR_EW(tr_copy_kernel, (size_t)R * 64, dx, dz0, (size_t)R * 64);  // dx now = dy partial
-    if (pd > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dz0, (size_t)R * 64, seed, 12u + 4u * b, pd);
     TR_RUN(tr_linear_bwd_weight(dz0, W.g, G + o.w2, G + o.b2, R, 64, 256, st));
     TR_RUN(tr_linear_bwd_data(dz0, P + o.w2, ws.d256, R, 64, 256, 0, st));  // d g
     TR_EW(tr_gelu_bwd, (size_t)R * 256, W.a, ws.d256, (size_t)R * 256, seed, 11u + 4u * b, pd);  // -> d a
@@ -1018,10 +1026,8 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     // LN1: dy -> dy0 (gradient of dropout(o) + x)
     float* dy0 = ws.d64a;
     hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, W.xhat1, W.rstd1, P + o.ln1_w, dy0, G + o.ln1_w,
-                       G + o.ln1_b, R);
+                       G + o.ln1_b, R, dx, seed, 10u + 4u * b, pa);   // residual: dx_in = the LN gradient + ...; branch: dropout(it)
     LR_CHECK_LAUNCH("tr_ln_bwd");
-    TR_EW(tr_copy_kernel, (size_t)R * 64, dx, dy0, (size_t)R * 64);  // residual: dx_in = dy0 + ...
-    if (pa > 0.f) TR_EW(tr_drop_bwd, (size_t)R * 64, dy0, (size_t)R * 64, seed, 10u + 4u * b, pa);
     // out_proj (derived real form [64][256] over (Re h | Im h))
     TR_RUN(tr_linear_bwd_weight(dy0, W.h, D + W.d.dwo, D + W.d.dbo, R, 64, 256, st));
     TR_RUN(tr_linear_bwd_data(dy0, D + W.d.wo, ws.d256, R, 64, 256, 0, st));  // g_t = direct gradient of h_t
