@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
     }
   }
   if (want_rowsum) {
@@ -232,21 +232,40 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
     for (int i = 0; i < MI; ++i)
       if (m0 + (tid & 63) + 64 * i < M) atomicAdd(rowsum + m0 + (tid & 63) + 64 * i, rs[i]);
   }
+  // Operands are swapped in the MFMA (D = B_frag x A_frag; the same products summed in the same k order, so the same
+  // bits): a lane then owns ONE row (lane & 31) and, per group g, 4 CONSECUTIVE columns 8 g + 4 (lane >> 5) .. + 3 of each
+  // 32 x 32 block -- 16-byte stores. With one column per lane the score product's 155 MB of logits left through 64
+  // four-byte stores per lane (110-127 us for 4.95 GFLOP).
+  const bool vec_ok = (ldc & 3) == 0 && (reinterpret_cast<size_t>(C) & 15) == 0;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-    if (col >= N) continue;
-    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+  for (int i = 0; i < MI; ++i) {
+    const int row = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+    if (row >= M) continue;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M) {
-          float v = acc[i][j][r] + bv;
-          float* c = C + row * ldc + col;
-          if (gridDim.z > 1) atomicAdd(c, v);
-          else *c = accumulate ? (*c + v) : v;
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (col >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + ((bias && blockIdx.z == 0 && col + e < N) ? bias[col + e] : 0.f);
+        float* c = C + row * ldc + col;
+        if (gridDim.z > 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N) atomicAdd(c + e, v[e]);
+        } else if (vec_ok && col + 3 < N) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(c);
+            o = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
+          }
+          *reinterpret_cast<float4*>(c) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N) c[e] = accumulate ? (c[e] + v[e]) : v[e];
         }
       }
   }
@@ -770,7 +789,8 @@ static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, ch
   w.d64b = take(r * 64);
   w.d256 = take(r * 256);
   w.materialise = tr_use_materialised(cfg, R, lay.V + 1);
-  w.ce = take(w.materialise ? (size_t)R * (lay.V + 1) : lr_train_ce_part_floats(R, lay.V + 1));
+  // stored logits: rows padded to a multiple of 4 floats, so that the score product's 16-byte stores are aligned
+  w.ce = take(w.materialise ? (size_t)R * (((size_t)lay.V + 1 + 3) & ~(size_t)3) : lr_train_ce_part_floats(R, lay.V + 1));
   w.total = o;
   return w;
 }
@@ -994,12 +1014,13 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // item chunks add into it
   if (ws.materialise) {
     float* logits = ws.ce;
-    TR_RUN(tr_gemm(x, 64, 1, P + lay.emb, 1, 64, logits, C, P + lay.bias, R, C, 64, 0, st));  // scores (model/lru.py:85)
-    hipLaunchKernelGGL(tr_ce_kernel, dim3(R), dim3(256), 0, st, logits, (long long)C, C, lab, h->scal);
+    const long long ldl = ((long long)C + 3) & ~3LL;   // padded row pitch (see the workspace carve)
+    TR_RUN(tr_gemm(x, 64, 1, P + lay.emb, 1, 64, logits, ldl, P + lay.bias, R, C, 64, 0, st));  // scores (model/lru.py:85)
+    hipLaunchKernelGGL(tr_ce_kernel, dim3(R), dim3(256), 0, st, logits, ldl, C, lab, h->scal);
     LR_CHECK_LAUNCH("tr_ce_kernel");
-    TR_RUN(tr_gemm(logits, C, 1, P + lay.emb, 64, 1, dx, 64, nullptr, R, 64, C, 1, st, true));  // d x
+    TR_RUN(tr_gemm(logits, ldl, 1, P + lay.emb, 64, 1, dx, 64, nullptr, R, 64, C, 1, st, true));  // d x
     // d table += d logits^T x, and d bias += column sums of d logits (the row sums of the A operand)
-    TR_RUN(tr_gemm(logits, 1, C, x, 64, 1, G + lay.emb, 64, nullptr, C, 64, R, 1, st, true, G + lay.bias));
+    TR_RUN(tr_gemm(logits, 1, ldl, x, 64, 1, G + lay.emb, 64, nullptr, C, 64, R, 1, st, true, G + lay.bias));
   } else {
     TR_RUN(lr_launch_train_ce(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
   }
