@@ -146,7 +146,7 @@ struct lr_lru_train {
 // Tile BM x BN (64 or 128 each), 4 waves (2 x 2) of (BM/64) x (BN/64) MFMA blocks of 32 x 32: the three V-sized products
 // of a step (scores, d hidden, d table: 4.95 GFLOP each on Beauty = 31 us at the f32 MFMA peak) run on 128-row tiles --
 // on 64 x 64 a K step is 16 MFMAs per wave between two barriers and 16 LDS stores per thread, and they took 82-110 us.
-template <int BM, int BN>
+template <int BM, int BN, bool SWAP>
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, long long sam, long long sak,
                                                          const float* __restrict__ B, long long sbk, long long sbn,
                                                          float* C, long long ldc, const float* bias, int M, int N,
@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   if (want_rowsum) {
@@ -236,6 +238,30 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
   // bits): a lane then owns ONE row (lane & 31) and, per group g, 4 CONSECUTIVE columns 8 g + 4 (lane >> 5) .. + 3 of each
   // 32 x 32 block -- 16-byte stores. With one column per lane the score product's 155 MB of logits left through 64
   // four-byte stores per lane (110-127 us for 4.95 GFLOP).
+  // SWAP only without a K split: the split's atomic adds want a wave-instruction to cover whole 128-byte row segments
+  // (a lane per column), which is the un-swapped layout -- 64 lanes in 64 different rows is the slow shape for atomics
+  // (MI355X_MICROARCH.md, global float atomics; measured: 82-103 -> 264 us on the split products with the swap).
+  if (!SWAP) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (col >= N) continue;
+      const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M) {
+            float v = acc[i][j][r] + bv;
+            float* c = C + row * ldc + col;
+            if (gridDim.z > 1) atomicAdd(c, v);
+            else *c = accumulate ? (*c + v) : v;
+          }
+        }
+    }
+    return;
+  }
   const bool vec_ok = (ldc & 3) == 0 && (reinterpret_cast<size_t>(C) & 15) == 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -273,42 +299,26 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 
 // accumulate: 0 = overwrite, 1 = add to C. split_ok: the caller guarantees that C already holds the value to add to
 // (zero for a fresh result), so K may be split over workgroups with atomic adds when the tiles alone are too few.
-// Tile: the largest of 128 x 128, 128 x 64, 64 x 64 that still gives the launch >= 512 workgroups (K splits counted
-// where they are allowed) -- the V-sized products; everything else stays on 64 x 64 (a 3200 x 256 x 64 linear has 200
-// tiles of 64 x 64 and would have 50 of 128 x 128).
-template <int BM, int BN>
-static void tr_gemm_launch(dim3 grid, hipStream_t st, const float* A, long long sam, long long sak, const float* B,
-                           long long sbk, long long sbn, float* C, long long ldc, const float* bias, int M, int N, int K,
-                           int accumulate, float* rowsum) {
-  hipLaunchKernelGGL((train_gemm_kernel<BM, BN>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K,
-                     accumulate, rowsum);
-}
 static int tr_gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
                    long long ldc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st,
                    bool split_ok = false, float* rowsum = nullptr) {
   if (M <= 0 || N <= 0) return LR_OK;
-  const int ksteps = (K + TG_BK - 1) / TG_BK;
-  auto splits = [&](int tiles) {
-    if (!split_ok) return 1;
+  dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
+  if (split_ok) {
+    const int tiles = grid.x * grid.y, ksteps = (K + TG_BK - 1) / TG_BK;
     int S = 1024 / tiles;                // ~4 workgroups per CU
     if (S > ksteps / 8) S = ksteps / 8;  // >= 8 K steps per split
-    return S > 1 ? S : 1;
-  };
-  int bm = 64, bn = 64;
-  const int cand[2][2] = {{128, 128}, {128, 64}};
-  for (int c = 0; c < 2; ++c) {
-    const int tiles = ((M + cand[c][0] - 1) / cand[c][0]) * ((N + cand[c][1] - 1) / cand[c][1]);
-    if (N > cand[c][1] / 2 && tiles * splits(tiles) >= 512) {
-      bm = cand[c][0];
-      bn = cand[c][1];
-      break;
-    }
+    if (S > 1) grid.z = S;
   }
-  dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, 1);
-  grid.z = splits(grid.x * grid.y);
-  if (bm == 128 && bn == 128) tr_gemm_launch<128, 128>(grid, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, accumulate, rowsum);
-  else if (bm == 128) tr_gemm_launch<128, 64>(grid, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, accumulate, rowsum);
-  else tr_gemm_launch<64, 64>(grid, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N, K, accumulate, rowsum);
+  // 64 x 64 tiles for every product: 128-row tiles (the template still takes them) were measured on the three V-sized
+  // products of the Beauty step and lost -- scores 110 -> 127 us, the split products 82-88 -> 103 us (3 instead of 8
+  // workgroups per CU, and these launches live on occupancy: K = 64 is two K steps between a cold start and the store)
+  if (grid.z > 1)
+    hipLaunchKernelGGL((train_gemm_kernel<64, 64, false>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N,
+                       K, accumulate, rowsum);
+  else
+    hipLaunchKernelGGL((train_gemm_kernel<64, 64, true>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N,
+                       K, accumulate, rowsum);
   LR_CHECK_LAUNCH("train_gemm_kernel");
   return LR_OK;
 }
