@@ -397,13 +397,11 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
 #define RB_MFMA(bfrag, mh, nh)                                                                        \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                      \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
     acc[(mh)*4 + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);                \
-  __builtin_amdgcn_s_setprio(0);
+        bfrag[ks * 2 + nt], afr[ks * 4 + mt], acc[(mh)*4 + mt][(nh)*2 + nt], 0, 0, 0);
 #define RB_WAIT(steady)                               \
   if (steady) { PP_WAIT_VM(10); } else { PP_WAIT_VM(0); }
 
@@ -459,7 +457,14 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
   PP_BARRIER();
   RB_LOAD_B(b0x, smem, 0)
   GEMM_STAMP(1)
-  if (wm == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
+  if (wm == 1) {
+    // Static priority for the second-dispatched half (waves 4-7), NO per-segment s_setprio flips around the MFMA runs
+    // (round 1-2 raised the priority around every 16-MFMA segment): within a SIMD the two waves are arbitrated by priority,
+    // then age, and the younger wave loses every segment start (MI355X_MICROARCH.md, two waves per SIMD, item 4). Same-box
+    // A/B, three interleaved rounds (gpurun_out/abprio): 149.1 -> 149.8 users/s, GEMMs 1414 -> 1420 TF/s, qkv 1370 -> 1384.
+    __builtin_amdgcn_s_setprio(1);
+    PP_BARRIER();  // group 1 runs one barrier behind group 0
+  }
 
   for (int kt = 0; kt < nkt; kt += 2) {
     RB_TILE(kt, b0x, b0y)
