@@ -427,3 +427,23 @@ def test_lazy_eval_items_equal_the_eager_ones_and_stream_every_user_once(golden_
         n_batches += 1
     want = [(tuple(b["input_ids"][-300:]), b["labels"]) for b in eager[20:131]]
     assert sorted(seen) == sorted(want) and len(seen) == 111 and n_batches < 30
+
+
+def test_bench_expected_metrics_helper_matches_the_oracle_formulas():
+    """bench.py's host-side expectation for the planted labels (metrics_of_ranks: Recall / MRR / NDCG from 0-based ranks,
+    -1 = not retrieved) equals the oracle's rank-metric sums on ranked lists that realise those ranks."""
+    import bench
+    from oracle import lru_oracle as O
+
+    rng = np.random.default_rng(0)
+    n = 500
+    pos = (np.arange(n) % bench.PLANT_PERIOD).astype(np.int64)
+    pos[pos >= 50] = -1
+    ranked = np.stack([rng.permutation(1000)[:50] + 1 for _ in range(n)]).astype(np.int32)
+    labels = np.where(pos >= 0, ranked[np.arange(n), np.maximum(pos, 0)], 5000).astype(np.int64)
+    got = bench.metrics_of_ranks(pos, [10, 50])
+    sums = O.rank_metric_sums(ranked, labels, [50, 10])
+    for j, k in enumerate((50, 10)):
+        for c, name in enumerate(("Recall", "MRR", "NDCG")):
+            assert abs(got[f"{name}@{k}"] - sums[j, c] / n) < 1e-12
+    assert got["NDCG@10"] > 0.05 and got["Recall@50"] == pytest.approx(50 / 60 * (n // 60 * 60) / n + (n % 60 if n % 60 < 50 else 50) / n, abs=1e-12)
