@@ -381,17 +381,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
             st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][nt], qf[qt][ks], st[qt][nt], 0, 0, 0);
       }
 
-      // V^T fragments of the block's first 32 keys: they do not depend on the softmax, so they are requested HERE, behind
-      // the score MFMAs, and land during the softmax's vector work (the K fragment registers are free again); requested
-      // where P.V consumes them, the first MFMAs of that run waited a full LDS latency
-      short4v vpre[8][2];
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        vpre[dt][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb_off[dt] + VS));
-        vpre[dt][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + 4096)));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-
       if (STAMP) asm volatile("" ::"v"(st[0][0]), "v"(st[1][3]));
       FA_STAMP(2)  // S^T = K Q^T
       // ---- online softmax (lane-local row), P packed as the B operand of O^T = V^T P^T
@@ -453,9 +442,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       for (int ks2 = 0; ks2 < 2; ++ks2) {
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-          const short4v t0 = ks2 == 0 ? vpre[dt][0] : __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + ks2 * 8192)));
-          const short4v t1 = ks2 == 0 ? vpre[dt][1] : __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + ks2 * 8192 + 4096)));
           bf16x8 vf;
           const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
