@@ -39,8 +39,10 @@ if __name__ == "__main__":
     else:
         from llamarec_amd.packing import token_budget_steps
         from llamarec_amd.synth import synth_users
-        run([460] * 32, name="ml-100k step (32 x 460)")
-        run([740] * 16, name="beauty reference batch (16 x 740)")
+        variants = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
         T = synth_users("beauty", 100)[3]
-        run(T[token_budget_steps(T)[0]], name="beauty token-budget step")
-        run([1000] * 16, name="16 x 1000")
+        for v in variants:
+            run([460] * 32, v, name="ml-100k step (32 x 460)")
+            run([740] * 16, v, name="beauty reference batch (16 x 740)")
+            run(T[token_budget_steps(T)[0]], v, name="beauty token-budget step")
+            run([1000] * 16, v, name="16 x 1000")
