@@ -117,17 +117,14 @@ __device__ __forceinline__ int v_off(int row, int ch) {  // dual-use swizzle, 25
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-__device__ __forceinline__ void attn_glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // LDS-DMA through a buffer descriptor as INLINE ASM. With the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc
 // knows an LDS write is pending on the vector-memory counter and -- unable to prove that a ds_read_b64_tr_b16 (the V^T
 // fragment reads) touches another stage buffer -- puts `s_waitcnt vmcnt(0)` in front of the first transposed read of every
 // key block: each wave then sat out the landing of the NEXT block's tiles in the middle of the current block (found in
 // round 3 in the .s of the product kernel; it is also why requesting the V fragments earlier was slower). The asm form is
 // invisible to that pass; the one wait that is needed stands in front of the block's barrier, written by hand.
+// (M0 is a reserved register to hipcc: it cannot be named as a clobber, and nothing else in these kernels uses it --
+// gfx9+ LDS instructions do not read M0.)
 typedef int fa_int4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ fa_int4 fa_make_rsrc(const void* base, int num_records) {
   const unsigned long long b = reinterpret_cast<unsigned long long>(base);
@@ -140,12 +137,12 @@ __device__ __forceinline__ fa_int4 fa_make_rsrc(const void* base, int num_record
 }
 __device__ __forceinline__ void fa_glds16(const void* gsrc, const void* lds_wave_base) {   // per-lane source address
   const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
 }
 __device__ __forceinline__ void fa_dma16(fa_int4 rsrc, const void* lds_wave_base, unsigned voff) {
   const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc)
-               : "memory", "m0");
+               : "memory");
 }
 
 // x[lane] (op) x[lane ^ 16] and x[lane] (op) x[lane ^ 32] without the LDS crossbar: gfx950's row / half swaps
@@ -199,6 +196,20 @@ __device__ __forceinline__ float fa_sum_xor16_32(float v) {
 // LR_ATTN_STAMPS=1 at run time; tools/attn_stamps.py); the product library holds no stamping code. s_memtime deltas
 // of the key-block loop's segments summed over the loop, wave 0 of the first 64 workgroups.
 __device__ unsigned long long g_attn_stamps[64 * 8];
+// per-workgroup timeline of a stamped launch (s_memrealtime, 100 MHz; tools/attn_wg_trace.py):
+// entry | prologue done | key-block loop done | exit | HW_ID | XCC_ID | key blocks | blockIdx
+#define FA_WG_TRACE 8192
+#ifdef LR_EXPERIMENTS
+__device__ unsigned long long g_attn_wg[FA_WG_TRACE * 8];
+#else
+__device__ unsigned long long g_attn_wg[8];   // never written: the stamped instantiation exists in experiment builds only
+#endif
+#define FA_RT(dst)                                                                \
+  if (STAMP) {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  }
 #define FA_STAMP(slot)                                                         \
   if (STAMP) {                                                                 \
     unsigned long long t_;                                                     \
@@ -220,6 +231,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
                                                               int max_qblocks, int n_pairs, float* lse,
                                                               const u16* __restrict__ q_rows_last = nullptr) {
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  unsigned long long rt_entry = 0, rt_pro = 0, rt_loop = 0, rt_exit = 0;
+  FA_RT(rt_entry)
   if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
   // [2 stages][K 16 KiB | V 16 KiB]; filled by LDS-DMA (lane-linear 1 KiB pieces = 4 rows x 256 B),
   // the XOR swizzles are applied to the SOURCE chunk: position p of row r holds chunk p ^ s(r).
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the asm DMAs of block 0 (hipcc does not count them)
   __syncthreads();
   FA_STAMP(0)  // prologue: Q fragments + first K/V tile landed
+  FA_RT(rt_pro)
 
   auto block = [&](const int kb, auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
@@ -493,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     if (kb + 1 <= kb_last) block(kb + 1, std::integral_constant<int, 1>{});
   }
 
+  FA_RT(rt_loop)
   // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -531,312 +546,25 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 #pragma unroll
       for (int i = 0; i < 8; ++i) g_attn_stamps[wg * 8 + i] = stamp_acc[i];
     }
-  }
-}
-
-
-// =============================================================================================
-// MFMA, head_dim 128, PING-PONG: 8 waves, 256 query rows per workgroup, one workgroup per CU
-// =============================================================================================
-// The 4-wave kernel above leaves the overlap of matrix and vector work to chance: its two co-resident workgroups are
-// unsynchronised, and PMC shows a wave parked at the per-block barrier / DMA wait for a third of its life and stalled
-// at issue behind the matrix pipe for another third while that pipe is 30 % busy. Here the two waves of a SIMD belong
-// to ONE workgroup and run ONE BARRIER APART (the GEMM's schedule): per key block every wave executes
-//     MFMA phase : O^T += V^T P^T of block kb - 1, then S^T = K Q^T of block kb        (64 MFMAs, 48 LDS reads)
-//     | s_barrier |
-//     VALU phase : LDS-DMA of block kb + 2, online softmax of block kb                  (~260 vector instructions)
-//     | s_barrier |
-// and waves 4-7 start one barrier late, so a SIMD always has one wave on the matrix pipe and one on the vector ALU.
-// K/V tiles live in a ring of four 32 KiB stages shared by all eight waves (half the DMA issue per wave): block kb + 2
-// is requested during the first group's VALU phase kb (by both groups: the second one issues its pieces at the start of
-// its concurrent MFMA phase), confirmed one block later with a counted vmcnt and first read one barrier after that; its
-// stage held block kb - 2, whose last read (V) lies two barriers before the request.
-// Rows: wave w takes the 32-row chunk 2 (w & 3) + (w >> 2) of the tile, so both wave groups reach the diagonal together.
-#define FP_QROWS 256
-#define FP_STAGES 4
-
-template <bool WITH_LSE>
-__global__ __launch_bounds__(512) void attn_pp_kernel(const u16* __restrict__ qkv, u16* out, const int32_t* cu, int prefix_len,
-                                                      int nh, int nkv, int max_qblocks, int n_pairs, float* lse) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int hd = 128;
-  int seg, h, qb;
-  {
-    const int id = blockIdx.x, stream = id & 7, j = id >> 3;
-    const int pl = j / max_qblocks;
-    qb = max_qblocks - 1 - j % max_qblocks;      // heaviest tile of a pair first
-    const int pair = pl * 8 + stream;
-    if (pair >= n_pairs) return;
-    seg = __builtin_amdgcn_readfirstlane(pair / nh);
-    h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
-    qb = __builtin_amdgcn_readfirstlane(qb);
-  }
-  const int tok0 = cu[seg];
-  const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;
-  const int T = P + cu[seg + 1] - tok0;
-  if (qb * FP_QROWS >= T || (qb + 1) * FP_QROWS <= P) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
-  const int quad = lane >> 4, li = lane & 15;
-  const int kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
-  const int stride = (nh + 2 * nkv) * hd;
-  const int koff0 = (nh + kvh) * hd, voff0 = koff0 + nkv * hd;
-  const int vtok0 = tok0 - P;
-  const u16* kbase = qkv + (size_t)vtok0 * stride + koff0;
-  const u16* vbase = qkv + (size_t)vtok0 * stride + voff0;
-  const u16* pkbase = qkv + koff0;
-  const u16* pvbase = qkv + voff0;
-
-  const int r0 = qb * FP_QROWS + (2 * (wave & 3) + grp) * 32;   // first query row of this wave
-  bf16x8 qf[2][4];
-  int qabs[2];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qabs[qt] = r0 + qt * 16 + li;
-    const int qr = min(max(qabs[qt], P), T - 1);
-    const u16* qp = qkv + (size_t)(vtok0 + qr) * stride + h * hd + quad * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
-  }
-  floatx4 ot[2][8];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
-  float l_run[2] = {0.f, 0.f};
-  const int kb_last = min(qb * FP_QROWS + FP_QROWS - 1, T - 1) / FA_KB;       // the workgroup's last key block
-  const int wave_q_last = r0 + 31;
-  const bool wave_live = r0 < T && wave_q_last >= P;                           // the wave owns at least one row of the segment
-  const int wkb_last = wave_live ? min(wave_q_last, T - 1) / FA_KB : -1;       // the wave's last key block
-  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;
-
-  // ---- DMA staging: 16 K + 16 V pieces per block (4 rows each); wave w moves pieces 2 w, 2 w + 1 of each
-  const int prow = lane >> 4, ppos = lane & 15;
-  unsigned koff[2], voff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 4 + prow;
-    koff[i] = (unsigned)(row * stride + (ppos ^ (row & 15)) * 8) * 2u;
-    voff[i] = (unsigned)(row * stride + (ppos ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 8) * 2u;
-  }
-  auto stage = [&](int kb) __attribute__((always_inline)) {
-    char* base = smem + (kb & (FP_STAGES - 1)) * FA_STAGE_BYTES + wave * 2048;
-    if (kb * FA_KB >= P) {
-      const size_t blk_off = (size_t)kb * FA_KB * stride * 2;
-      const int records = ((T - 1 - kb * FA_KB) * stride + hd) * 2;
-      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(kbase) + blk_off), 0, records, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(vbase) + blk_off), 0, records, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, koff[i], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(base + FA_TILE_BYTES + i * 1024), 16,
-                                                 voff[i], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 4 + prow;
-        const int key = min(kb * FA_KB + row, T - 1);
-        const int kchunk = ppos ^ (row & 15);
-        const int vchunk = ppos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        const u16* kr = key < P ? pkbase : kbase;
-        const u16* vr = key < P ? pvbase : vbase;
-        attn_glds16(kr + (size_t)key * stride + kchunk * 8, base + i * 1024);
-        attn_glds16(vr + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
-      }
-    }
-  };
-
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
-  lds_char* const lds = (lds_char*)smem;
-  lds_char *kb_off[4], *vb_off[8];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kb_off[ks] = lds + (li * 256 + (((ks * 4 + quad) ^ li) << 4));
-  {
-    const int qp = li >> 2, p4 = li & 3;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) vb_off[dt] = lds + (v_off(quad * 4 + qp, dt * 2 + (p4 >> 1)) + 8 * (p4 & 1));
-  }
-
-  floatx4 st[2][4];
-  bf16x8 pa[2][2];
-
-  // ---- the two phases of key block kb; BUF = kb & 3 and PBUF = (kb - 1) & 3 are compile-time (loop unrolled by four)
-  auto mfma_phase = [&](const int kb, auto buf_c) __attribute__((always_inline)) {
-    constexpr int BUF = decltype(buf_c)::value, PBUF = (BUF + FP_STAGES - 1) & (FP_STAGES - 1);
-    constexpr int KS = BUF * FA_STAGE_BYTES, VS = PBUF * FA_STAGE_BYTES + FA_TILE_BYTES;
-    if (grp == 1 && kb + 2 <= kb_last) stage(kb + 2);   // the second group requests its pieces while the first one does (its VALU phase)
-    if (kb >= 1 && kb - 1 <= wkb_last) {   // O^T += V^T P^T of block kb - 1
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-          const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + ks2 * 8192)));
-          const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) short4v*)(vb_off[dt] + (VS + ks2 * 8192 + 4096)));
-          bf16x8 vf;
-          const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            vf[r] = b0[r];
-            vf[4 + r] = b1[r];
-          }
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
-            ot[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa[qt][ks2], ot[qt][dt], 0, 0, 0);
-        }
-      }
-    }
-    if (kb <= wkb_last) {   // S^T = K Q^T of block kb
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) st[qt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-      bf16x8 kf[2][4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) kf[0][nt] = *reinterpret_cast<lds_bf16x8*>(kb_off[0] + (KS + nt * 4096));
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            kf[(ks + 1) & 1][nt] = *reinterpret_cast<lds_bf16x8*>(kb_off[ks + 1] + (KS + nt * 4096));
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
-            st[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][nt], qf[qt][ks], st[qt][nt], 0, 0, 0);
-      }
-    }
-  };
-  auto valu_phase = [&](const int kb) __attribute__((always_inline)) {
-    if (grp == 0 && kb + 2 <= kb_last) stage(kb + 2);
-    if (kb > wkb_last) return;
-    const bool diag = (kb * FA_KB + FA_KB - 1) > r0;   // block needs masking for some row of the wave
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      if (diag) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kb * FA_KB + nt * 16 + quad * 4 + r;
-            st[qt][nt][r] = (key <= qabs[qt]) ? st[qt][nt][r] : -__builtin_inff();
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      float mx = fa_max3(st[qt][0][0], st[qt][0][1], st[qt][0][2]);
-      mx = fa_max3(mx, st[qt][0][3], st[qt][1][0]);
-#pragma unroll
-      for (int nt = 1; nt < 4; ++nt) {
-        mx = fa_max3(mx, st[qt][nt][1], st[qt][nt][2]);
-        if (nt < 3) mx = fa_max3(mx, st[qt][nt][3], st[qt][nt + 1][0]);
-      }
-      mx = fa_max2(mx, st[qt][3][3]);
-      mx = fa_max_xor16_32(mx);
-      const float m_new = fa_max2(m_run[qt], mx * sl2);
-      const bool grew = m_new > m_run[qt];
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-      m_run[qt] = m_new;
-      float ps = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][nt][r], sl2, -m_new));
-          ps += p;
-          pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
-        }
-      l_run[qt] = l_run[qt] * alpha + ps;
-      if (__any(grew)) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
-      }
-    }
-  };
-#define FP_BARRIER()                     \
-  do {                                   \
-    __builtin_amdgcn_sched_barrier(0);   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();        \
-    __builtin_amdgcn_sched_barrier(0);   \
-  } while (0)
-
-  // ---- prologue: blocks 0 and 1 staged, Q resident
-  stage(0);
-  if (kb_last >= 1) stage(1);
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  FP_BARRIER();
-  if (grp == 1) FP_BARRIER();   // the second group runs one barrier behind
-  // kb runs to kb_last + 1: the last iteration only drains O^T += V^T P^T of block kb_last
-  // Block kb + 1 was requested one block ago (first group: VALU phase kb - 1, second group: MFMA phase kb - 1 -- the same
-  // moment) and is confirmed at the end of the phase in which block kb + 2 is requested: all but the newest request
-  // (4 DMA instructions) must have landed; one barrier later the first group reads it.
-  auto confirm = [&](const int kb) __attribute__((always_inline)) {
-    if (kb + 2 <= kb_last) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  auto iter = [&](const int kb, auto buf_c) __attribute__((always_inline)) {
-    __builtin_amdgcn_s_setprio(1);   // the wave on the matrix pipe wins the issue arbitration against its partner's vector stream
-    mfma_phase(kb, buf_c);
-    __builtin_amdgcn_s_setprio(0);
-    if (grp == 1) confirm(kb);
-    FP_BARRIER();
-    valu_phase(kb);
-    if (grp == 0) confirm(kb);
-    FP_BARRIER();
-  };
-  for (int kb = 0; kb <= kb_last + 1; kb += 4) {
-    iter(kb, std::integral_constant<int, 0>{});
-    if (kb + 1 <= kb_last + 1) iter(kb + 1, std::integral_constant<int, 1>{});
-    if (kb + 2 <= kb_last + 1) iter(kb + 2, std::integral_constant<int, 2>{});
-    if (kb + 3 <= kb_last + 1) iter(kb + 3, std::integral_constant<int, 3>{});
-  }
-  if (grp == 0) FP_BARRIER();   // balance the second group's extra barrier
-#undef FP_BARRIER
-
-  // ---- normalise and store (as in the 4-wave kernel)
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const float l = fa_sum_xor16_32(l_run[qt]);
-    const float inv = 1.0f / l;
-    const bool live = qabs[qt] < T && qabs[qt] >= P;
-    if (WITH_LSE && live && lse && quad == 0)
-      lse[(size_t)(vtok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
-    u16* op = out + (size_t)(vtok0 + (live ? qabs[qt] : P)) * nh * hd + h * hd + (quad & 1) * 16 + (quad >> 1) * 8;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned a[2], b[2];
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        a[w] = (unsigned)f2bf(ot[qt][2 * k][2 * w] * inv) | ((unsigned)f2bf(ot[qt][2 * k][2 * w + 1] * inv) << 16);
-        b[w] = (unsigned)f2bf(ot[qt][2 * k + 1][2 * w] * inv) | ((unsigned)f2bf(ot[qt][2 * k + 1][2 * w + 1] * inv) << 16);
-        const auto sw = __builtin_amdgcn_permlane16_swap(a[w], b[w], false, false);
-        a[w] = sw[0];
-        b[w] = sw[1];
-      }
-      if (live) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<u32x4*>(op + k * 32) = u32x4{a[0], a[1], b[0], b[1]};
-      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores have left
+    FA_RT(rt_exit)
+    if (wg < FA_WG_TRACE && tid == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* w = g_attn_wg + (size_t)wg * 8;
+      w[0] = rt_entry; w[1] = rt_pro; w[2] = rt_loop; w[3] = rt_exit; w[4] = hw; w[5] = xcc; w[6] = kb_last + 1; w[7] = wg;
     }
   }
 }
+
 
 #ifdef LR_EXPERIMENTS
+extern "C" int lr_debug_attn_wg_trace(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > FA_WG_TRACE * 8) LR_FAIL(LR_EINVAL, "lr_debug_attn_wg_trace: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_wg), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
+}
 extern "C" int lr_debug_attn_stamps(unsigned long long* out, int n) {
   if (!out || n < 1 || n > 64 * 8) LR_FAIL(LR_EINVAL, "lr_debug_attn_stamps: bad arguments");
   LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), (size_t)n * sizeof(unsigned long long)));
@@ -868,7 +596,7 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
   if (n_tok <= 0 || B <= 0) return LR_OK;
   if (nh % nkv != 0) LR_FAIL(LR_EINVAL, "attention: num_heads %d not a multiple of num_kv_heads %d", nh, nkv);
   if (variant == 0) variant = (hd == 128) ? 2 : 1;
-  if (prefix_len < 0 || (prefix_len > 0 && ((variant != 2 && variant != 3) || cu_host[1] - cu_host[0] != prefix_len)))
+  if (prefix_len < 0 || (prefix_len > 0 && (variant != 2 || cu_host[1] - cu_host[0] != prefix_len)))
     LR_FAIL(LR_EINVAL, "attention: shared prefix of %d tokens needs the head_dim-128 MFMA kernel and segment 0 = the prefix",
             prefix_len);
   double work = 0;  // causal QK^T + PV flops of the rows each segment owns
@@ -907,26 +635,6 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
       hipLaunchKernelGGL(attn_mfma128_kernel<false>, dim3(grid), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
                          prefix_len, nh, nkv, mq, n_pairs, lse);
     LR_CHECK_LAUNCH("attn_mfma128_kernel");
-  } else if (variant == 3) {
-    if (hd != 128) LR_FAIL(LR_EUNSUPPORTED, "attention variant 3 needs head_dim 128 (got %d)", hd);
-    const int mq = (maxT + FP_QROWS - 1) / FP_QROWS;
-    const long long n_pairs_ll = (long long)B * nh, grid_ll = 8 * ((n_pairs_ll + 7) / 8) * mq;
-    if (grid_ll > 0x7fffffffLL) LR_FAIL(LR_EUNSUPPORTED, "attention: %lld workgroups exceed the grid limit", grid_ll);
-    if ((long long)n_tok * (nh + 2 * nkv) * hd * 2 > 0x7fffffffLL * 2)
-      LR_FAIL(LR_EUNSUPPORTED, "attention: packed qkv of %d tokens exceeds the 4 GiB a buffer descriptor addresses", n_tok);
-    static bool lds_pp[LR_MAX_DEVICES] = {}, lds_pp_lse[LR_MAX_DEVICES] = {};
-    if (lse) {
-      if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_pp_kernel<true>), FP_STAGES * FA_STAGE_BYTES, lds_pp_lse))
-        return rc;
-      hipLaunchKernelGGL(attn_pp_kernel<true>, dim3((unsigned)grid_ll), dim3(512), FP_STAGES * FA_STAGE_BYTES, st, qkv, out, cu,
-                         prefix_len, nh, nkv, mq, (int)n_pairs_ll, lse);
-    } else {
-      if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_pp_kernel<false>), FP_STAGES * FA_STAGE_BYTES, lds_pp))
-        return rc;
-      hipLaunchKernelGGL(attn_pp_kernel<false>, dim3((unsigned)grid_ll), dim3(512), FP_STAGES * FA_STAGE_BYTES, st, qkv, out, cu,
-                         prefix_len, nh, nkv, mq, (int)n_pairs_ll, lse);
-    }
-    LR_CHECK_LAUNCH("attn_pp_kernel");
   } else if (variant == 1) {
     if (hd > 256) LR_FAIL(LR_EUNSUPPORTED, "attention: head_dim %d > 256", hd);
     const int items = n_tok * nh;
@@ -934,7 +642,7 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
                        n_tok, nh, nkv, hd, (const int32_t*)nullptr, lse);
     LR_CHECK_LAUNCH("attn_generic_kernel");
   } else {
-    LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA, 3 = 8-wave ping-pong)", variant);
+    LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA)", variant);
   }
   return LR_OK;
 }

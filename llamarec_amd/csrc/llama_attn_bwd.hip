@@ -119,10 +119,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_to_bf16_kernel(const float* d
 __device__ __forceinline__ int ab_sw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ int ab_off(int row, int ch) { return 256 * row + 16 * (ch ^ ab_sw(row)); }
 
+// LDS-DMA as inline asm (see llama_attn.hip: issued through the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the
+// first transposed LDS read that follows -- here in the middle of the iteration that should hide the fetch). hipcc does not
+// count these requests: the one wait they need is written by hand in front of each iteration's barrier.
 __device__ __forceinline__ void ab_glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
 }
+#define AB_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // stage one 64 x 128 tile (rows row0.., clamped to [0, T-1]) of a row-major matrix with `stride` elements per row:
 // 16 pieces of 4 rows, wave w moves pieces 4w..4w+3 (LDS image lane-linear, swizzle applied to the source chunk)
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
     for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]), "v"(dof[qt][ks]));
     asm volatile("" ::"v"(lse2[qt]), "v"(dq_row[qt]));
   }
+  AB_DMA_LANDED();
   __syncthreads();
 
   for (int kb = 0; kb <= kb_last; ++kb) {
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const u16* __restri
             dqt[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsb[qt][ks2], dqt[qt][dt], 0, 0, 0);
         }
     }
+    AB_DMA_LANDED();   // this wave's pieces of block kb + 1
     __syncthreads();
   }
   // ---- store scale * dQ: lane owns query row li, d = dt*16 + 4*quad + r
@@ -364,6 +370,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
   const int qb_first = kb, qb_last = (T - 1) / AB_KB;
   const int nqb = qb_last - qb_first + 1;
   const int steps = nqb * rep;  // (query head of the group, query block) pairs, head-major
+  // a step's tiles are requested at the top of the step before (LDS-DMA) together with its 64 query rows' statistics
+  // (ordinary loads into two registers of wave 0); the statistics are written to LDS at the END of that step, so that the
+  // wait hipcc puts in front of the write coincides with the hand-written one for the DMA
+  float st_l = 0.f, st_dd = 0.f;
   auto stage = [&](int step, int buf) {
     const int h = kvh * rep + step / nqb, qb = qb_first + step % nqb;
     char* base = smem + buf * AB_STAGE_BYTES;
@@ -371,13 +381,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
     ab_stage_tile(d_out + (size_t)tok0 * ostride + h * hd, ostride, qb * AB_KB, T, base + AB_TILE_BYTES, wave, lane);
     if (tid < 64) {
       const int q = min(qb * AB_KB + tid, T - 1);
-      stats[buf * 128 + tid] = lse[(size_t)(tok0 + q) * nh + h] * 1.4426950408889634f;
-      stats[buf * 128 + 64 + tid] = dsum[(size_t)(tok0 + q) * nh + h];
+      st_l = lse[(size_t)(tok0 + q) * nh + h];   // (first use of either value: commit_stats)
+      st_dd = dsum[(size_t)(tok0 + q) * nh + h];
+    }
+  };
+  auto commit_stats = [&](int buf) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < 64) {
+      stats[buf * 128 + tid] = st_l * 1.4426950408889634f;
+      stats[buf * 128 + 64 + tid] = st_dd;
     }
   };
   stage(0, 0);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(kf[ks]), "v"(vf[ks]));
+  commit_stats(0);
+  AB_DMA_LANDED();
   __syncthreads();
 
   for (int step = 0; step < steps; ++step) {
@@ -425,6 +444,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const u16* __restr
         dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pb[ks2], dvt[dt], 0, 0, 0);
         dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsb[ks2], dkt[dt], 0, 0, 0);
       }
+    if (step + 1 < steps) commit_stats((step + 1) & 1);
+    AB_DMA_LANDED();   // this wave's pieces of step + 1
     __syncthreads();
   }
   if (kabs < T) {

@@ -148,7 +148,7 @@ def attention_ref(qkv, cu, nh, nkv, hd):
 
 
 @pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 1),
-                                               (4, 2, 16, 1), (2, 2, 64, 1), (4, 4, 128, 3), (4, 2, 128, 3)])
+                                               (4, 2, 16, 1), (2, 2, 64, 1)])
 def test_attention_vs_numpy(nh, nkv, hd, variant):
     lens = [1, 63, 64, 65, 128, 129, 300, 2, 256, 257, 600]
     cu = np.concatenate([[0], np.cumsum(lens)])
@@ -602,7 +602,6 @@ def test_attention_online_softmax_with_forced_maximum_jumps():
             k[key, h] = gain * np.mean([q[j, h] for j in qs], axis=0)
     qkv = bf16_round(qkv)
     got = attention(qkv, cu, nh, nkv, hd, 2)
-    got3 = attention(qkv, cu, nh, nkv, hd, 3)      # the 8-wave ping-pong kernel: same arithmetic per row
     # float64 reference with bf16 probabilities (the kernel's rounding point)
     ref = np.zeros((n, nh * hd))
     qq = qkv[:, : nh * hd].reshape(n, nh, hd).astype(np.float64)
@@ -628,7 +627,6 @@ def test_attention_online_softmax_with_forced_maximum_jumps():
     err = np.abs(got - ref)
     scale = np.abs(ref).max()
     assert err.max() < 2.0e-2 * max(1.0, scale), (err.max(), scale)
-    assert np.isfinite(got3).all() and np.abs(got3 - ref).max() < 2.0e-2 * max(1.0, scale)
     # and the generic kernel (plain online softmax) agrees on the same input
     gen = attention(qkv, cu, nh, nkv, hd, 1)
     assert np.abs(gen - ref).max() < 2.0e-2 * max(1.0, scale)
