@@ -625,10 +625,12 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     static bool lds_set_stamp[LR_MAX_DEVICES] = {};
     const char* stamp_env = getenv("LR_ATTN_STAMPS");
     if (stamp_env && stamp_env[0] == '1') {
-      if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<true>), 2 * FA_STAGE_BYTES,
-                                         lds_set_stamp))
+      // LR_ATTN_ONE_PER_CU=1: ask for 104 KiB of LDS so that only ONE workgroup fits a CU (what a block costs a lone wave per SIMD)
+      const char* one_env = getenv("LR_ATTN_ONE_PER_CU");
+      const int lds_bytes = (one_env && one_env[0] == '1') ? 104 * 1024 : 2 * FA_STAGE_BYTES;
+      if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<true>), 104 * 1024, lds_set_stamp))
         return rc;
-      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(grid), dim3(256), 2 * FA_STAGE_BYTES, st, qkv, out, cu,
+      hipLaunchKernelGGL(attn_mfma128_kernel<true>, dim3(grid), dim3(256), lds_bytes, st, qkv, out, cu,
                          prefix_len, nh, nkv, mq, n_pairs, lse);
     } else
 #endif
