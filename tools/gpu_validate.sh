@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 3 validation: full GPU suite, DP rehearsal (gloo, 2 ranks on one card), token-budget sweep, default bench line
-OUT=gpurun_out/${1:-r3g}
+# round validation (bash tools/gpu_validate.sh <tag>): full GPU suite, DP rehearsal (gloo, 2 ranks on one card), default bench line
+OUT=gpurun_out/${1:-validate}
 mkdir -p $OUT
 timeout -k 10 800 python -m pytest tests -m gpu -q -x --durations=5 > $OUT/tests.log 2>&1
 rc=$?
 tail -12 $OUT/tests.log
 [ $rc -eq 0 ] || { echo "pytest rc=$rc: stopping"; exit 1; }
 timeout -k 10 600 bash tools/rehearse_dp.sh > $OUT/rehearse.log 2>&1; echo "rehearse rc=$?"; tail -8 $OUT/rehearse.log | cut -c1-400
-for tb in 32768 65536 32768 65536; do
+for tb in; do
   timeout -k 10 300 python bench.py --steps 10 --warmup 2 --token-budget $tb --no-cpu-baseline --no-other-shapes > $OUT/tb_$tb.json 2> $OUT/tb_$tb.err || { echo "bench tb=$tb failed"; tail -5 $OUT/tb_$tb.err; continue; }
   python - $OUT/tb_$tb.json $tb <<'PY'
 import json,sys
