@@ -217,6 +217,16 @@ def stream_token_budget_batches(items, lo, hi, token_budget, max_text_len, max_p
 
     q = queue.Queue(maxsize=depth)
     END = object()
+    stop = threading.Event()   # set when the consumer leaves early (closed generator, error downstream)
+
+    def put(x):
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.25)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
@@ -234,23 +244,27 @@ def stream_token_budget_batches(items, lo, hi, token_budget, max_text_len, max_p
                 emit = steps if last else steps[:-1]
                 taken = set()
                 for idx in emit:
-                    q.put(P.eval_pack([pending[int(i)] for i in idx], max_text_len))
+                    if not put(P.eval_pack([pending[int(i)] for i in idx], max_text_len)):
+                        return
                     taken.update(int(i) for i in idx)
                 pending = [it for i, it in enumerate(pending) if i not in taken]
-            q.put(END)
+            put(END)
         except BaseException as e:  # surface producer failures in the consumer
-            q.put(e)
+            put(e)
 
     t = threading.Thread(target=produce, daemon=True, name="llamarec-tokenize")
     t.start()
-    while True:
-        b = q.get()
-        if b is END:
-            break
-        if isinstance(b, BaseException):
-            raise b
-        yield b
-    t.join()
+    try:
+        while True:
+            b = q.get()
+            if b is END:
+                break
+            if isinstance(b, BaseException):
+                raise b
+            yield b
+    finally:   # also reached when the consumer abandons the generator: release a producer blocked on a full queue
+        stop.set()
+        t.join()
 
 
 def build_val_items(dataset, retrieved, tokenizer, args=None, prompter=None):

@@ -427,6 +427,13 @@ def test_lazy_eval_items_equal_the_eager_ones_and_stream_every_user_once(golden_
         n_batches += 1
     want = [(tuple(b["input_ids"][-300:]), b["labels"]) for b in eager[20:131]]
     assert sorted(seen) == sorted(want) and len(seen) == 111 and n_batches < 30
+    # a consumer that leaves early (error downstream, closed generator) must not strand the producer on a full queue
+    import threading
+
+    gen = stream_token_budget_batches(lazy, 0, 150, 600, 300, chunk=8, depth=1)
+    next(gen)
+    gen.close()
+    assert not any(t.name == "llamarec-tokenize" and t.is_alive() for t in threading.enumerate())
 
 
 def test_bench_expected_metrics_helper_matches_the_oracle_formulas():
