@@ -313,6 +313,14 @@ int lr_gemm_bf16_nt_epi(const uint16_t* A, const uint16_t* B, uint16_t* C, const
                         int32_t K, int32_t epilogue, int32_t variant, const int32_t* tok_pos, const float* rope_cs,
                         int32_t rope_positions, int32_t head_dim, int32_t rot_cols, void* workspace, size_t workspace_bytes,
                         void* hip_stream);
+/* o_proj / down_proj together with the RMSNorm that reads their result (exposed for parity tests):
+ *   C = bf16(bf16(A B^T) + R),   norm_out = bf16(norm_w * bf16(C * rsqrt(mean(C^2) + eps)))     (C may alias R)
+ * fuse != 0 lets a product that variant 5 splits over K write norm_out in its reduce pass (one launch less per product in
+ * the online path); *was_fused (optional) reports whether that happened. Both outputs carry the same bits either way. */
+int lr_gemm_bf16_nt_residual_rmsnorm(const uint16_t* A, const uint16_t* B, uint16_t* C, const uint16_t* R, int32_t M,
+                                     int32_t N, int32_t K, int32_t variant, const uint16_t* norm_w, uint16_t* norm_out,
+                                     float eps, int32_t fuse, int32_t* was_fused, void* workspace, size_t workspace_bytes,
+                                     void* hip_stream);
 /* cs: DEVICE buffer of lr_rope_table_bytes(max_positions, head_dim) bytes: fp32 [max_positions][head_dim/2][2] = (cos, sin)
  * of position * theta^(-2i/head_dim), rounded to bf16 values (HF LlamaRotaryEmbedding casts cos/sin to the activations'
  * dtype), followed by the same values packed as bf16 pairs, uint32 [max_positions][head_dim/2] = cos | sin << 16. */

@@ -44,6 +44,9 @@ PROTOTYPES = {
     "lr_gemm_bf16_nt_epi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_gemm_bf16_nt_residual_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                                   C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_rope_table_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "lr_rope_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "lr_metrics_from_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

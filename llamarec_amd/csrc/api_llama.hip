@@ -196,6 +196,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
                            ws.prefix_bad));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st, ws.rope16));
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
+  bool input_normed = false;   // ws.xn already holds RMSNorm(ws.x) with this layer's input_norm
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->layers[l];
     // RMSNorm: either its own pass (read + write every row), or -- folded -- only the row statistic, with the norm
@@ -210,7 +211,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     if (last_q_only) {
       const int q_w = nh * hd, kv_w = 2 * nkv * hd;
       const int pv = (h->gemm_variant == 5 || (h->gemm_variant == 0 && B <= 256)) ? 5 : 1;
-      RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+      if (!input_normed) RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
       RUN(lr_launch_gemm(ws.xn, w.wqkv + (size_t)q_w * d, ws.qkv, nullptr, n, kv_w, d, LR_EPI_ROPE, h->gemm_variant, st,
                          ws.tok_pos, ws.rope, hd, nkv * hd, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, ws.rope16));
       RUN(lr_launch_gather_rows(ws.xn, ws.last_rows, B, d, ws.xn_last, st));
@@ -222,7 +223,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       RUN(lr_launch_gemm(ws.x, h->wqkv_folded[l], ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
                          ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd, ws.rope16));
     } else {
-      RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+      if (!input_normed) RUN(lr_launch_rmsnorm(ws.x, w.input_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
       RUN(lr_launch_gemm(ws.xn, w.wqkv, ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
                          ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, ws.rope16));
     }
@@ -247,9 +248,10 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       // else is in the batch; more prompts than that take the small-tile kernel as before. (Shapes the 256-tile kernel
       // does not take fall back to it inside lr_launch_gemm.)
       const int pv = (h->gemm_variant == 5 || (h->gemm_variant == 0 && B <= 256)) ? 5 : 1;
+      bool normed = false;   // a split-K product's reduce pass also writes the RMSNorm that follows (same bits)
       RUN(lr_launch_gemm(ws.att_last, w.wo, ws.x_last, ws.x_last, B, d, nh * hd, LR_EPI_RESIDUAL, pv, st, nullptr, nullptr,
-                         0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
-      RUN(lr_launch_rmsnorm(ws.x_last, w.post_norm, ws.xn_last, B, d, c.rms_eps, nullptr, st));
+                         0, 0, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, nullptr, w.post_norm, ws.xn_last, c.rms_eps, &normed));
+      if (!normed) RUN(lr_launch_rmsnorm(ws.x_last, w.post_norm, ws.xn_last, B, d, c.rms_eps, nullptr, st));
       RUN(lr_launch_gemm(ws.xn_last, w.wgu, ws.h_last, nullptr, B, 2 * f, d, LR_EPI_SWIGLU, pv, st, nullptr, nullptr, 0, 0,
                          ws.splitk, LR_SPLITK_WS_BYTES));
       RUN(lr_launch_gemm(ws.h_last, w.wdown, ws.x_last, ws.x_last, B, d, f, LR_EPI_RESIDUAL, pv, st, nullptr, nullptr, 0, 0,
@@ -259,19 +261,24 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
     }
     RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,
                             h->attn_variant, nullptr, st, P));
+    bool post_normed = false;
     RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0,
-                       0, ws.splitk, LR_SPLITK_WS_BYTES));
+                       0, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, nullptr, folded ? nullptr : w.post_norm, ws.xn, c.rms_eps,
+                       &post_normed));
     if (folded) {
       RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
       RUN(lr_launch_gemm(ws.x, h->wgu_folded[l], ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr,
                          nullptr, 0, 0, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd));
     } else {
-      RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
+      if (!post_normed) RUN(lr_launch_rmsnorm(ws.x, w.post_norm, ws.xn, n, d, c.rms_eps, nullptr, st));
       RUN(lr_launch_gemm(ws.xn, w.wgu, ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr, nullptr,
                          0, 0, ws.splitk, LR_SPLITK_WS_BYTES));
     }
+    // down_proj; its reduce pass (latency mode) also writes the NEXT layer's input RMSNorm when that layer reads ws.xn
+    const bool next_reads_xn = l + 1 < c.num_layers && !folded;
     RUN(lr_launch_gemm(ws.hmid, w.wdown, ws.x, ws.x, n, d, f, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0, 0,
-                       ws.splitk, LR_SPLITK_WS_BYTES));
+                       ws.splitk, LR_SPLITK_WS_BYTES, nullptr, nullptr, next_reads_xn ? h->layers[l + 1].input_norm : nullptr,
+                       ws.xn, c.rms_eps, &input_normed));
   }
 #undef RUN
   *out_ws = ws;
@@ -389,6 +396,21 @@ extern "C" int lr_gemm_bf16_nt_epi(const uint16_t* A, const uint16_t* B, uint16_
                              ? reinterpret_cast<const unsigned*>(rope_cs + (size_t)rope_positions * head_dim) : nullptr;
   return lr_launch_gemm(A, B, C, R, M, N, K, epilogue, variant, (hipStream_t)hip_stream, tok_pos, rope_cs, head_dim,
                         rot_cols, (float*)workspace, workspace_bytes, nullptr, cs16);
+}
+
+extern "C" int lr_gemm_bf16_nt_residual_rmsnorm(const uint16_t* A, const uint16_t* B, uint16_t* C, const uint16_t* R,
+                                                int32_t M, int32_t N, int32_t K, int32_t variant, const uint16_t* norm_w,
+                                                uint16_t* norm_out, float eps, int32_t fuse, int32_t* was_fused,
+                                                void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!A || !B || !C || !R || !norm_w || !norm_out) LR_FAIL(LR_EINVAL, "lr_gemm_bf16_nt_residual_rmsnorm: null pointer");
+  hipStream_t st = (hipStream_t)hip_stream;
+  bool done = false;
+  int rc = lr_launch_gemm(A, B, C, R, M, N, K, LR_EPI_RESIDUAL, variant, st, nullptr, nullptr, 0, 0, (float*)workspace,
+                          workspace_bytes, nullptr, nullptr, fuse ? norm_w : nullptr, norm_out, eps, &done);
+  if (rc) return rc;
+  if (was_fused) *was_fused = done ? 1 : 0;
+  if (done) return LR_OK;
+  return lr_launch_rmsnorm(C, norm_w, norm_out, M, N, eps, nullptr, st);
 }
 
 extern "C" size_t lr_rope_table_bytes(int32_t max_positions, int32_t head_dim) {

@@ -13,6 +13,7 @@
 
 typedef unsigned short u16;
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll
@@ -146,6 +147,77 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* x, const u16* w
       orow[i] = o;
     }
   }
+}
+
+// ---- split-K reduce + residual add + the RMSNorm that follows, one pass per row --------------------------------------
+// The latency mode's o_proj / down_proj leave S fp32 partial planes (llama_gemm.hip, variant 5); summing them, adding the
+// residual and storing the new residual row is one launch, the RMSNorm of that row for the next projection another: two
+// dependent ~5-9 us launches per product at B = 1. Here a workgroup owns a row: thread t takes the chunks t + 256 k of 8
+// columns, exactly rmsnorm_kernel's assignment, so the square sum is formed from the same values in the same order and the
+// two outputs (residual row C, normalised row `out`) carry the same bits as the two-launch form (planes summed in split
+// order, then bf16(bf16(sum) + residual) as in the GEMM's residual epilogue).
+__global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ part, int S, size_t plane,
+                                                                      u16* C, const u16* R, int N, const u16* w, u16* out,
+                                                                      float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int nv = N / 8;
+  u16x8 vb[RMS_KEEP], wb[RMS_KEEP];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < RMS_KEEP; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < nv) {
+      const size_t off = (size_t)row * N + (size_t)i * 8;
+      floatx4 a = *reinterpret_cast<const floatx4*>(part + off), b = *reinterpret_cast<const floatx4*>(part + off + 4);
+      for (int sp = 1; sp < S; ++sp) {
+        a += *reinterpret_cast<const floatx4*>(part + sp * plane + off);
+        b += *reinterpret_cast<const floatx4*>(part + sp * plane + off + 4);
+      }
+      const u16x8 r = *reinterpret_cast<const u16x8*>(R + off);
+      u16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = f2bf(bf2f(f2bf(a[j])) + bf2f(r[j]));
+        o[4 + j] = f2bf(bf2f(f2bf(b[j])) + bf2f(r[4 + j]));
+      }
+      *reinterpret_cast<u16x8*>(C + off) = o;
+      vb[k] = o;
+      wb[k] = reinterpret_cast<const u16x8*>(w)[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RMS_KEEP; ++k) {
+    if (threadIdx.x + 256 * k < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf2f(vb[k][j]);
+        ss = __builtin_fmaf(f, f, ss);
+      }
+    }
+  }
+  ss = block_sum_256(ss, red);
+  const float rstd = 1.0f / sqrtf(ss / (float)N + eps);
+#pragma unroll
+  for (int k = 0; k < RMS_KEEP; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < nv) {
+      u16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wb[k][j]) * bf2f(f2bf(bf2f(vb[k][j]) * rstd)));
+      reinterpret_cast<u16x8*>(out + (size_t)row * N)[i] = o;
+    }
+  }
+}
+// false: the row is too long to keep in registers (the caller then runs the two launches)
+bool lr_reduce_residual_rmsnorm_fits(int N) { return N % 8 == 0 && N / 8 <= 256 * RMS_KEEP; }
+int lr_launch_reduce_residual_rmsnorm(const float* part, int S, u16* C, const u16* R, int M, int N, const u16* norm_w,
+                                      u16* norm_out, float eps, hipStream_t st) {
+  if (!lr_reduce_residual_rmsnorm_fits(N)) LR_FAIL(LR_EUNSUPPORTED, "fused reduce + RMSNorm: %d columns", N);
+  hipLaunchKernelGGL(reduce_residual_rmsnorm_kernel, dim3(M), dim3(256), 0, st, part, S, (size_t)M * N, C, R, N, norm_w,
+                     norm_out, eps);
+  LR_CHECK_LAUNCH("reduce_residual_rmsnorm_kernel");
+  return LR_OK;
 }
 
 // ---- RMSNorm statistic only (the normalisation itself is folded into the next GEMM, llama_gemm.hip RopeArgs) ------

@@ -726,13 +726,18 @@ static int gemm256_prepare() {
 
 template <int EPI>
 static int launch_splitk(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int S, RopeArgs rope,
-                         float* ws, hipStream_t st) {
+                         float* ws, hipStream_t st, const u16* then_norm_w = nullptr, u16* then_norm_out = nullptr,
+                         float then_norm_eps = 0.f, bool* then_norm_done = nullptr) {
   LrProfScope prof(LR_PROF_GEMM256, 2.0 * M * (double)N * K, st, LR_PROF_GEMM_TAG(EPI, N, K));
   if (int rc = gemm256_prepare<LR_EPI_PARTIAL>()) return rc;
   const int nwg = ((M + 255) / 256) * (N / 256);
   hipLaunchKernelGGL(gemm256rb_kernel<LR_EPI_PARTIAL>, dim3(nwg, S), dim3(512), 2 * G2_STAGE_BYTES, st, A, B,
                      reinterpret_cast<u16*>(ws), nullptr, M, N, K, gemm256_group_m(K), rope);
   LR_CHECK_LAUNCH("gemm256rb_kernel<partial>");
+  if (EPI == LR_EPI_RESIDUAL && then_norm_w && then_norm_out && then_norm_done && lr_reduce_residual_rmsnorm_fits(N)) {
+    *then_norm_done = true;   // the reduce pass also writes RMSNorm(C) for the next projection
+    return lr_launch_reduce_residual_rmsnorm(ws, S, C, R, M, N, then_norm_w, then_norm_out, then_norm_eps, st);
+  }
   const size_t quads = (EPI == LR_EPI_SWIGLU ? (size_t)M * (N >> 1) : (size_t)M * N) / 4;
   hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, ws, S, C, R, M,
                      N, rope);
@@ -797,7 +802,9 @@ extern "C" int lr_debug_gemm_stamps(unsigned long long* out, int n_workgroups) {
 int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int N, int K, int epi,
                    int variant, hipStream_t st, const int32_t* tok_pos, const float* rope_cs, int head_dim,
                    int rot_cols, float* splitk_ws, size_t splitk_ws_bytes, const float* row_scale,
-                   const unsigned* rope_cs16) {
+                   const unsigned* rope_cs16, const u16* then_norm_w, u16* then_norm_out, float then_norm_eps,
+                   bool* then_norm_done) {
+  if (then_norm_done) *then_norm_done = false;
   if (M <= 0) return LR_OK;
   if (N <= 0 || K <= 0) LR_FAIL(LR_EINVAL, "gemm: N=%d K=%d", N, K);
   const bool fast_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 1;
@@ -824,7 +831,9 @@ int lr_launch_gemm(const u16* A, const u16* B, u16* C, const u16* R, int M, int 
                 (size_t)S * M * N * sizeof(float), splitk_ws ? splitk_ws_bytes : (size_t)0);
       switch (epi) {
         case LR_EPI_STORE: return launch_splitk<LR_EPI_STORE>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
-        case LR_EPI_RESIDUAL: return launch_splitk<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
+        case LR_EPI_RESIDUAL:
+          return launch_splitk<LR_EPI_RESIDUAL>(A, B, C, R, M, N, K, S, rope, splitk_ws, st, then_norm_w, then_norm_out,
+                                                then_norm_eps, then_norm_done);
         case LR_EPI_SWIGLU: return launch_splitk<LR_EPI_SWIGLU>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
         case LR_EPI_ROPE: return launch_splitk<LR_EPI_ROPE>(A, B, C, R, M, N, K, S, rope, splitk_ws, st);
       }

@@ -60,7 +60,16 @@ int lr_launch_gemm(const unsigned short* A, const unsigned short* B, unsigned sh
                    int rot_cols = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0,
                    const float* row_scale = nullptr /* rope / swiglu epilogues: accumulator row m times row_scale[m] */,
                    const unsigned* rope_cs16 = nullptr /* the rope table as packed bf16 pairs (lr_launch_rope_table): lets
-                   the 256-tile kernel stage a tile's (cos, sin) rows through LDS instead of 262 KB of half-line loads */);
+                   the 256-tile kernel stage a tile's (cos, sin) rows through LDS instead of 262 KB of half-line loads */,
+                   const unsigned short* then_norm_w = nullptr, unsigned short* then_norm_out = nullptr,
+                   float then_norm_eps = 0.f, bool* then_norm_done = nullptr /* residual epilogue only: the caller runs
+                   RMSNorm(C) with this weight into then_norm_out next. If the product is split over K, its reduce pass
+                   does that too (same bits) and *then_norm_done is set; otherwise it is left false and the caller launches
+                   lr_launch_rmsnorm itself */);
+// split-K reduce (S fp32 planes of M x N) + residual + RMSNorm of the result in one pass (llama_elem.hip)
+bool lr_reduce_residual_rmsnorm_fits(int N);
+int lr_launch_reduce_residual_rmsnorm(const float* part, int S, unsigned short* C, const unsigned short* R, int M, int N,
+                                      const unsigned short* norm_w, unsigned short* norm_out, float eps, hipStream_t st);
 // rstd[m] = 1 / sqrt(mean(x[m][:]^2) + eps), fp32 (the statistic of HF's LlamaRMSNorm)
 int lr_launch_rms_rstd(const unsigned short* x, float* rstd, int rows, int d, float eps, hipStream_t st);
 // out[j][k] = bf16(w[j][k] * norm_w[k]): an RMSNorm weight folded into the following projection's [out][in] matrix

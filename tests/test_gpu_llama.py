@@ -160,6 +160,45 @@ def test_attention_vs_numpy(nh, nkv, hd, variant):
     assert err.max() < 1.5e-2, err.max()  # |out| <= 1 here; bf16 P and bf16 output rounding
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(460, 4096, 4096), (23, 4096, 11008), (700, 4096, 4096), (300, 512, 2048)])
+def test_split_k_reduce_with_fused_rmsnorm_is_bit_identical(M, N, K):
+    """Latency mode: the reduce pass of a split-K o_proj / down_proj can also write the RMSNorm that reads its result
+    (llama_elem.hip, reduce_residual_rmsnorm_kernel). Both outputs -- the new residual rows and the normalised rows --
+    must equal the two-launch form bit for bit, in place (C aliasing R) as the prefill calls it; and the fused pass must
+    really have run where the product is split."""
+    import ctypes as C
+
+    from llamarec_amd._lib import check, lib, stream_ptr
+
+    A = bf16_round(hash_uniform(M + N, (M, K), 1.0))
+    B = bf16_round(hash_uniform(K + 3, (N, K), 0.05))
+    R = bf16_round(hash_uniform(11, (M, N), 2.0))
+    w = bf16_round(1.0 + hash_uniform(5, (N,), 0.3))
+    a, b, wd = dev_bf16(A), dev_bf16(B), dev_bf16(w)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = {}
+    for fuse in (0, 1):
+        c = dev_bf16(R).clone()                    # in place: the residual row is replaced by the new one
+        xn = torch.full((M, N), 0x7FC0, dtype=torch.int16, device="cuda")
+        was = C.c_int32(-1)
+        check(lib().lr_gemm_bf16_nt_residual_rmsnorm(a.data_ptr(), b.data_ptr(), c.data_ptr(), c.data_ptr(), M, N, K, 5,
+                                                     wd.data_ptr(), xn.data_ptr(), 1e-5, fuse, C.byref(was), ws.data_ptr(),
+                                                     ws.numel(), stream_ptr()), "gemm + rmsnorm")
+        torch.cuda.synchronize()
+        outs[fuse] = (c.cpu().numpy().copy(), xn.cpu().numpy().copy(), was.value)
+    split = (N % 256 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 256) <= 128 and (K // 64) // 16 >= 2)
+    assert outs[0][2] == 0 and outs[1][2] == (1 if split else 0), (outs[0][2], outs[1][2], split)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # and the pair is what it says: float64 reference of the product + residual, then the norm of the bf16 result
+    c_ref = bf16_round((A.astype(np.float64) @ B.astype(np.float64).T).astype(np.float32)) + R
+    got_c = host_f32(torch.from_numpy(outs[1][0]))
+    assert np.abs(got_c - c_ref).max() <= 0.02 * max(1.0, np.abs(c_ref).max())
+    rstd = 1.0 / np.sqrt((got_c.astype(np.float64) ** 2).mean(-1, keepdims=True) + 1e-5)
+    xn_ref = w * bf16_round((got_c * rstd).astype(np.float32))
+    assert np.abs(host_f32(torch.from_numpy(outs[1][1])) - xn_ref).max() <= 0.02 * max(1.0, np.abs(xn_ref).max())
+
+
 def load_golden(golden_dir, name):
     z = np.load(os.path.join(golden_dir, f"llama_{name}.npz"))
     cfg = json.loads(str(z["config"]))

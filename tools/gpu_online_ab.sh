@@ -1,6 +1,6 @@
 #!/bin/bash
 # online single-user path: GEMM / llama tests with the current build, then tools/bench_online.py with the previous build
-# (llamarec_amd/lib/libllamarec_old.so) and the current one, and the current one with finer K splits
+# (llamarec_amd/lib/libllamarec_old.so) and the current one, at 460 and 1000 tokens
 set -o pipefail
 OUT=gpurun_out/${1:-online_ab}; mkdir -p $OUT
 L=$(pwd)/llamarec_amd/lib
@@ -10,7 +10,7 @@ rc=$?; tail -3 $OUT/tests.log
 for i in 1 2; do
   echo "== old $i"; LLAMAREC_LIB=$L/libllamarec_old.so timeout -k 10 300 python tools/bench_online.py 2>&1 | grep "online path" || exit 1
   echo "== new $i"; timeout -k 10 300 python tools/bench_online.py 2>&1 | grep "online path" || exit 1
-  for kt in 8 4; do echo "== new, LR_SPLITK_MIN_KT=$kt"; LR_SPLITK_MIN_KT=$kt timeout -k 10 300 python tools/bench_online.py 2>&1 | grep "online path" || exit 1; done
+
 done
 timeout -k 10 300 python tools/bench_online.py --tokens 1000 2>&1 | grep "online path"
 LLAMAREC_LIB=$L/libllamarec_old.so timeout -k 10 300 python tools/bench_online.py --tokens 1000 2>&1 | grep "online path"
