@@ -487,7 +487,9 @@ extern "C" int lr_debug_topk_stamps(unsigned long long* out, int n) {
 // tiles) 0.53 % of 12 086 items = 64 candidates per user against 275 inserts without the bound.
 typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
 
-#define TK_BUSERS 256  // users per workgroup of the pre-pass: 4 waves x 2 MFMA column tiles of 32 users
+#define TK_BUSERS 512  // users per workgroup of the pre-pass: 8 waves x 2 MFMA column tiles of 32 users. Every user tile
+                       // re-reads the packed table (1 M items: 128 MB): 4 096 users are 8 sweeps instead of the 16 of a
+                       // 256-user workgroup, and a tile fetched by one wave is an L1 hit for the seven that follow it
 
 struct BoundParams {
   const unsigned short* emb16;  // bf16 table in A-fragment order [tile][step][lane][8] (lr_lru_pack)
@@ -501,7 +503,7 @@ struct BoundParams {
   int gshift;                   // 0: one maximum per tile (catalogs up to 65 536 items); >= 2: per 4, 8, 16 .. tiles
 };
 
-__global__ __launch_bounds__(256) void item_bound_kernel(BoundParams p) {
+__global__ __launch_bounds__(TK_BUSERS) void item_bound_kernel(BoundParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int tile_begin = blockIdx.x * p.tiles_per_chunk;
@@ -668,13 +670,13 @@ struct CandParams {
   int tiles_per_chunk;
 };
 
-#define TK_CAND_LCAP 48  // candidate slots per user in the workgroup's LDS list (one chunk of tiles: ~3 expected)
+#define TK_CAND_LCAP 24  // candidate slots per user in the workgroup's LDS list (one chunk of tiles: ~3-6 expected; 48 KiB)
 
 // Passing items are collected in LDS (one list per user of the workgroup, LDS atomics only) and appended to the user's
 // global list once per workgroup: a returning global atomic per passing element inside the tile loop cost 4x the
 // scoring itself. Per element the common path is bias add + compare + one bit of a per-lane mask; one wave-uniform
 // branch per 32 x 32 tile handles the lanes that caught something.
-__global__ __launch_bounds__(256) void item_cand_kernel(CandParams p) {
+__global__ __launch_bounds__(TK_BUSERS) void item_cand_kernel(CandParams p) {
   __shared__ int lcnt[TK_BUSERS];
   __shared__ int32_t llist[TK_BUSERS * TK_CAND_LCAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1189,13 +1191,13 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     bw += lr_align_up(((size_t)B + 1) * sizeof(int), 256);
     int32_t* cand = reinterpret_cast<int32_t*>(bw);
     const int n_ut = (B + TK_BUSERS - 1) / TK_BUSERS;
-    int chunks = (2048 + n_ut - 1) / n_ut;                 // ~8 light workgroups per CU
+    int chunks = (1024 + n_ut - 1) / n_ut;                 // ~4 workgroups of 8 light waves per CU
     const int unit = bp.gshift > 2 ? (1 << bp.gshift) : 4;   // a chunk is whole float4 iterations AND whole tile groups
     const int units = (p.n_tiles + unit - 1) / unit;
     if (chunks > units) chunks = units;
     bp.tiles_per_chunk = unit * ((units + chunks - 1) / chunks);
     chunks = (p.n_tiles + bp.tiles_per_chunk - 1) / bp.tiles_per_chunk;
-    hipLaunchKernelGGL(item_bound_kernel, dim3(chunks, n_ut), dim3(256), 0, st, bp);
+    hipLaunchKernelGGL(item_bound_kernel, dim3(chunks, n_ut), dim3(TK_BUSERS), 0, st, bp);
     LR_CHECK_LAUNCH("item_bound_kernel");
 #define TK_SELECT(NS_)                                                                                               \
   hipLaunchKernelGGL(bound_select_kernel<NS_>, dim3((B + 3) / 4), dim3(256), 0, st, bp.tmax, bp.ld, n_groups, q, ids, L, \
@@ -1215,7 +1217,7 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     cp.cand_count = cand_count;
     cp.cand = cand;
     cp.tiles_per_chunk = bp.tiles_per_chunk;
-    hipLaunchKernelGGL(item_cand_kernel, dim3(chunks, n_ut), dim3(256), 0, st, cp);
+    hipLaunchKernelGGL(item_cand_kernel, dim3(chunks, n_ut), dim3(TK_BUSERS), 0, st, cp);
     LR_CHECK_LAUNCH("item_cand_kernel");
     hipLaunchKernelGGL(cand_rescore_kernel, dim3((B + 3) / 4), dim3(256), 0, st, p.emb, p.bias, q, p.hist_sorted, L,
                        p.exclude, B, K, p.n_rows, cand_count, cand, overflow_flag, out_idx, out_score);
