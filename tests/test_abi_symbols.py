@@ -73,6 +73,11 @@ def test_error_reporting_without_gpu():
     sums = np.zeros(3)
     rc = l.lr_metrics_from_histogram(hist.ctypes.data, 4, ks.ctypes.data, 1, sums.ctypes.data)
     assert rc == -1 and b"outside" in l.lr_last_error()
+    # argument checks of device entry points run before anything touches a GPU
+    rc = l.lr_gemm_bf16_nt_residual_rmsnorm(None, None, None, None, 8, 256, 64, 5, None, None, 1e-5, 1, None, None, 0, None)
+    assert rc == -1 and b"null pointer" in l.lr_last_error()
+    rc = l.lr_gemm_bf16_nt_epi(None, None, None, None, 8, 256, 64, 0, 4, None, None, 0, 0, 0, None, 0, None)
+    assert rc == -1 and b"null pointer" in l.lr_last_error()
 
 
 def test_metrics_from_histogram_matches_oracle(golden_dir):
