@@ -25,6 +25,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
   cpu_baseline -- the CPU oracle (a port of the reference algorithm) timed on the host cores on a bounded sample
                   of the same workload (N = 1 only)
   parity       -- GPU vs that oracle on the same sample, outside the timed region (N = 1 only)
+  roofline_item_gemm -- north_star's second roofline: the item GEMM + top-K at the Synth-1M shape (260 MB table, 4 096
+                  users, one retrieve_topk call), timed after a warm-up, outside `value` (N = 1 only)
 """
 from __future__ import annotations
 
@@ -68,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that reuses it)")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the short ML-100k-shape and LoRA-step side measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-item-roofline", action="store_true", help="skip the Synth-1M item-GEMM roofline side field (N = 1)")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to "
                     "rehearse several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -547,12 +550,86 @@ def main():
         out.update(extra)
         if world == 1 and not args.no_other_shapes and args.layers == LLAMA2_7B["num_hidden_layers"]:
             out.update(side_measurements(args, ranker, label_ids, dev, steps, shared))
+        if world == 1 and not args.no_item_roofline:
+            out.update(item_gemm_roofline(dev))
         if world == 1 and not args.no_cpu_baseline:
             n1 = min(len(hist), 512)
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(args.workload, hist[:n1], labels[:n1], T[:4], lru_sd,
                                                                          retriever, dev)
         print(json.dumps(out), flush=True)
     D.barrier()
+
+
+PEAK_HBM_GBPS = 8000.0     # HBM3E spec, MI355X_MICROARCH.md (6 290 GB/s measured for a float4 copy)
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def item_gemm_roofline(dev, users=4096, reps=5):
+    """north_star's second roofline (the item GEMM's meaningful point is Synth-1M, whose 260 MB table does
+    not sit in L2): LRURec at BASELINE.json configs[4]'s shape (V = 1e6, L = 200), `users` histories resident in HBM, ONE
+    `retrieve_topk(ids, 50, exclude_history)` call per repetition, timed after a warm-up call; N = 1, never part of
+    `value`. The item part (history sort, bound -> candidates -> exact rescoring, or the exact f32 pass) and the encoder
+    are separated by the library's own HIP events on the launch stream (lr_profile kinds 5 and 4).
+    Algorithmic work, SURVEY.md 8(d): flops = 2 * 64 * (V + 1) per user; bytes = (V + 1) * 65 * 4 (fp32 table + bias once per
+    call) + B * 64 * 4 (q) + B * L * 8 (ids) + B * 50 * 8 (out). At 4 096 users the intensity is ~2 000 flop per table byte,
+    i.e. MFMA-bound; the exact f32 scores would cost 0.524 TFLOP on the f32 pipe (3.3 ms at its 157 TF/s peak), the library
+    instead bounds every score on the bf16 pipe twice and rescores ~300 candidates per user exactly, so `achieved` =
+    algorithmic flops / item time is priced against the bf16 peak the executed instructions run on, and the f32 and HBM
+    views ride along."""
+    import torch
+
+    from llamarec_amd import _lib
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.synth import WORKLOADS, synth_users
+
+    w = WORKLOADS["synth-1m"]
+    V, L = w["V"], w["L"]
+    hist, _, n_hist, _ = synth_users("synth-1m", users)
+    model = LRURec.from_state_dict(init_lru_state_dict(V, seed=42), device=dev)
+    ids = torch.from_numpy(hist).to(dev)
+    top, _ = model.retrieve_topk(ids, 50, True)          # warm-up (also sizes the workspace)
+    torch.cuda.synchronize()
+    lib = _lib.lib()
+    _lib.check(lib.lr_profile_start(reps * 64), "lr_profile_start")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        top, _ = model.retrieve_topk(ids, 50, True)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    lib.lr_profile_stop()
+
+    def collect(kind):
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        lib.lr_profile_collect(kind, C.byref(ms), C.byref(work), C.byref(n))
+        return ms.value, n.value
+
+    enc_ms, enc_n = collect(4)
+    item_ms, item_n = collect(5)
+    enc_ms, item_ms = enc_ms / reps, item_ms / reps     # per call (a call may record several launches of a kind)
+    top = top.cpu().numpy()
+    # size-independent properties of the result (the bit-exact comparison with the oracle at this size is
+    # tests/test_gpu_lru.py::test_full_size_catalog_properties / test_grouped_bound_catalogs_vs_oracle)
+    distinct = bool(all(len(set(r.tolist())) == 50 for r in top[:: max(1, users // 64)]))
+    no_hist = bool(all(not (set(top[u].tolist()) & set(hist[u].tolist())) for u in range(0, users, max(1, users // 64))))
+    flops = 2.0 * 64 * (V + 1) * users
+    nbytes = (V + 1) * 65 * 4.0 + users * 64 * 4.0 + users * L * 8.0 + users * 50 * 8.0
+    ach = flops / (item_ms * 1e-3) / 1e12
+    del model
+    return {"roofline_item_gemm": {
+        "workload": (f"synth-1m (BASELINE.json configs[4] shape): LRURec(V={V}, L={L}, D=64, 2 blocks), {users} users "
+                     f"(mean history {float(n_hist.mean()):.0f}), one retrieve_topk(ids, 50, exclude_history=1) call, median-free mean of "
+                     f"{reps} calls after one warm-up"),
+        "kernel": "item_bound_kernel + item_cand_kernel (v_mfma_f32_32x32x16_bf16 over the packed bf16 table) -> cand_rescore_kernel (exact f32)",
+        "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+        "flops_alg": flops, "bytes_alg": nbytes, "item_ms": item_ms, "encoder_ms": enc_ms, "call_ms_wall": wall_ms,
+        "users_per_s": users / (wall_ms * 1e-3),
+        "executed_bf16_flops": 2.0 * flops, "executed_bf16_tflops": 2.0 * ach,
+        "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+        "hbm_view": {"achieved_gbps": nbytes / (item_ms * 1e-3) / 1e9, "peak_gbps": PEAK_HBM_GBPS,
+                     "frac": nbytes / (item_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                     "note": "bytes_alg once per call over the item time: the table stream is not what bounds 4 096 users"},
+        "traffic": None,
+        "checks": {"top50_distinct_sampled": distinct, "no_history_item_sampled": no_hist}}}
 
 
 def side_measurements(args, ranker, label_ids, dev, steps, shared):

@@ -64,6 +64,10 @@ extern "C" int lr_lru_pack(const LrLruWeightsDesc* d, void* host_out, size_t hos
     }
     o[L.item_stats + 0] = nextafterf((float)emax, INFINITY);
     o[L.item_stats + 1] = nextafterf((float)bmax, INFINITY);
+    for (size_t r = 0; r < 32; ++r) {   // the last tile's accumulator start values for the bf16 passes (lru_topk.hip, tk_stage_issue)
+      const size_t i = (size_t)L.rows_padded - 32 + r;
+      o[L.item_stats + 32 + r] = i < rows ? d->item_bias[i] : -INFINITY;
+    }
   }
   memcpy(o + L.emb_ln_w, d->emb_ln_w, 64 * sizeof(float));
   memcpy(o + L.emb_ln_b, d->emb_ln_b, 64 * sizeof(float));

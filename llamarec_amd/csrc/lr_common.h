@@ -68,7 +68,9 @@ struct LrLruLayout {
   size_t item_emb;       // [rows_padded][64]
   size_t item_bias;      // [rows_padded]
   size_t item_emb_bf16;  // [rows_padded][64] bfloat16 (round-to-nearest-even copy of item_emb): the top-K bound pre-pass
-  size_t item_stats;     // [0] >= max_i ||item_emb[i]||_2, [1] >= max_i |item_bias[i]|  (rounded up)
+  size_t item_stats;     // [0] >= max_i ||item_emb[i]||_2, [1] >= max_i |item_bias[i]|  (rounded up); [32..63] the biases of the
+                         // table's LAST 32-row tile with -inf on its padding rows (item_bias has NaN there): the bf16 passes'
+                         // accumulator start values, so that a padding row's approximate score is -inf and needs no row test
   size_t emb_ln_w, emb_ln_b;
   LrLruBlockLayout blk[LR_MAX_LRU_BLOCKS];
   size_t total_floats;

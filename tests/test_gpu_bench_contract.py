@@ -35,3 +35,54 @@ def test_bench_line_contract():
         assert k in cb, k
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port")
     assert d["parity"]["ok"] is True and d["metrics"]["retrieve_matches_expected"] is True
+    # north_star's second roofline: the item GEMM at the Synth-1M shape rides in the same line
+    ri = d["roofline_item_gemm"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flops_alg", "bytes_alg", "item_ms", "encoder_ms"):
+        assert k in ri, k
+    assert ri["bound"] in ("hbm", "mfma") and ri["unit"] == "TFLOP/s" and 0.0 < ri["frac"] < 1.0
+    assert abs(ri["frac"] - ri["achieved"] / ri["peak"]) < 1e-9
+    assert abs(ri["flops_alg"] - 2.0 * 64 * 1000001 * 4096) < 1.0 and abs(ri["bytes_alg"] - (1000001 * 260.0 + 4096 * (256 + 1600 + 400))) < 1.0
+    assert abs(ri["achieved"] - ri["flops_alg"] / (ri["item_ms"] * 1e-3) / 1e12) < 1e-6 * ri["achieved"]
+    assert 0.0 < ri["item_ms"] < 50.0 and 0.0 < ri["encoder_ms"] < 50.0
+    assert ri["checks"]["top50_distinct_sampled"] is True and ri["checks"]["no_history_item_sampled"] is True
+
+
+def _run_bench(extra, timeout=900):
+    cmd = [sys.executable, os.path.join(REPO, "bench.py")] + extra
+    return subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_card_over_gloo():
+    """`bench.py --gpus 2`: the parent starts its own two torchrun ranks BEFORE any HIP call (nothing is exec-replaced),
+    relays rank 0's line and exits with the children's code (spawn_ranks). A 1-GPU box rehearses it with both ranks on
+    cuda:0 over gloo (--share-gpu --dist-backend gloo): n_gpus, the all-reduced rank census, both ranks' users in the
+    all-reduced histogram and the planted-label metrics are checked. The driver's 8-GPU run is the same code with nccl."""
+    r = _run_bench(["--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--layers", "2", "--steps", "2", "--warmup", "1",
+                    "--no-other-shapes"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["collective_backend"] == "gloo"
+    per_rank = d["config"]["users_per_step"] * d["steps"]          # rank 0's users in the timed region
+    counted = d["metrics"]["users_counted"]                         # all-reduced over both ranks
+    assert counted > per_rank and abs(counted - 2 * per_rank) <= 0.2 * per_rank, (counted, per_rank)
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - counted) < 1e-6 * counted   # value = ALL ranks' users / time
+    assert d["metrics"]["retrieve_matches_expected"] is True and d["metrics"]["retrieve_NDCG@10"] > 0
+    assert d["roofline"] is not None and 0.0 < d["roofline"]["frac"] < 1.0
+    assert "cpu_baseline" not in d and "roofline_item_gemm" not in d     # N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N on a node with fewer than N cards (and no --share-gpu): exit code 2, a message, NO result line -- a
+    1-GPU number is never reported as n_gpus = N."""
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    r = _run_bench(["--gpus", str(n), "--layers", "2", "--steps", "1", "--warmup", "0", "--no-other-shapes"], timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "refusing" in r.stderr
