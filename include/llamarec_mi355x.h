@@ -118,6 +118,14 @@ int lr_lru_retrieve_topk(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L, 
                          int32_t exclude_history, int32_t* out_idx, float* out_score,
                          void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Diagnostic: which path the LAST lr_lru_retrieve_topk call with exactly these (B, L, K, exclude_history) on this
+ * workspace took -- *out_path = 0: the exact f32 pass over every item (catalogs and history lengths the bound does not
+ * serve), 1: bf16 bound -> candidates -> exact rescoring, 2: that path overflowed a candidate list and the exact pass
+ * redid the call (results are correct either way; 2 is a performance cliff the tests watch for). Synchronises the
+ * stream. No counterpart in the reference (it materialises every score, model/lru.py:85). */
+int lr_lru_topk_path(const lr_lru_t* h, int32_t B, int32_t L, int32_t K, int32_t exclude_history,
+                     const void* workspace, size_t workspace_bytes, int32_t* out_path, void* hip_stream);
+
 /* Compatibility path: materialise last-position scores [B][V+1] (fp32), optionally masked.
  * Replaces `self.model(seqs)[:, -1, :]` for callers that need the full score row
  * (trainer/lru.py:33, demo/inference.py:48). */

@@ -32,6 +32,8 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_lru_retrieve_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lr_lru_topk_path": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_int32), C.c_void_p]),
     "lr_lru_scores_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_rank_histogram": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

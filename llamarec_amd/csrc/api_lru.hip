@@ -185,6 +185,18 @@ extern "C" int lr_lru_retrieve_topk(lr_lru_t* h, const int64_t* ids, int32_t B, 
                              (char*)workspace + q_bytes(B), workspace_bytes - q_bytes(B), st);
 }
 
+extern "C" int lr_lru_topk_path(const lr_lru_t* h, int32_t B, int32_t L, int32_t K, int32_t exclude_history,
+                                const void* workspace, size_t workspace_bytes, int32_t* out_path, void* hip_stream) {
+  if (!h || !workspace || !out_path) LR_FAIL(LR_EINVAL, "lr_lru_topk_path: null argument");
+  if (workspace_bytes < q_bytes(B)) LR_FAIL(LR_EWORKSPACE, "lr_lru_topk_path: workspace too small");
+  int path = 0;
+  const int rc = lr_topk_path(h, B, K, L, exclude_history, (const char*)workspace + q_bytes(B), workspace_bytes - q_bytes(B), &path,
+                              (hipStream_t)hip_stream);
+  if (rc) return rc;
+  *out_path = path;
+  return LR_OK;
+}
+
 extern "C" int lr_lru_scores_last(lr_lru_t* h, const int64_t* ids, int32_t B, int32_t L,
                                   int32_t exclude_history, float* out_scores, void* workspace,
                                   size_t workspace_bytes, void* hip_stream) {

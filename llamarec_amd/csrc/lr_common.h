@@ -133,6 +133,8 @@ size_t lr_encoder_mfma_workspace_bytes(int B, int L);
 int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L, float* out_q, void* ws,
                               size_t ws_bytes, hipStream_t st);
 size_t lr_topk_workspace_bytes(int B, int K, int L, int n_tiles);
+int lr_topk_path(const lr_lru* h, int B, int K, int L, int exclude_history, const void* ws, size_t ws_bytes, int* out_path,
+                 hipStream_t st);
 int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int B, int L, int K,
                         int exclude_history, int32_t* out_idx, float* out_score, void* ws,
                         size_t ws_bytes, hipStream_t st);

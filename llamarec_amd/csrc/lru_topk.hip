@@ -489,195 +489,7 @@ extern "C" int lr_debug_topk_stamps(unsigned long long* out, int n) {
 //      output is bit-identical, and only ~1.2 K items per user pass instead of ~K ln(V / K).
 // A 32-item tile maximum at rank R sits at item quantile ~ 1 - (1 - R / n_tiles)^(1/32): for Beauty (R = 59 of 378
 // tiles) 0.53 % of 12 086 items = 64 candidates per user against 275 inserts without the bound.
-typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
-
-#define TK_BUSERS 512  // users per workgroup of the two bf16 passes: 8 waves x 2 MFMA column tiles of 32 users
-
-// ---- the table stream of the two bf16 passes: global -> LDS by LDS-DMA, shared by the workgroup's 8 waves -------------
-// Rounds 2-3 let every wave fetch its A fragments from global memory (4 KiB per tile and wave, L1 hits for seven of the
-// eight waves): 32 KiB per tile and workgroup through a 64 B/clk L1 = 512 cycles, exactly the 512 cycles the tile's 64
-// MFMAs take on the four SIMDs -- the passes ran at 0.22 of the bf16 MFMA peak with the vector-memory path as busy as the
-// matrix pipe. Now a tile crosses the L1 once per WORKGROUP: the packed tile (4 KiB of fragments, already in MFMA
-// A-fragment order, so the LDS image is lane-linear and its ds_read_b128 are conflict-free) and its 32 biases are
-// DMA'd into a two-stage LDS ring, ST tiles per stage, and every wave reads fragments and biases from LDS
-// (256 B/clk). The bias rides into the product as the MFMA's C operand (accumulator start value = bias of the lane's
-// 16 item rows), so no vector add is spent on it: the approximate score is fl(bias + sum) in whatever order the matrix
-// pipe adds, covered by delta's gamma term over 66 terms (bound_select_kernel). One barrier per stage; the next stage's
-// DMA is issued right behind it and lands while the current one is multiplied.
-// The DMA is inline asm on purpose: issued through the builtin, hipcc counts it as a pending LDS write and drains
-// vmcnt(0) in front of the next ds_read (llama_attn.hip, "the compiler's hidden wait"); the one wait that is needed is
-// written by hand in front of the stage's barrier. M0 is written inside the asm block only (tests/test_isa_checks.py
-// verifies that no compiler-emitted instruction of these kernels reads M0).
-__device__ __forceinline__ void tk_glds16(const void* gsrc, const void* lds_wave_base) {   // 64 lanes x 16 B -> 1 KiB
-  const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
-}
-__device__ __forceinline__ void tk_glds4(const void* gsrc, const void* lds_wave_base) {    // 64 lanes x 4 B -> 256 B
-  const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
-}
-
-template <int ST>
-struct TkStage {
-  static constexpr int FRAG_BYTES = ST * 4096;           // ST tiles x 4 MFMA steps x 64 lanes x 16 B
-  static constexpr int BIAS_BYTES = ST * 128;            // ST tiles x 32 floats
-  static constexpr int BYTES = FRAG_BYTES + BIAS_BYTES;  // 16-byte multiple
-};
-
-// Stage `tile0 .. tile0 + ST` -> `buf`. Tile indices are clamped to the table (a duplicate of the last tile is never
-// CONSUMED by the candidate pass and only repeats a maximum in the bound pass); every wave issues ST / 2 fragment pieces,
-// the first ST / 2 waves one bias piece (2 tiles' biases) each. All 64 lanes are active in every DMA instruction.
-// `bias_tail`: the last tile's 32 biases with -inf instead of NaN on the padding rows (LrLruLayout::item_stats + 32).
-template <int ST>
-__device__ __forceinline__ void tk_stage_issue(const unsigned short* emb16, const float* bias, const float* bias_tail,
-                                               int tile0, int n_tiles, char* buf, int wave, int lane) {
-  static_assert(ST % 2 == 0 && ST * 4 % 8 == 0, "a stage is whole pieces per wave");
-#pragma unroll
-  for (int i = 0; i < ST / 2; ++i) {
-    const int pc = wave + 8 * i;   // piece = (tile of the stage, MFMA step)
-    const int t = min(tile0 + (pc >> 2), n_tiles - 1);
-    tk_glds16(reinterpret_cast<const char*>(emb16) + (size_t)t * 4096 + (pc & 3) * 1024 + lane * 16, buf + pc * 1024);
-  }
-  if (wave < ST / 2) {
-    const int row = min((tile0 + 2 * wave) * 32 + lane, n_tiles * 32 - 1);
-    const int tail0 = (n_tiles - 1) * 32;
-    tk_glds4(row >= tail0 ? bias_tail + (row - tail0) : bias + row, buf + TkStage<ST>::FRAG_BYTES + wave * 256);
-  }
-}
-
-// the users' q rows as MFMA B operands: q[user][k], k = 32 half + 8 s + j for MFMA step s -- the k order of the packed A
-// fragments; any order is as good as another for a sum that only has to be APPROXIMATELY the score. Two column tiles of
-// 32 users per wave share every A fragment. Both passes call this with the same arguments: the same operands.
-__device__ __forceinline__ void tk_load_q_bf16(const float* q, int B, int user0, int col, int half, int user[2],
-                                               tk_bf16x8 bq[2][4]) {
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    user[c] = user0 + c * 32 + col;
-    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)(user[c] < B ? user[c] : 0) * 64 + 32 * half);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 a = qp[2 * s], b = qp[2 * s + 1];
-      bq[c][s][0] = (__bf16)a.x; bq[c][s][1] = (__bf16)a.y; bq[c][s][2] = (__bf16)a.z; bq[c][s][3] = (__bf16)a.w;
-      bq[c][s][4] = (__bf16)b.x; bq[c][s][5] = (__bf16)b.y; bq[c][s][6] = (__bf16)b.z; bq[c][s][7] = (__bf16)b.w;
-    }
-  }
-}
-
-// One 32-item tile against one of the wave's two 32-user column tiles, operands from the LDS stage: acc[4 g + e] =
-// approximate score of item 32 tile + 8 g + 4 half + e for user c * 32 + col. THE instruction sequence both passes share
-// (TkTile::load, then TkTile::scores per column tile).
-struct TkTile {
-  tk_bf16x8 a[4];
-  floatx16 ci;   // the 16 item rows' biases: the accumulator's start value
-  __device__ __forceinline__ void load(const char* tb, const char* bb, int lane, int half) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const tk_bf16x8*>(tb + s * 1024 + lane * 16);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b = *reinterpret_cast<const float4*>(bb + (8 * g + 4 * half) * 4);
-      ci[4 * g] = b.x; ci[4 * g + 1] = b.y; ci[4 * g + 2] = b.z; ci[4 * g + 3] = b.w;
-    }
-  }
-  __device__ __forceinline__ floatx16 scores(const tk_bf16x8 (&bqc)[4]) const {
-    floatx16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bqc[0], ci, 0, 0, 0);
-#pragma unroll
-    for (int s = 1; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bqc[s], acc, 0, 0, 0);
-    return acc;
-  }
-};
-
-// max of the 16 accumulator registers. v_med3_f32(x, y, +inf) = max(x, y) without the `v_max x, x` canonicalisation hipcc
-// puts in front of fmaxf on every MFMA output (IEEE mode); no NaN reaches it (padding rows are replaced first).
-__device__ __forceinline__ float tk_max16(const floatx16& v) {
-  const float inf = __builtin_inff();
-  float m0 = __builtin_amdgcn_fmed3f(v[0], v[1], inf), m1 = __builtin_amdgcn_fmed3f(v[2], v[3], inf);
-  float m2 = __builtin_amdgcn_fmed3f(v[4], v[5], inf), m3 = __builtin_amdgcn_fmed3f(v[6], v[7], inf);
-  m0 = __builtin_amdgcn_fmed3f(m0, v[8], inf);  m1 = __builtin_amdgcn_fmed3f(m1, v[9], inf);
-  m2 = __builtin_amdgcn_fmed3f(m2, v[10], inf); m3 = __builtin_amdgcn_fmed3f(m3, v[11], inf);
-  m0 = __builtin_amdgcn_fmed3f(m0, v[12], inf); m1 = __builtin_amdgcn_fmed3f(m1, v[13], inf);
-  m2 = __builtin_amdgcn_fmed3f(m2, v[14], inf); m3 = __builtin_amdgcn_fmed3f(m3, v[15], inf);
-  return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(m0, m1, inf), __builtin_amdgcn_fmed3f(m2, m3, inf), inf);
-}
-
-struct BoundParams {
-  const unsigned short* emb16;  // bf16 table in A-fragment order [tile][step][lane][8] (lr_lru_pack)
-  const float* bias;            // [rows_padded]
-  const float* bias_tail;       // [32] the last tile's biases, -inf on padding rows
-  int n_rows, n_tiles;
-  const float* q;               // [B][64]
-  int B;
-  float* tmax;                  // [B][ld]: maxima of GROUPS of 2^gshift consecutive tiles
-  int ld;                       // number of groups rounded up to 4
-  int tiles_per_chunk;          // multiple of max(8, 2^gshift)
-  int gshift;                   // 0: one maximum per tile (catalogs up to 65 536 items); >= 2: per 4, 8, 16 .. tiles
-};
-
-#define TK_BOUND_ST 8   // tiles per LDS stage of the bound pass: 2 x 33 KiB -> two workgroups per CU
-
-__global__ __launch_bounds__(TK_BUSERS, 4) void item_bound_kernel(BoundParams p) {
-  constexpr int ST = TK_BOUND_ST;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TkStage<ST>::BYTES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the DMA's LDS base goes through M0 (an SGPR)
-  const int half = lane >> 5, col = lane & 31;
-  const int tile_begin = blockIdx.x * p.tiles_per_chunk;
-  const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
-  if (tile_begin >= tile_end) return;
-  const int n_stages = (tile_end - tile_begin + ST - 1) / ST;
-  tk_stage_issue<ST>(p.emb16, p.bias, p.bias_tail, tile_begin, p.n_tiles, smem, wave, lane);
-  int user[2];
-  tk_bf16x8 bq[2][4];
-  tk_load_q_bf16(p.q, p.B, blockIdx.y * TK_BUSERS + wave * 64, col, half, user, bq);
-  float gm[2] = {-__builtin_inff(), -__builtin_inff()};   // running maximum of the current tile group (gshift >= 2)
-  for (int st = 0; st < n_stages; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage st have landed ...
-    __syncthreads();                                   // ... everyone's have, and everyone is done reading stage st - 1
-    char* const buf = smem + (st & 1) * TkStage<ST>::BYTES;
-    if (st + 1 < n_stages)
-      tk_stage_issue<ST>(p.emb16, p.bias, p.bias_tail, tile_begin + (st + 1) * ST, p.n_tiles, smem + ((st + 1) & 1) * TkStage<ST>::BYTES,
-                         wave, lane);
-#pragma unroll 1
-    for (int u4 = 0; u4 < ST; u4 += 4) {
-      const int t4 = tile_begin + st * ST + u4;
-      if (t4 >= tile_end) break;   // wave-uniform (tile_begin and tiles_per_chunk are multiples of 4)
-      // four tiles per pass of this loop, one at a time (unrolled, hipcc requests all four tiles' fragments first: 149
-      // VGPRs against the 128 that two workgroups per CU leave a wave); their maxima collect in a float4 by selects
-      float4 m4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-#pragma unroll 1
-      for (int u = 0; u < 4; ++u) {
-        TkTile tl;   // tiles past the table are the DMA's duplicates of the last tile: they repeat its maximum
-
-        tl.load(buf + (u4 + u) * 4096, buf + TkStage<ST>::FRAG_BYTES + (u4 + u) * 128, lane, half);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const floatx16 acc = tl.scores(bq[c]);   // padding rows of the last tile: -inf (their accumulator start value)
-          float m = tk_max16(acc);
-          m = __builtin_amdgcn_fmed3f(m, __shfl_xor(m, 32, 64), __builtin_inff());   // the other lane half holds the tile's other 16 items
-          m4[c].x = u == 0 ? m : m4[c].x;
-          m4[c].y = u == 1 ? m : m4[c].y;
-          m4[c].z = u == 2 ? m : m4[c].z;
-          m4[c].w = u == 3 ? m : m4[c].w;
-        }
-      }
-      if (p.gshift == 0) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-          if (user[c] < p.B && half == 0)
-            *reinterpret_cast<float4*>(p.tmax + (size_t)user[c] * p.ld + t4) = m4[c];
-      } else {   // groups of 2^gshift >= 4 tiles (chunks start on group boundaries): one maximum per group
-        const bool last_of_group = (((t4 + 4) >> p.gshift) != (t4 >> p.gshift)) || t4 + 4 >= tile_end;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          gm[c] = fmaxf(gm[c], fmaxf(fmaxf(m4[c].x, m4[c].y), fmaxf(m4[c].z, m4[c].w)));
-          if (last_of_group) {
-            if (user[c] < p.B && half == 0) p.tmax[(size_t)user[c] * p.ld + (t4 >> p.gshift)] = gm[c];
-            gm[c] = -__builtin_inff();
-          }
-        }
-      }
-    }
-  }
-}
+#include "lru_topk_bf16.h"
 
 #define TK_BOUND_MAX_TILES 2048  // 32 maxima per lane in bound_select_kernel: one per tile for catalogs up to 65 536 items,
                                  // one per group of 2^gshift tiles beyond (bound_group_shift): the R-th largest GROUP maximum
@@ -756,105 +568,6 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const float* tmax, in
 // those EXACTLY -- lr_item_score's fmaf chain, the bits of the oracle and of item_topk_kernel -- drops masked ids and
 // ranks them. If any user's list overflows TK_CAND_CAP (degenerate data: thousands of near-equal scores) a device flag
 // turns on the exact full pass (item_topk_kernel + merge, launched behind it with run_flag) for the whole call.
-#define TK_CAND_CAP 1024  // candidate slots per user (1 M items: ~270 above the bound + ~40 % in the 2 delta band)
-
-struct CandParams {
-  const unsigned short* emb16;
-  const float* bias;
-  const float* bias_tail;
-  int n_tiles;
-  const float* q;
-  int B;
-  const float* cand_thresh;  // [B]
-  int* cand_count;           // [B]
-  int32_t* cand;             // [B][TK_CAND_CAP] item ids
-  int tiles_per_chunk;
-};
-
-#define TK_CAND_ST 4      // tiles per LDS stage of the candidate pass (2 x 16.5 KiB)
-#define TK_CAND_LCAP 40   // candidate slots per user in the workgroup's LDS list, 16-bit offsets from the chunk's first item
-                          // (40 KiB; with the stage ring and the counters 75 KiB: two workgroups per CU). A chunk is at
-                          // most TK_CAND_CHUNK_TILES tiles (lr_launch_item_topk), so ~1 000 candidates per user at 1 M
-                          // items are ~16 per chunk at worst and ~5 typically; an overflowing list turns on the exact pass
-#define TK_CAND_CHUNK_TILES 512   // x 32 items = 16 384 < 65 536 offsets
-
-// Passing items are collected in LDS (one list per user of the workgroup, LDS atomics only) and appended to the user's
-// global list once per workgroup: a returning global atomic per passing element inside the tile loop cost 4x the
-// scoring itself. The common path of a (tile, column tile) is the 16-register maximum and one wave-uniform branch; only
-// when some lane's maximum reaches its user's threshold (~ a third of the column tiles at 1 M items) are the 16
-// registers compared one by one. Same operands, same instruction sequence (TkTile) as item_bound_kernel: the
-// same approximate scores.
-__global__ __launch_bounds__(TK_BUSERS, 4) void item_cand_kernel(CandParams p) {
-  constexpr int ST = TK_CAND_ST;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TkStage<ST>::BYTES + TK_BUSERS * 4 + TK_BUSERS * TK_CAND_LCAP * 2];
-  int* const lcnt = reinterpret_cast<int*>(smem + 2 * TkStage<ST>::BYTES);
-  unsigned short* const llist = reinterpret_cast<unsigned short*>(smem + 2 * TkStage<ST>::BYTES + TK_BUSERS * 4);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the DMA's LDS base goes through M0 (an SGPR)
-  const int half = lane >> 5, col = lane & 31;
-  const int tile_begin = blockIdx.x * p.tiles_per_chunk;
-  const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
-  if (tile_begin >= tile_end) return;
-  const int n_stages = (tile_end - tile_begin + ST - 1) / ST;
-  tk_stage_issue<ST>(p.emb16, p.bias, p.bias_tail, tile_begin, p.n_tiles, smem, wave, lane);
-  lcnt[tid] = 0;
-  int user[2];
-  float thr[2];
-  tk_bf16x8 bq[2][4];
-  tk_load_q_bf16(p.q, p.B, blockIdx.y * TK_BUSERS + wave * 64, col, half, user, bq);
-#pragma unroll
-  for (int c = 0; c < 2; ++c) thr[c] = user[c] < p.B ? p.cand_thresh[user[c]] : __builtin_inff();
-  for (int st = 0; st < n_stages; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    char* const buf = smem + (st & 1) * TkStage<ST>::BYTES;
-    if (st + 1 < n_stages)
-      tk_stage_issue<ST>(p.emb16, p.bias, p.bias_tail, tile_begin + (st + 1) * ST, p.n_tiles, smem + ((st + 1) & 1) * TkStage<ST>::BYTES,
-                         wave, lane);
-#pragma unroll
-    for (int u = 0; u < ST; ++u) {
-      const int tile = tile_begin + st * ST + u;
-      if (tile >= tile_end) break;   // wave-uniform
-      TkTile tl;
-      tl.load(buf + u * 4096, buf + TkStage<ST>::FRAG_BYTES + u * 128, lane, half);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const floatx16 acc = tl.scores(bq[c]);
-        const bool hot = tk_max16(acc) >= thr[c];
-        if (__ballot(hot) != 0ull) {   // wave-uniform
-          unsigned mask = 0u;   // bit 4 g + e: the item of accumulator register 4 g + e passed (padding rows: -inf; should a user
-                                // have no bound, threshold -inf, its list overflows and the exact pass takes over)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mask |= (acc[r] >= thr[c] ? 1u : 0u) << r;
-          if (mask) {
-            const int ul = wave * 64 + c * 32 + col;
-            int slot = atomicAdd(&lcnt[ul], __popc(mask));   // the user's two lane halves share the counter
-            const int off0 = (tile - tile_begin) * 32 + 4 * half;
-            do {
-              const int idx = __ffs(mask) - 1;
-              mask &= mask - 1u;
-              if (slot < TK_CAND_LCAP) llist[ul * TK_CAND_LCAP + slot] = (unsigned short)(off0 + 8 * (idx >> 2) + (idx & 3));
-              ++slot;
-            } while (mask);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  {  // thread = one user of the workgroup: reserve room in the global list once, copy
-    const int gu = blockIdx.y * TK_BUSERS + tid;
-    const int n = lcnt[tid];
-    if (gu < p.B && n > 0) {
-      // an overflowing LDS list is reported as an overflowing global count: cand_rescore_kernel then raises the flag
-      const int base = atomicAdd(p.cand_count + gu, n > TK_CAND_LCAP ? TK_CAND_CAP + 1 : n);
-      const int m = min(n, TK_CAND_LCAP);
-      for (int i = 0; i < m; ++i)
-        if (base + i < TK_CAND_CAP) p.cand[(size_t)gu * TK_CAND_CAP + base + i] = tile_begin * 32 + (int)llist[tid * TK_CAND_LCAP + i];
-    }
-  }
-}
-
 // One wave per user: exact scores of the candidates, masked ids dropped, rank by counting, ordered top-K written.
 __global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, const float* bias, const float* q,
                                                            const int32_t* hist_sorted, int L, int exclude, int B, int K,
@@ -1294,20 +1007,20 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     overflow_flag = cand_count + B;
     bw += lr_align_up(((size_t)B + 1) * sizeof(int), 256);
     int32_t* cand = reinterpret_cast<int32_t*>(bw);
-    const int n_ut = (B + TK_BUSERS - 1) / TK_BUSERS;
+    const int upw = lr_bf16_users_per_wg(B);
+    const int n_ut = (B + upw - 1) / upw;
     int chunks = (1024 + n_ut - 1) / n_ut;                 // two rounds of the 512 resident workgroups (two per CU)
-    // ... but never more than TK_CAND_CHUNK_TILES tiles per chunk, however many user tiles there are: the candidate
-    // pass's per-chunk LDS lists hold TK_CAND_LCAP entries per user with 16-bit offsets (16 k users
-    // used to get 32 chunks of ~1 000 tiles at 1 M items, ~12 expected candidates per user and chunk against 24 slots)
-    const int min_chunks = (p.n_tiles + TK_CAND_CHUNK_TILES - 1) / TK_CAND_CHUNK_TILES;
+    // ... but never more than lr_bf16_max_chunk_tiles(B) tiles per chunk, however many user tiles there are: the candidate
+    // pass's per-chunk LDS lists hold 20-40 entries per user with 16-bit offsets (16 k users used to get
+    // 32 chunks of ~1 000 tiles at 1 M items, ~12 expected candidates per user and chunk against 24 slots)
+    const int min_chunks = (p.n_tiles + lr_bf16_max_chunk_tiles(B) - 1) / lr_bf16_max_chunk_tiles(B);
     if (chunks < min_chunks) chunks = min_chunks;
     const int unit = bp.gshift > 2 ? (1 << bp.gshift) : 4;   // a chunk is whole float4 iterations AND whole tile groups
     const int units = (p.n_tiles + unit - 1) / unit;
     if (chunks > units) chunks = units;
     bp.tiles_per_chunk = unit * ((units + chunks - 1) / chunks);
     chunks = (p.n_tiles + bp.tiles_per_chunk - 1) / bp.tiles_per_chunk;
-    hipLaunchKernelGGL(item_bound_kernel, dim3(chunks, n_ut), dim3(TK_BUSERS), 0, st, bp);
-    LR_CHECK_LAUNCH("item_bound_kernel");
+    if (int rc = lr_launch_item_bound(bp, chunks, st)) return rc;
 #define TK_SELECT(NS_)                                                                                               \
   hipLaunchKernelGGL(bound_select_kernel<NS_>, dim3((B + 3) / 4), dim3(256), 0, st, bp.tmax, bp.ld, n_groups, q, ids, L, \
                      p.n_rows, p.exclude, B, K, h->img + h->lay.item_stats, thresh, cand_thresh, cand_count, overflow_flag)
@@ -1327,8 +1040,7 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     cp.cand_count = cand_count;
     cp.cand = cand;
     cp.tiles_per_chunk = bp.tiles_per_chunk;
-    hipLaunchKernelGGL(item_cand_kernel, dim3(chunks, n_ut), dim3(TK_BUSERS), 0, st, cp);
-    LR_CHECK_LAUNCH("item_cand_kernel");
+    if (int rc = lr_launch_item_cand(cp, chunks, st)) return rc;
     hipLaunchKernelGGL(cand_rescore_kernel, dim3((B + 3) / 4), dim3(256), 0, st, p.emb, p.bias, q, p.hist_sorted, L,
                        p.exclude, B, K, p.n_rows, cand_count, cand, overflow_flag, out_idx, out_score);
     LR_CHECK_LAUNCH("cand_rescore_kernel");
@@ -1365,6 +1077,31 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
   else
     hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, st, m);
   LR_CHECK_LAUNCH("topk_merge_kernel");
+  return LR_OK;
+}
+
+// Which path the LAST lr_launch_item_topk call with exactly these (B, K, L) on this workspace took: 0 = the exact full
+// pass (the bound does not serve this shape), 1 = bound -> candidates -> exact rescoring, 2 = that path overflowed a
+// candidate list and the exact full pass redid the call. Reads the call's overflow flag where the call carved it.
+int lr_topk_path(const lr_lru* h, int B, int K, int L, int exclude_history, const void* ws, size_t ws_bytes, int* out_path,
+                 hipStream_t st) {
+  const int n_tiles = h->lay.rows_padded / LR_ITEM_TILE;
+  if (!bound_enabled(n_tiles, K, L) || B <= 0) {
+    *out_path = 0;
+    return LR_OK;
+  }
+  int n_chunks, tpc;
+  topk_geometry(n_tiles, B, true, &n_chunks, &tpc);
+  const size_t need_partial = lr_align_up((size_t)B * n_chunks * K * sizeof(unsigned long long), 256);
+  const size_t need_hist = exclude_history ? lr_align_up((size_t)B * L * sizeof(int32_t), 256) : 0;
+  if (need_partial + need_hist + bound_bytes(B, n_tiles) > ws_bytes) LR_FAIL(LR_EWORKSPACE, "lr_topk_path: workspace too small");
+  const size_t ld = lr_align_up((size_t)bound_groups(n_tiles), 4);
+  const char* bw = reinterpret_cast<const char*>(ws) + need_partial + need_hist + lr_align_up((size_t)B * ld * sizeof(float), 256) +
+                   2 * lr_align_up((size_t)B * sizeof(float), 256);
+  int flag = 0;
+  LR_CHECK_HIP(hipMemcpyAsync(&flag, reinterpret_cast<const int*>(bw) + B, sizeof(int), hipMemcpyDeviceToHost, st));
+  LR_CHECK_HIP(hipStreamSynchronize(st));
+  *out_path = flag ? 2 : 1;
   return LR_OK;
 }
 

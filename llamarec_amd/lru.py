@@ -220,6 +220,18 @@ class LRURec:
                                              stream_ptr()), "lr_lru_retrieve_topk")
         return idx, sc
 
+    def last_topk_path(self, B, L, k, exclude_history=True):
+        """Diagnostic (lr_lru_topk_path): which path the last retrieve_topk call of exactly this shape took -- 0 exact full
+        pass, 1 bound -> candidates -> rescoring, 2 that path overflowed and the exact pass redid the call."""
+        import ctypes as C
+
+        ws = self._workspace(B, k, L)
+        out = C.c_int32(-1)
+        with torch.cuda.device(self.device):
+            check(lib().lr_lru_topk_path(self._h, B, L, k, int(bool(exclude_history)), ws.data_ptr(), ws.numel(), C.byref(out),
+                                         stream_ptr()), "lr_lru_topk_path")
+        return int(out.value)
+
     def forward(self, x):
         """Reference-compatible call: returns fp32 [B, 1, V+1] holding the LAST position's scores,
         so the reference idiom `model(seqs)[:, -1, :]` (trainer/lru.py:33,67,105,

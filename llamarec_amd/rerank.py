@@ -71,6 +71,7 @@ class LLMEvaluator:
             # shard FIRST (by the title-cache estimate of every prompt's tokens), tokenise only this rank's users, in a
             # producer thread that stays ahead of the GPU loop
             lo, hi = PK.shard_by_tokens(self.items.estimate_lengths(), world)[rank]
+            self._shard = (lo, hi)
             if self.token_budget:
                 stream = stream_token_budget_batches(self.items, lo, hi, self.token_budget, self.max_text_len,
                                                      self.max_prompts)
@@ -84,6 +85,7 @@ class LLMEvaluator:
         # contiguous shards balanced by prompt TOKENS, then token-budget batches inside the shard
         lens = np.array([min(len(it["input_ids"]), self.max_text_len) for it in self.items], dtype=np.int64)
         lo, hi = PK.shard_by_tokens(lens, world)[rank]
+        self._shard = (lo, hi)
         mine = self.items[lo:hi]
         if self.token_budget:
             # the prompts' common template prefix is run once per batch (llm.prefill_verbalize): budget the rows it leaves
@@ -105,7 +107,16 @@ class LLMEvaluator:
     def _finish(self, hist, t0):
         from . import dist as D
 
+        # every rank cut its own shard (the lazy path from its own least-squares estimate of the prompt lengths): the
+        # shards must tile the items exactly and the all-reduced histogram must count every user once, or a rounding
+        # difference between nodes would silently drop or double-count users
+        lo, hi = getattr(self, "_shard", (0, len(self.items)))
+        cover = torch.tensor([hi - lo], dtype=torch.int64, device=hist.device)
+        D.all_reduce_sum_(cover)
         D.all_reduce_sum_(hist)
+        if int(cover.item()) != len(self.items) or int(hist.sum().item()) != len(self.items):
+            raise RuntimeError(f"rerank shards cover {int(cover.item())} and the rank histogram counts {int(hist.sum().item())} "
+                               f"of {len(self.items)} users: the ranks derived different shard edges")
         m = M.metrics_from_histogram(hist, self.ks) if len(self.items) else {}
         out = {"test_" + k: v for k, v in m.items()}
         out["test_loss"] = -1.0  # model/llm.py:128-129: eval loss is the constant -1
@@ -230,13 +241,16 @@ def stream_token_budget_batches(items, lo, hi, token_budget, max_text_len, max_p
 
     def produce():
         try:
-            pending, shared = [], None
+            pending = []
             for c0 in range(lo, hi, chunk):
                 pending += items.build(c0, min(c0 + chunk, hi))
                 last = c0 + chunk >= hi
                 seqs_all = [np.asarray(it["input_ids"][-max_text_len:], dtype=np.int32) for it in pending]
-                if shared is None:
-                    shared = common_prefix_len(*pack_prompts(seqs_all)) if len(seqs_all) > 1 else 0
+                # the budgeted prefix is THIS pool's (measured once on the first chunk, a later pool with a
+                # left-truncated prompt -- which has lost the template -- was budgeted with a prefix its batches do not have
+                # and ran up to (n - 1) * P rows over the token budget); prefill_verbalize shares the prefix of each
+                # emitted batch, a subset of the pool, so the pool's common prefix never over-promises
+                shared = common_prefix_len(*pack_prompts(seqs_all)) if len(seqs_all) > 1 else 0
                 lens = np.array([len(s) for s in seqs_all], dtype=np.int64)
                 sp = shared if len(lens) and shared < int(lens.min()) else 0
                 steps = PK.token_budget_steps(lens, max(token_budget, int(lens.max())), shared_prefix=sp,

@@ -183,6 +183,37 @@ def test_full_size_catalog_properties():
     assert np.array_equal(oi, i50n[pick]) and np.array_equal(osc, s50n[pick])
 
 
+def test_many_users_on_the_full_size_catalog_keep_the_candidate_path():
+    """at 1 M items the candidate pass's chunk count used to shrink with the number of user tiles
+    (chunks = 1024 / n_ut): 16 384 users got 32 chunks of ~1 000 tiles, ~12 expected candidates per user and chunk against
+    24 LDS slots, so some list overflowed on essentially every call and the exact full pass redid it -- correct results, a
+    performance cliff above the measured 4 096-user point. Chunks are now at most 512 tiles whatever the batch
+    (lr_bf16_max_chunk_tiles); lr_lru_topk_path reports which path a call took. 16 384 users (L = 50 keeps the encoder
+    short): path 1, and a user's list equals the one it gets in a 300-user call (and, for four users, the oracle's)."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from llamarec_amd.synth import synth_users
+    from oracle import lru_oracle as O
+
+    V, U, L = 1_000_000, 16384, 50
+    hist = synth_users("synth-1m", U)[0][:, -L:]
+    sd = init_lru_state_dict(V, seed=42)
+    model = LRURec.from_state_dict(sd)
+    ids = torch.from_numpy(np.ascontiguousarray(hist)).cuda()
+    i50, s50 = model.retrieve_topk(ids, 50, True)
+    assert model.last_topk_path(U, L, 50, True) == 1          # no candidate list overflowed
+    small_i, small_s = model.retrieve_topk(ids[5000:5300], 50, True)
+    assert model.last_topk_path(300, L, 50, True) == 1
+    assert torch.equal(small_i, i50[5000:5300]) and torch.equal(small_s, s50[5000:5300])
+    pick = [0, 4097, 9999, 16383]
+    oi, osc = O.LruOracle(sd).retrieve_topk(np.ascontiguousarray(hist[pick]), 50, True)
+    assert np.array_equal(oi, i50.cpu().numpy()[pick]) and np.array_equal(osc, s50.cpu().numpy()[pick])
+    # shapes the bound does not serve report path 0 (ML-100k: 200-id histories against 115 tiles)
+    small = LRURec.from_state_dict(init_lru_state_dict(3650, seed=1))
+    h2 = torch.from_numpy(synth_users("ml-100k", 32)[0]).cuda()
+    small.retrieve_topk(h2, 20, True)
+    assert small.last_topk_path(32, h2.shape[1], 20, True) == 0
+
+
 @pytest.mark.parametrize("V,L", [(100_000, 50), (70_003, 200), (262_144, 20)])
 def test_grouped_bound_catalogs_vs_oracle(V, L):
     """Catalogs beyond 65 536 items (2 048 tiles) keep one approximate maximum per group of 4 / 8 / 16 tiles; the proof of
@@ -258,6 +289,11 @@ def test_candidate_path_adversarial(variant):
         top_unmasked, _ = orc.retrieve_topk(ids, 50, False)
         ids = np.where(top_unmasked == 0, 1, top_unmasked).astype(np.int64)   # (history ids: 0 is the pad)
     idx, sc = model.retrieve_topk(ids, K, excl)
+    # the overflow hand-over really happened where it was provoked, and only there (lr_lru_topk_path)
+    # (no_exclude_k7 scales ONE row by 30: the bound's delta is proportional to the table's largest row norm, so its
+    # candidate threshold sinks below most of the catalog and the lists may overflow too -- either path is legitimate)
+    path = model.last_topk_path(B, L, K, excl)
+    assert path == 2 if variant == "all_equal" else path in ((1, 2) if variant == "no_exclude_k7" else (1,)), path
     oi, os_ = orc.retrieve_topk(ids, K, excl)
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(_bits(sc.cpu().numpy()), _bits(os_))

@@ -1,0 +1,84 @@
+"""Build-time checks on the gfx950 ISA of the kernels that issue LDS-DMA from inline asm.
+
+`fa_glds16` / `fa_dma16` (llama_attn.hip), `ab_glds16` (llama_attn_bwd.hip) and `tk_glds16` / `tk_glds4`
+(lru_topk_bf16.hip) write M0 inside an asm block that does not (cannot: M0 is a reserved register for hipcc's inline
+asm) declare the clobber, and they are invisible to hipcc's vmcnt tracking. That is correct as long as
+  (1) no compiler-emitted instruction of those kernels depends on M0 -- every M0 write is the asm block's own
+      `s_mov_b32 m0, sN`, followed (after its s_nop) by the LDS-DMA instruction it serves, and nothing else reads M0
+      (no s_movrel / v_movrel / s_set_gpr_idx, no LDS-DMA issued through the builtin in the same kernel);
+  (2) every LDS-DMA is waited for by hand before the data is read by another wave: walking back from any s_barrier of
+      such a kernel an `s_waitcnt vmcnt(N)` is met before any LDS-DMA instruction.
+A violation would be silent data corruption, not a build error; this test disassembles what the Makefile builds and
+checks both statements per kernel. Runs without a GPU (hipcc cross-compiles)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "llamarec_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function"]
+FILES = {"llama_attn.hip": [], "llama_attn_bwd.hip": [], "lru_topk_bf16.hip": ["-fno-honor-nans"]}
+
+DMA = re.compile(r"^\s*(global_load_lds_\w+|buffer_load_\w+ .*\blds\b)")
+M0_USERS = re.compile(r"^\s*(s_movrel\w*|v_movrel\w*|s_set_gpr_idx\w*|ds_gws_\w+|s_sendmsg\w*)\b")
+
+
+def _kernels(asm_text):
+    """{kernel symbol: [instruction lines]} for every .amdhsa_kernel of the module."""
+    names = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", asm_text, flags=re.M)
+    out = {}
+    for n in names:
+        m = re.search(r"^%s:[^\n]*\n(.*?)^\s*s_endpgm" % re.escape(n), asm_text, flags=re.M | re.S)
+        assert m, n
+        body = []
+        for ln in m.group(1).splitlines():
+            ln = ln.split(";")[0].rstrip()
+            if ln.strip() and not ln.strip().startswith(".") and not ln.strip().endswith(":"):
+                body.append(ln.strip())
+        out[n] = body
+    return out
+
+
+@pytest.mark.parametrize("src", sorted(FILES))
+def test_inline_asm_lds_dma_kernels_keep_m0_and_vmcnt_by_hand(src, tmp_path):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC] + FLAGS + FILES[src] + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+                   check=True, capture_output=True, cwd=CSRC)
+    kernels = _kernels(out.read_text())
+    assert kernels, src
+    checked = 0
+    for name, body in kernels.items():
+        dma_at = [i for i, ln in enumerate(body) if DMA.match(ln)]
+        if not dma_at:
+            # a kernel without LDS-DMA must not touch M0 at all (nothing of ours needs it)
+            assert not any(re.search(r"\bm0\b", ln) for ln in body), (src, name)
+            continue
+        checked += 1
+        # (1) every instruction that names M0 is `s_mov_b32 m0, sN` and serves an LDS-DMA within the next 3 instructions
+        for i, ln in enumerate(body):
+            assert not M0_USERS.match(ln), (src, name, ln)
+            if re.search(r"\bm0\b", ln):
+                assert re.match(r"s_mov_b32 m0, s\d+$", ln), (src, name, ln)
+                nxt = body[i + 1:i + 4]
+                assert any(DMA.match(x) for x in nxt), (src, name, ln, nxt)
+                assert all(DMA.match(x) or x.startswith("s_nop") for x in nxt[:[bool(DMA.match(x)) for x in nxt].index(True) + 1]), \
+                    (src, name, nxt)
+        # ... and every LDS-DMA has its own M0 write right in front of it (the asm block's, not a hoisted one)
+        for i in dma_at:
+            prev = body[max(0, i - 3):i]
+            assert any(re.match(r"s_mov_b32 m0, s\d+$", x) for x in prev), (src, name, body[i], prev)
+        # (2) hipcc does not know these DMAs, so none of ITS waits is there for them: walking back from every s_barrier
+        # of such a kernel, an `s_waitcnt ... vmcnt(N)` must come before any LDS-DMA does (text order: inside a loop body
+        # the stage's wait stands in front of the barrier and the next stage's DMAs behind it)
+        for i, ln in enumerate(body):
+            if ln.startswith("s_barrier"):
+                for x in reversed(body[:i]):
+                    if re.match(r"s_waitcnt\b.*vmcnt\(\d+\)", x):
+                        break
+                    assert not DMA.match(x), (src, name, "an LDS-DMA reaches an s_barrier without a vmcnt wait in between", x)
+    assert checked >= 1, src
