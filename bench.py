@@ -307,8 +307,12 @@ def pmc_traffic(shapes):
         per_shape[k] = {"hbm_side_bytes_per_launch": b, "algorithmic_bytes_per_launch": alg, "ratio": b / alg}
         num += b * v["launches"]
         den += v["launches"]
-    src = (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on "
-           f"a 2-layer slice; per-epilogue bytes weighted by this run's launch mix of the full-row products; not collected by this run)")
+    import hashlib
+
+    sha = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    src = (f"profiles/{os.path.basename(path)} sha256:{sha} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command "
+           f"on a 2-layer slice; per-epilogue bytes weighted by this run's launch mix of the full-row products; not collected by "
+           f"this run: the hash names the committed file the figure was read from)")
     return (num / den if den else None), src, per_shape
 
 

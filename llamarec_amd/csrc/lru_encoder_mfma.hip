@@ -410,6 +410,12 @@ __global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     EM_STAMP(3);
 
     if (HAS_A) {
+      // The two waves of a SIMD (w and w + 4) would run chain -> epilogue -> chain -> epilogue in lockstep: both chains
+      // share the matrix pipe at half rate, then both epilogues (GELU: ~25 vector instructions per value) share the
+      // vector ALU while the pipe idles. With the second-dispatched half at priority 1 its chain takes the pipe first and
+      // the partner's follows while the first wave is in its epilogue: chain | chain || epilogue | ... instead of
+      // (chain + chain) | (epilogue + epilogue).
+      if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float a[32];  // token row t*32 + col, 32 de-interleaved values of my half
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           }
         }
       }
+      if (wave >= 4) __builtin_amdgcn_s_setprio(0);
       EM_STAMP(4);
       EM_BARRIER();
       EM_STAMP(5);
@@ -479,6 +486,72 @@ __global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           h_r0 = h_r1 = h_i0 = h_i1 = 0.f;  // overwritten by the segment's first row
         }
         float* base = ul + sc_pos;
+        // one recurrence step on the lane's two complex channels (the oracle's fmaf order), then the row's hand-over:
+        // MODE 0 writes the state back over the row, MODE 2 emits it where a user ends
+#define EM_SCAN_STEP(t_, bre_, bim_, is_first_)                                                        \
+  {                                                                                                    \
+    if (is_first_) {                                                                                   \
+      h_r0 = (bre_).x; h_r1 = (bre_).y; h_i0 = (bim_).x; h_i1 = (bim_).y;                             \
+    } else {                                                                                           \
+      const float nr0 = lr_fma(lam_r0, h_r0, lr_fma(-lam_i0, h_i0, (bre_).x));                         \
+      const float ni0 = lr_fma(lam_r0, h_i0, lr_fma(lam_i0, h_r0, (bim_).x));                          \
+      const float nr1 = lr_fma(lam_r1, h_r1, lr_fma(-lam_i1, h_i1, (bre_).y));                         \
+      const float ni1 = lr_fma(lam_r1, h_i1, lr_fma(lam_i1, h_r1, (bim_).y));                          \
+      h_r0 = nr0; h_i0 = ni0; h_r1 = nr1; h_i1 = ni1;                                                  \
+    }                                                                                                  \
+    if (MODE == 0) {                                                                                   \
+      *reinterpret_cast<float2*>(base + (t_) * EM_US) = make_float2(h_r0, h_r1);                       \
+      *reinterpret_cast<float2*>(base + (t_) * EM_US + 128) = make_float2(h_i0, h_i1);                 \
+    } else if ((lasts >> (t_)) & 1) {                                                                  \
+      float* o = p.OUT + (size_t)(tags[(t_)] >> 2) * 256;                                              \
+      o[sc_k] = h_r0;                                                                                  \
+      o[sc_k + 2] = h_r1;                                                                              \
+      o[128 + sc_k] = h_i0;                                                                            \
+      o[128 + sc_k + 2] = h_i1;                                                                        \
+    }                                                                                                  \
+  }
+        // users' first rows strictly inside the segment (a segment STARTS at a first row or continues the previous tile)
+        const unsigned long long upto = sb >= 64 ? ~0ull : ((1ull << sb) - 1ull);
+        const unsigned long long inner_firsts = firsts & upto & ~((2ull << sa) - 1ull);
+        if (inner_firsts == 0ull) {
+          // ONE user from sa to sb (long histories: Synth-1M's 110-row users fill whole tiles, and this wave then walks
+          // all 64 rows alone while seven waves and the matrix pipe wait -- 7.8 k of a tile's 31.7 k cycles with the loop
+          // below, tools/em_stamps.py). No per-row first test, and the next four rows' operands are requested before the
+          // current four are stepped through, so the chain waits for fmas only. Same operations in the same order.
+          int t = sa;
+          {
+            const float2 b_re = *reinterpret_cast<const float2*>(base + t * EM_US);
+            const float2 b_im = *reinterpret_cast<const float2*>(base + t * EM_US + 128);
+            const bool first = (firsts >> t) & 1;   // wave-uniform
+            EM_SCAN_STEP(t, b_re, b_im, first)
+            ++t;
+          }
+          float2 cr[4], ci[4], nr[4], ni[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int tt = min(t + i, sb - 1);
+            cr[i] = *reinterpret_cast<const float2*>(base + tt * EM_US);
+            ci[i] = *reinterpret_cast<const float2*>(base + tt * EM_US + 128);
+          }
+          for (; t + 4 <= sb; t += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // rows t + 4 .. t + 7 (clamped: a repeated read of row sb - 1 is never used)
+              const int tt = min(t + 4 + i, sb - 1);
+              nr[i] = *reinterpret_cast<const float2*>(base + tt * EM_US);
+              ni[i] = *reinterpret_cast<const float2*>(base + tt * EM_US + 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) EM_SCAN_STEP(t + i, cr[i], ci[i], false)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              cr[i] = nr[i];
+              ci[i] = ni[i];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            if (t + i < sb) EM_SCAN_STEP(t + i, cr[i], ci[i], false)   // wave-uniform
+        } else {
         for (int t0 = sa; t0 < sb; t0 += 4) {
           float2 br[4], bi[4];
 #pragma unroll
@@ -491,28 +564,13 @@ __global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           for (int i = 0; i < 4; ++i) {
             const int t = t0 + i;
             if (t < sb) {  // wave-uniform
-              if ((firsts >> t) & 1) {
-                h_r0 = br[i].x; h_r1 = br[i].y; h_i0 = bi[i].x; h_i1 = bi[i].y;
-              } else {
-                const float nr0 = lr_fma(lam_r0, h_r0, lr_fma(-lam_i0, h_i0, br[i].x));
-                const float ni0 = lr_fma(lam_r0, h_i0, lr_fma(lam_i0, h_r0, bi[i].x));
-                const float nr1 = lr_fma(lam_r1, h_r1, lr_fma(-lam_i1, h_i1, br[i].y));
-                const float ni1 = lr_fma(lam_r1, h_i1, lr_fma(lam_i1, h_r1, bi[i].y));
-                h_r0 = nr0; h_i0 = ni0; h_r1 = nr1; h_i1 = ni1;
-              }
-              if (MODE == 0) {
-                *reinterpret_cast<float2*>(base + t * EM_US) = make_float2(h_r0, h_r1);
-                *reinterpret_cast<float2*>(base + t * EM_US + 128) = make_float2(h_i0, h_i1);
-              } else if ((lasts >> t) & 1) {
-                float* o = p.OUT + (size_t)(tags[t] >> 2) * 256;
-                o[sc_k] = h_r0;
-                o[sc_k + 2] = h_r1;
-                o[128 + sc_k] = h_i0;
-                o[128 + sc_k + 2] = h_i1;
-              }
+              const bool first = (firsts >> t) & 1;
+              EM_SCAN_STEP(t, br[i], bi[i], first)
             }
           }
         }
+        }
+#undef EM_SCAN_STEP
         // (the other buffer: wave 0 may not have read this tile's carry-in yet)
         if (sb == EM_ST) *reinterpret_cast<float4*>(carry + (par ^ 1) * 256 + 4 * lane) = make_float4(h_r0, h_r1, h_i0, h_i1);
       }

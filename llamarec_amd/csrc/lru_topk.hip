@@ -1014,6 +1014,14 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     // pass's per-chunk LDS lists hold 20-40 entries per user with 16-bit offsets (16 k users used to get
     // 32 chunks of ~1 000 tiles at 1 M items, ~12 expected candidates per user and chunk against 24 slots)
     const int min_chunks = (p.n_tiles + lr_bf16_max_chunk_tiles(B) - 1) / lr_bf16_max_chunk_tiles(B);
+    {
+      static int target_wgs = -1;   // LR_BF16_WGS=n: tuning knob (workgroups per launch; 0 / unset = 1024)
+      if (target_wgs < 0) {
+        const char* e = getenv("LR_BF16_WGS");
+        target_wgs = e ? atoi(e) : 0;
+      }
+      if (target_wgs > 0) chunks = (target_wgs + n_ut - 1) / n_ut;
+    }
     if (chunks < min_chunks) chunks = min_chunks;
     const int unit = bp.gshift > 2 ? (1 << bp.gshift) : 4;   // a chunk is whole float4 iterations AND whole tile groups
     const int units = (p.n_tiles + unit - 1) / unit;
