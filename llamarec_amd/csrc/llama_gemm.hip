@@ -712,7 +712,7 @@ static int splitk_factor(int M, int N, int K) {
 // tile raster: M tiles per group (llama_gemm.hip header). An XCD's 32 concurrent workgroups form a group_m x (32 / group_m)
 // block of tiles that marches along N: every step of that march re-reads the group's A panels (group_m x 256 rows x K)
 // and reads 32 / group_m new B panels, so the bytes an XCD's L2 pulls per tile are (group_m + 32 / group_m) / 32 of a
-// tile's operand bytes: minimal at 4 x 8 or 8 x 4. Measured at M = 16384 (tools/gpu_gemm_groupm.sh): 8 is best for the
+// tile's operand bytes: minimal at 4 x 8 or 8 x 4. Measured at M = 16384 (docs/EXPERIMENTS.md, round 2): 8 is best for the
 // K = 4096 products, 4 (shorter A panels stay closer to the 4 MiB L2) for down_proj's K = 11008 (+3 %).
 // LR_GEMM_GROUP_M overrides it for tuning runs only.
 static int gemm256_group_m(int K) {
