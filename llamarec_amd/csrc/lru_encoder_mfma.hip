@@ -690,6 +690,446 @@ __global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #endif
 }
 
+
+// =============================================================================================
+// em_pipe_kernel: the same layer pair, software-pipelined over super tiles (round 4)
+// =============================================================================================
+// em_layer_kernel runs a tile's stages one after the other with all eight waves in each: phase A (MFMA) -> recurrence (one
+// to eight waves, vector ALU + LDS) -> phase B (MFMA on waves 0..3) -> LayerNorm + store; at Synth-1M the matrix pipe works
+// for 16.4 k of a tile's ~29 k cycles (tools/gpu_em_stamps.sh). Here the workgroup is split into roles and two tiles are in
+// flight:
+//     waves 0..3 ("B waves", one per SIMD): phase B chain, residual, LayerNorm, store of tile j
+//     waves 4..7 ("A waves", one per SIMD): staging, phase A (two 32-output blocks each) and the recurrence of tile j + 1
+// with the 256-wide intermediate double-buffered in LDS. That needs 2 x 65 KiB, so the phase B weights (65 KiB in
+// em_layer_kernel's LDS) live in the B waves' REGISTERS instead: 128 per lane, in the register array that holds the A
+// waves' 64 phase A weights. One iteration is two intervals separated by workgroup barriers:
+//     interval 1:  A waves: phase A of tile j+1 -> ul[(j+1)&1]      | B waves: LayerNorm + store of tile j-1, then the first
+//                                                                   |          EP_B1 of the 16 groups of tile j's chain
+//     interval 2:  A waves: recurrence of tile j+1, staging of j+2  | B waves: the rest of the chain, + residual, hand-over
+// so every SIMD's matrix pipe has the A wave's and the B wave's chains to interleave in interval 1 and the B wave's in
+// interval 2, while the recurrence, the staging, the epilogues and the LayerNorm run beside them on the other wave.
+// Every chain is the one em_layer_kernel runs (same operands, same k order); which rows share a tile, and which wave
+// walks which segment of the recurrence, never changes a row's arithmetic: bit-identical to em_layer_kernel and to the
+// oracle. MODE 0 (LRU layer) and MODE 1 (feed-forward); the last block's two kernels (MODE 2, 3) stay on em_layer_kernel.
+#define EP_B1 4
+
+template <int MODE>
+__global__ __launch_bounds__(EM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void em_pipe_kernel(EmLayer p) {
+  static_assert(MODE == 0 || MODE == 1, "em_pipe_kernel: LRU layer or feed-forward");
+  constexpr bool SCAN = MODE == 0;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float* ul0 = smem_f;                       // [2][EM_ST][EM_US] the 256-wide intermediate of two tiles
+  float* xs = ul0 + 2 * EM_ST * EM_US;       // [EM_ST][EM_XS]    phase A input, de-interleaved
+  float* ex = xs + EM_ST * EM_XS;            // [2][16][64]       feature block 1 -> block 0 hand-over
+  float* lnp = ex + 2 * 16 * 64;             // [2][64]           LayerNorm weight, bias
+  int* tags0 = reinterpret_cast<int*>(lnp + 128);               // [2][EM_ST]
+  float* erf_lds = reinterpret_cast<float*>(tags0 + 2 * EM_ST);  // [LR_ERF_NINT][EM_ERF_ROW]
+  float* carry = erf_lds + LR_ERF_NINT * EM_ERF_ROW;            // [2][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const bool is_b = wave < 4;
+#ifdef LR_EXPERIMENTS
+  // experiment builds (tools/gpu_em_stamps.sh): s_memtime ticks per stage summed over the tiles, wave 0 (B role: slots
+  // 0 LayerNorm | 1 chain part 1 | 2 wait | 3 chain part 2 + hand-over | 4 wait) and wave 4 (A role: 5 phase A | 6 wait |
+  // 7 loads + recurrence + staging | 8 wait), first 16 workgroups
+  unsigned long long st_acc[12] = {}, st_prev = __builtin_amdgcn_s_memtime();
+#define EP_STAMP(k)                                                      \
+  do {                                                                   \
+    if (p.stamp) {                                                       \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+      st_acc[k] += now_ - st_prev;                                       \
+      st_prev = now_;                                                    \
+    }                                                                    \
+  } while (0)
+#else
+#define EP_STAMP(k) do { } while (0)
+#endif
+  const int aw = wave & 3;   // index inside the role
+
+  int ra, rb, step;
+  if (p.wg_row) {
+    ra = p.wg_row[blockIdx.x];
+    rb = p.wg_row[blockIdx.x + 1];
+    step = EM_ST;
+  } else {
+    ra = blockIdx.x * EM_ST;
+    rb = p.n_rows_ptr ? *p.n_rows_ptr : p.n_rows_fixed;
+    step = gridDim.x * EM_ST;
+  }
+  if (ra >= rb) return;
+  const int nt = (rb - ra + step - 1) / step;   // tiles of this workgroup: rows ra + j * step ..
+
+  if (tid < 64) lnp[tid] = p.lnw[tid];
+  else if (tid < 128) lnp[tid] = p.lnb[tid - 64];
+  if (MODE == 1)
+    for (int i = tid; i < LR_ERF_NINT * EM_ERF_ROW; i += EM_THREADS) {
+      const int c = i % EM_ERF_ROW;
+      erf_lds[i] = c <= LR_ERF_DEG ? em_erf_tab[(i / EM_ERF_ROW) * (LR_ERF_DEG + 1) + c] : 0.f;
+    }
+  // ---- roles. The two roles are two separate loops below (same number of barriers in each): written as one loop with a
+  // branch per interval, every role's loop-carried registers (128 + 64 weights, accumulator, residual, staged rows ...)
+  // would be live in every wave and hipcc spilled 216 of them.
+  const int rt = (wave >> 1) & 1, jb = wave & 1;   // B waves: row tile, feature block
+  // recurrence (A waves): lane = two complex channels k, k + 2 (neighbours in the de-interleaved row)
+  const int sc_k = (lane >> 5) * 64 + 4 * (lane & 15) + ((lane >> 4) & 1);
+  const int sc_pos = em_pos(sc_k);
+  float lam_r0 = 0.f, lam_i0 = 0.f, lam_r1 = 0.f, lam_i1 = 0.f;
+  if (SCAN) {
+    lam_r0 = p.lam_re[sc_k];
+    lam_i0 = p.lam_im[sc_k];
+    lam_r1 = p.lam_re[sc_k + 2];
+    lam_i1 = p.lam_im[sc_k + 2];
+    *reinterpret_cast<float4*>(carry + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);  // every wave: same zeros
+  }
+  int par = 0;   // parity of the carry buffer the next recurrence reads
+
+  if (!is_b) {
+    // ================================================= A waves =================================================
+    // phase A weights of my two output blocks 2 aw, 2 aw + 1 (step s uses k = 2 s + half)
+    float wq[64], bq[2], gq[2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      const int out = (2 * aw + bi) * 32 + col;
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) wq[bi * 32 + s2] = p.wa[(size_t)(2 * s2 + half) * 256 + out];
+      bq[bi] = p.ba[out];
+      gq[bi] = MODE == 1 ? 0.f : p.gamma[out & 127];
+    }
+  // ---- A-wave stages ------------------------------------------------------------------------------------------------
+  const int atid = tid & 255;   // thread index inside the role
+  // staging of tile `jt`: two (row, part) pairs per A thread -- 8 floats of a 64-float input row each, de-interleaved:
+  // xs[row][h*32 + s] = x[row][2s + h] -- and the rows' tags. Loads and LDS writes are separate calls so that the loads can
+  // be in flight across the recurrence.
+  float4 pre[2][2];
+  int pre_tag = 1;
+  auto stage_load = [&](int jt) {
+    const int r0 = ra + jt * step;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) em_load_rows8(pre[h2], p.IN, r0, rb, (atid >> 3) + 32 * h2, atid & 7);
+    if (SCAN) pre_tag = (atid < EM_ST && r0 + atid < rb) ? p.row_tag[r0 + atid] : 1;
+  };
+  auto stage_store = [&](int jt) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      float* dst = xs + ((atid >> 3) + 32 * h2) * EM_XS + (atid & 7) * 4;
+      *reinterpret_cast<float4*>(dst) = make_float4(pre[h2][0].x, pre[h2][0].z, pre[h2][1].x, pre[h2][1].z);
+      *reinterpret_cast<float4*>(dst + 32) = make_float4(pre[h2][0].y, pre[h2][0].w, pre[h2][1].y, pre[h2][1].w);
+    }
+    if (SCAN && atid < EM_ST) tags0[(jt & 1) * EM_ST + atid] = pre_tag;
+  };
+  // phase A of the tile staged in xs -> ulb: my two output blocks for both 32-row tiles
+  auto phase_a = [&](float* ulb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float a[32];  // token row t*32 + col, 32 de-interleaved values of my half
+      const float* xr = xs + (t * 32 + col) * EM_XS + 32 * half;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v4 = *reinterpret_cast<const float4*>(xr + 4 * q);
+        a[4 * q + 0] = v4.x; a[4 * q + 1] = v4.y; a[4 * q + 2] = v4.z; a[4 * q + 3] = v4.w;
+      }
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi) {
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bq[bi];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wq[bi * 32 + s2], acc, 0, 0, 0);
+        // D[token i][out]: lane = out column, register r = token (r&3) + 8*(r>>2) + 4*half
+        const int blk = 2 * aw + bi;
+        float* dst = ulb + (blk >> 1) * 64 + (col & 1) * 32 + (blk & 1) * 16 + (col >> 1);  // em_pos(blk*32 + col)
+#pragma unroll
+        for (int r8 = 0; r8 < 16; r8 += 4) {   // four values at a time (eight, as in em_layer_kernel, spill beside wq[64])
+          float xin[4], val[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xin[i] = acc[r8 + i];
+          if (MODE == 1) {
+            em_gelu_tab12<4>(xin, val, erf_lds);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) val[i] = xin[i] * gq[bi];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = r8 + i;
+            const int tok = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            dst[tok * EM_US] = val[i];
+          }
+        }
+      }
+    }
+  };
+  // recurrence over the 64 rows of ulb (MODE 0), four A waves: the rows are cut at users' first rows into up to four
+  // segments (cuts at the first start at or after row 16, 32, 48); wave aw walks segment aw. Only segment 0 can continue a
+  // user of the previous tile: its carry comes from the wave that walked row 63 there, through LDS.
+  auto scan = [&](float* ulb, const int* tg) {
+    const int tg_lane = tg[lane];
+    const unsigned long long firsts = __ballot(tg_lane & 1);
+    int sa = 0, sb = EM_ST;
+    if (aw > 0) {
+      const unsigned long long m = firsts & (~0ull << (16 * aw));
+      sa = m ? __builtin_ctzll(m) : EM_ST;
+    }
+    if (aw < 3) {
+      const unsigned long long m = firsts & (~0ull << (16 * (aw + 1)));
+      sb = m ? __builtin_ctzll(m) : EM_ST;
+    }
+    sa = __builtin_amdgcn_readfirstlane(sa);
+    sb = __builtin_amdgcn_readfirstlane(sb);
+    if (sa < sb) {
+      float h_r0, h_r1, h_i0, h_i1;
+      if (aw == 0) {
+        const float4 cv = *reinterpret_cast<const float4*>(carry + par * 256 + 4 * lane);
+        h_r0 = cv.x; h_r1 = cv.y; h_i0 = cv.z; h_i1 = cv.w;
+      } else {
+        h_r0 = h_r1 = h_i0 = h_i1 = 0.f;  // overwritten by the segment's first row
+      }
+      float* base = ulb + sc_pos;
+#define EP_SCAN_STEP(t_, bre_, bim_, is_first_)                                                        \
+  {                                                                                                    \
+    if (is_first_) {                                                                                   \
+      h_r0 = (bre_).x; h_r1 = (bre_).y; h_i0 = (bim_).x; h_i1 = (bim_).y;                             \
+    } else {                                                                                           \
+      const float nr0 = lr_fma(lam_r0, h_r0, lr_fma(-lam_i0, h_i0, (bre_).x));                         \
+      const float ni0 = lr_fma(lam_r0, h_i0, lr_fma(lam_i0, h_r0, (bim_).x));                          \
+      const float nr1 = lr_fma(lam_r1, h_r1, lr_fma(-lam_i1, h_i1, (bre_).y));                         \
+      const float ni1 = lr_fma(lam_r1, h_i1, lr_fma(lam_i1, h_r1, (bim_).y));                          \
+      h_r0 = nr0; h_i0 = ni0; h_r1 = nr1; h_i1 = ni1;                                                  \
+    }                                                                                                  \
+    *reinterpret_cast<float2*>(base + (t_) * EM_US) = make_float2(h_r0, h_r1);                         \
+    *reinterpret_cast<float2*>(base + (t_) * EM_US + 128) = make_float2(h_i0, h_i1);                   \
+  }
+      const unsigned long long upto = sb >= 64 ? ~0ull : ((1ull << sb) - 1ull);
+      const unsigned long long inner_firsts = firsts & upto & ~((2ull << sa) - 1ull);
+      if (inner_firsts == 0ull) {   // one user from sa to sb: no per-row first test, operands requested four rows ahead
+        int t = sa;
+        {
+          const float2 b_re = *reinterpret_cast<const float2*>(base + t * EM_US);
+          const float2 b_im = *reinterpret_cast<const float2*>(base + t * EM_US + 128);
+          const bool first = (firsts >> t) & 1;   // wave-uniform
+          EP_SCAN_STEP(t, b_re, b_im, first)
+          ++t;
+        }
+        float2 cr[4], ci[4], nr[4], ni[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tt = min(t + i, sb - 1);
+          cr[i] = *reinterpret_cast<const float2*>(base + tt * EM_US);
+          ci[i] = *reinterpret_cast<const float2*>(base + tt * EM_US + 128);
+        }
+        for (; t + 4 <= sb; t += 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int tt = min(t + 4 + i, sb - 1);
+            nr[i] = *reinterpret_cast<const float2*>(base + tt * EM_US);
+            ni[i] = *reinterpret_cast<const float2*>(base + tt * EM_US + 128);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) EP_SCAN_STEP(t + i, cr[i], ci[i], false)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            cr[i] = nr[i];
+            ci[i] = ni[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (t + i < sb) EP_SCAN_STEP(t + i, cr[i], ci[i], false)   // wave-uniform
+      } else {
+        for (int t0 = sa; t0 < sb; t0 += 4) {
+          float2 br[4], bi2[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int t = min(t0 + i, sb - 1);
+            br[i] = *reinterpret_cast<const float2*>(base + t * EM_US);
+            bi2[i] = *reinterpret_cast<const float2*>(base + t * EM_US + 128);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int t = t0 + i;
+            if (t < sb) {  // wave-uniform
+              const bool first = (firsts >> t) & 1;
+              EP_SCAN_STEP(t, br[i], bi2[i], first)
+            }
+          }
+        }
+      }
+#undef EP_SCAN_STEP
+      // (the other buffer: wave 0 may not have read this tile's carry-in yet)
+      if (sb == EM_ST) *reinterpret_cast<float4*>(carry + (par ^ 1) * 256 + 4 * lane) = make_float4(h_r0, h_r1, h_i0, h_i1);
+    }
+    par ^= 1;
+  };
+
+
+    // prologue: tile 0 through staging, phase A and the recurrence; tile 1 staged
+    stage_load(0);
+    stage_store(0);
+    EM_BARRIER();
+    if (nt > 1) stage_load(1);
+    phase_a(ul0);
+    EM_BARRIER();
+    if (SCAN) scan(ul0, tags0);
+    if (nt > 1) stage_store(1);
+    EM_BARRIER();
+    EP_STAMP(11);
+    for (int j = 0; j < nt; ++j) {
+      float* const uln = ul0 + ((j + 1) & 1) * (EM_ST * EM_US);
+      if (j + 1 < nt) phase_a(uln);                                         // interval 1
+      EP_STAMP(5);
+      EM_BARRIER();
+      EP_STAMP(6);
+      if (j + 2 < nt) stage_load(j + 2);                                    // interval 2
+      if (SCAN && j + 1 < nt) scan(uln, tags0 + ((j + 1) & 1) * EM_ST);
+      if (j + 2 < nt) stage_store(j + 2);
+      EP_STAMP(7);
+      EM_BARRIER();
+      EP_STAMP(8);
+    }
+#ifdef LR_EXPERIMENTS
+    if (p.stamp && tid == 256 && blockIdx.x < 16)
+      for (int k = 5; k < 12; ++k) g_em_stamps[MODE][blockIdx.x][k] = st_acc[k];
+#endif
+  } else {
+    // ================================================= B waves =================================================
+    // 128 phase B weights of feature jb*32 + col: chain step i uses k = (i >> 5) * 64 + 2 * (i & 31) + half, the order
+    // em_layer_kernel reads them from LDS
+    float wreg[128];
+    {
+      const int f = jb * 32 + col;
+#pragma unroll
+      for (int i = 0; i < 128; ++i) wreg[i] = p.wb[(size_t)((i >> 5) * 64 + 2 * (i & 31) + half) * 64 + f];
+    }
+  // ---- B-wave stages ------------------------------------------------------------------------------------------------
+  floatx16 acc_b;     // the chain's accumulator, alive across the barrier between its two parts
+  float4 r4[4];       // residual of my row, requested before the chain
+  float v0[16];       // my 16 features (+ residual) of the finished tile, alive until its LayerNorm in the next interval 1
+  int ln_gr = 0;      // global row of v0's token, -1: none / not live
+  auto chain_begin = [&](int jt) {
+    const int r0 = ra + jt * step;
+    const int lrow = rt * 32 + col;
+    const bool live = r0 + lrow < rb;
+    const int gr = r0 + lrow;
+    const float* res = p.RES + (size_t)(live ? (p.res_rows ? p.res_rows[gr] : gr) : 0) * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      r4[g] = live ? *reinterpret_cast<const float4*>(res + jb * 32 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_b[r] = p.bb[jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];   // (L1-resident; 16 registers less)
+  };
+  // groups [G0, G1) of the 16-group chain (8 k steps each) on the tile in ulb; the operands of the next group are requested
+  // before the current group's 8 MFMAs
+#define EP_CHAIN(ulb_, G0, G1)                                                                             \
+  {                                                                                                        \
+    const float* tr = (ulb_) + (rt * 32 + col) * EM_US + 32 * half;   /* token row rt*32 + col */           \
+    float4 bc[2], bn[2];                                                                                   \
+    {                                                                                                      \
+      const int o0 = ((G0) >> 2) * 64 + ((G0)&3) * 8;                                                      \
+      bc[0] = *reinterpret_cast<const float4*>(tr + o0);                                                   \
+      bc[1] = *reinterpret_cast<const float4*>(tr + o0 + 4);                                               \
+    }                                                                                                      \
+    _Pragma("unroll") for (int g = (G0); g < (G1); ++g) {                                                  \
+      if (g + 1 < (G1)) {                                                                                  \
+        const int o = ((g + 1) >> 2) * 64 + ((g + 1) & 3) * 8;                                             \
+        bn[0] = *reinterpret_cast<const float4*>(tr + o);                                                  \
+        bn[1] = *reinterpret_cast<const float4*>(tr + o + 4);                                              \
+      }                                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[g * 8 + 4 * i + 0], bc[i].x, acc_b, 0, 0, 0);    \
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[g * 8 + 4 * i + 1], bc[i].y, acc_b, 0, 0, 0);    \
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[g * 8 + 4 * i + 2], bc[i].z, acc_b, 0, 0, 0);    \
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[g * 8 + 4 * i + 3], bc[i].w, acc_b, 0, 0, 0);    \
+      }                                                                                                    \
+      bc[0] = bn[0];                                                                                       \
+      bc[1] = bn[1];                                                                                       \
+    }                                                                                                      \
+  }
+  auto chain_end = [&](int jt) {   // + residual; block 1 hands its 16 values to the block-0 wave of its row tile
+    const int r0 = ra + jt * step;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v0[4 * g + 0] = acc_b[4 * g + 0] + r4[g].x;
+      v0[4 * g + 1] = acc_b[4 * g + 1] + r4[g].y;
+      v0[4 * g + 2] = acc_b[4 * g + 2] + r4[g].z;
+      v0[4 * g + 3] = acc_b[4 * g + 3] + r4[g].w;
+    }
+    if (jb == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ex[(rt * 16 + r) * 64 + lane] = v0[r];
+    }
+    ln_gr = (r0 + rt * 32 + col < rb) ? r0 + rt * 32 + col : -1;
+  };
+  auto layer_norm_store = [&]() {   // block-0 waves: the LayerNorm butterfly over my 16 + the handed-over 16 features
+    float v[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v[0][r] = v0[r];
+      v[1][r] = ex[(rt * 16 + r) * 64 + lane];
+    }
+    const float mean = em_butterfly64(v) * 0.015625f;
+    float d2[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v[j][r] = v[j][r] - mean;
+        d2[j][r] = v[j][r] * v[j][r];
+      }
+    const float var = em_butterfly64(d2) * 0.015625f;
+    const float rstd = 1.0f / sqrtf(var + LR_LN_EPS);
+    if (ln_gr >= 0) {
+      float* y = p.OUT + (size_t)ln_gr * 64;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f = j * 32 + 8 * g + 4 * half;
+          const float4 w4 = *reinterpret_cast<const float4*>(lnp + f);
+          const float4 c4 = *reinterpret_cast<const float4*>(lnp + 64 + f);
+          float4 o;
+          o.x = lr_fma(v[j][4 * g + 0] * rstd, w4.x, c4.x);
+          o.y = lr_fma(v[j][4 * g + 1] * rstd, w4.y, c4.y);
+          o.z = lr_fma(v[j][4 * g + 2] * rstd, w4.z, c4.z);
+          o.w = lr_fma(v[j][4 * g + 3] * rstd, w4.w, c4.w);
+          *reinterpret_cast<float4*>(y + f) = o;
+        }
+    }
+  };
+
+
+    EM_BARRIER();   // the A waves' prologue: three barriers
+    EM_BARRIER();
+    EM_BARRIER();
+    EP_STAMP(10);
+    for (int j = 0; j < nt; ++j) {
+      float* const ulj = ul0 + (j & 1) * (EM_ST * EM_US);
+      if (j > 0 && jb == 0) layer_norm_store();   // interval 1: tile j - 1 (its hand-over was written before the last barrier)
+      EP_STAMP(0);
+      chain_begin(j);
+      EP_CHAIN(ulj, 0, EP_B1)
+      EP_STAMP(1);
+      EM_BARRIER();
+      EP_STAMP(2);
+      EP_CHAIN(ulj, EP_B1, 16)                     // interval 2
+      chain_end(j);
+      EP_STAMP(3);
+      EM_BARRIER();
+      EP_STAMP(4);
+    }
+    if (jb == 0) layer_norm_store();   // the last tile
+#ifdef LR_EXPERIMENTS
+    if (p.stamp && tid == 0 && blockIdx.x < 16) {
+      for (int k = 0; k < 5; ++k) g_em_stamps[MODE][blockIdx.x][k] = st_acc[k];
+      g_em_stamps[MODE][blockIdx.x][10] = st_acc[10];
+    }
+#endif
+  }
+#undef EP_CHAIN
+#undef EP_STAMP
+}
+
 #ifdef LR_EXPERIMENTS
 extern "C" int lr_debug_em_stamps(unsigned long long* out, int n) {
   if (!out || n != 4 * 16 * 12) LR_FAIL(LR_EINVAL, "lr_debug_em_stamps: bad arguments");
@@ -718,8 +1158,37 @@ size_t lr_encoder_mfma_workspace_bytes(int B, int L) {
   return o;
 }
 
+// LR_EM_PIPE=0: the LRU layer and the feed-forward on em_layer_kernel (one tile at a time) instead of em_pipe_kernel -- A/B
+// runs and the bit-identity test of the two (tests/test_gpu_lru.py); both produce the same bits
+static bool em_use_pipe() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LR_EM_PIPE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
 template <int MODE>
 static int em_launch_layer(int grid, size_t lds, hipStream_t st, const EmLayer& p) {
+  // The pipelined kernel serves the LRU layer only. Measured at Synth-1M / Beauty (gpurun_out/r4s5): LRU layer 425 -> 395 us /
+  // 144 -> 139 us, feed-forward 409 -> 449 us / 152 -> 171 us. The stamps say why the gain is small and the feed-forward
+  // loses: v_mfma_f32_32x32x2_f32 runs on the f32 vector datapath, so a SIMD's vector work (recurrence, LayerNorm, GELU) does
+  // NOT hide behind its partner wave's chain -- LayerNorm takes 6.6 k cycles per tile beside phase A against 1.5 k alone,
+  // the recurrence 12.3 k beside the phase B chain against 5.5 k -- and the roles only move where a SIMD's MFMA + vector
+  // cycles are spent: the SIMD whose A wave walks a long user's 64 rows carries 16.4 k + 5.5 k + epilogues while the others
+  // wait at the barrier, and four A waves evaluate the GELU that eight waves shared.
+  if constexpr (MODE == 0) {
+    if (em_use_pipe()) {
+      // [2][64][EM_US] intermediates | xs | hand-over | LayerNorm | 2 x tags | erf table | carry
+      const size_t lds_pipe = (size_t)(2 * EM_ST * EM_US + EM_ST * EM_XS + 2 * 16 * 64 + 128 + 2 * EM_ST + LR_ERF_NINT * EM_ERF_ROW + 512) * sizeof(float);
+      static bool lds_set_pipe[LR_MAX_DEVICES] = {};
+      if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(em_pipe_kernel<MODE>), (int)lds_pipe, lds_set_pipe)) return rc;
+      hipLaunchKernelGGL(em_pipe_kernel<MODE>, dim3(grid), dim3(EM_THREADS), lds_pipe, st, p);
+      LR_CHECK_LAUNCH("em_pipe_kernel");
+      return LR_OK;
+    }
+  }
   static bool lds_set[LR_MAX_DEVICES] = {};
   if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(em_layer_kernel<MODE>), (int)lds, lds_set)) return rc;
   hipLaunchKernelGGL(em_layer_kernel<MODE>, dim3(grid), dim3(EM_THREADS), lds, st, p);

@@ -20,5 +20,6 @@ s = out.reshape(4, 16, 12).astype(np.float64)
 np.set_printoptions(precision=0, suppress=True, linewidth=220)
 print("s_memtime ticks (100 MHz? no: shader clock) summed over the super tiles of wave 0, mean of 16 workgroups; last launch of each mode")
 print("cols: 0 prologue | 1 top barrier | 2 stage | 3 barrier | 4 phase A | 5 barrier | 6 recurrence | 7 barrier | 8 phase B chain | 9 hand-over | 10 barrier | 11 LayerNorm+store")
+print("em_pipe_kernel (modes 0, 1 unless LR_EM_PIPE=0): B wave 0: 0 LayerNorm | 1 chain part 1 | 2 wait | 3 chain part 2 + hand-over | 4 wait | 10 prologue;  A wave 4: 5 phase A | 6 wait | 7 loads + recurrence + staging | 8 wait | 11 prologue")
 for m, nm in enumerate(["LRU layer", "FFN", "LRU last block", "out_proj last rows"]):
     print(nm, s[m].mean(0), " total", s[m].mean(0).sum())
