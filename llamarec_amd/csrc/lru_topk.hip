@@ -568,14 +568,16 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const float* tmax, in
 // those EXACTLY -- lr_item_score's fmaf chain, the bits of the oracle and of item_topk_kernel -- drops masked ids and
 // ranks them. If any user's list overflows TK_CAND_CAP (degenerate data: thousands of near-equal scores) a device flag
 // turns on the exact full pass (item_topk_kernel + merge, launched behind it with run_flag) for the whole call.
+#define TK_RESCORE_HIST 256   // history ids a wave of cand_rescore_kernel stages in LDS (4 KiB per workgroup)
 // One wave per user: exact scores of the candidates, masked ids dropped, rank by counting, ordered top-K written.
 __global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, const float* bias, const float* q,
                                                            const int32_t* hist_sorted, int L, int exclude, int B, int K,
                                                            int n_rows, const int* cand_count, const int32_t* cand,
-                                                           int* overflow_flag,
+                                                           const float* thresh, int* overflow_flag,
                                                            int32_t* out_idx, float* out_score) {
   __shared__ float qs[4][64];
-  __shared__ int32_t hsl[4][64];   // the user's sorted history when L <= 64 (else the search reads global memory)
+  __shared__ int32_t hsl[4][TK_RESCORE_HIST];   // the user's sorted history when L <= TK_RESCORE_HIST (else the search reads global
+                                              // memory: 8 dependent loads per candidate -- at L = 200 that was most of the kernel's 170 us)
   __shared__ unsigned long long keys[4][TK_CAND_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int user = blockIdx.x * 4 + wave;
@@ -586,68 +588,77 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const float* emb, con
     return;
   }
   qs[wave][lane] = q[(size_t)user * 64 + lane];
-  const bool hist_in_lds = exclude && L <= 64;
-  if (hist_in_lds) hsl[wave][lane] = lane < L ? hist_sorted[(size_t)user * L + lane] : INT_MAX;
+  const bool hist_in_lds = exclude && L <= TK_RESCORE_HIST;
+  if (hist_in_lds)
+    for (int t = lane; t < TK_RESCORE_HIST; t += 64) hsl[wave][t] = t < L ? hist_sorted[(size_t)user * L + t] : INT_MAX;
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   const int32_t* hs = hist_in_lds ? hsl[wave] : hist_sorted + (size_t)user * L;
-  int valid = 0;
-  for (int c = lane; c < n; c += 64) {
-    const int item = cand[(size_t)user * TK_CAND_CAP + c];
-    bool masked = (unsigned)item >= (unsigned)n_rows;   // cannot happen (padding rows never pass); never index past the table
-
-    if (exclude && !masked) {
-      masked = item == 0;
-      int lo = 0, hi = L;   // sorted ascending, INT_MAX = unused entry
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const int h = hs[mid];
-        if (h < item) lo = mid + 1;
-        else hi = mid;
-      }
-      masked = masked || (lo < L && hs[lo] == item);   // (generic address space: LDS or global, same code)
-    }
+  // T = the bound's proven lower limit of this user's K-th best eligible EXACT score (bound_select_kernel): a candidate
+  // scoring below it cannot be in the top K, so it never enters the ranking. The candidates were admitted on their
+  // approximate scores down to T - delta; about a third of them fall below T, and the ranking is quadratic in their number
+  // (it was two thirds of this kernel's 170 us at 1 M items). Survivors are written compacted.
+  const float T = thresh ? thresh[user] : -__builtin_inff();
+  int m = 0;   // survivors so far (wave-uniform)
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int c = c0 + lane;
+    bool ok = false;
     unsigned long long key = 0ull;
-    if (!masked) {   // lr_item_score(): the one summation order stage 1 uses everywhere (lr_math.h)
-      const float4* e4 = reinterpret_cast<const float4*>(emb + (size_t)item * 64);
-      const float4* q4 = reinterpret_cast<const float4*>(qs[wave]);
-      float ev[64];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float4 v = e4[j];
-        ev[4 * j + 0] = v.x; ev[4 * j + 1] = v.y; ev[4 * j + 2] = v.z; ev[4 * j + 3] = v.w;
+    if (c < n) {
+      const int item = cand[(size_t)user * TK_CAND_CAP + c];
+      bool masked = (unsigned)item >= (unsigned)n_rows;   // (a padding row that passed a -inf threshold; never index past the table)
+      if (exclude && !masked) {
+        masked = item == 0;
+        int lo = 0, hi = L;   // sorted ascending, INT_MAX = unused entry
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const int h = hs[mid];
+          if (h < item) lo = mid + 1;
+          else hi = mid;
+        }
+        masked = masked || (lo < L && hs[lo] == item);   // (generic address space: LDS or global, same code)
       }
-      float acc = 0.0f;
+      if (!masked) {   // lr_item_score(): the one summation order stage 1 uses everywhere (lr_math.h)
+        const float4* e4 = reinterpret_cast<const float4*>(emb + (size_t)item * 64);
+        const float4* q4 = reinterpret_cast<const float4*>(qs[wave]);
+        float ev[64];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {   // s = 4 j .. 4 j + 3: fma(e[32 + s], q[32 + s], fma(e[s], q[s], acc))
-        const float4 qa = q4[j], qb = q4[8 + j];
-        acc = __builtin_fmaf(ev[4 * j + 0], qa.x, acc);
-        acc = __builtin_fmaf(ev[32 + 4 * j + 0], qb.x, acc);
-        acc = __builtin_fmaf(ev[4 * j + 1], qa.y, acc);
-        acc = __builtin_fmaf(ev[32 + 4 * j + 1], qb.y, acc);
-        acc = __builtin_fmaf(ev[4 * j + 2], qa.z, acc);
-        acc = __builtin_fmaf(ev[32 + 4 * j + 2], qb.z, acc);
-        acc = __builtin_fmaf(ev[4 * j + 3], qa.w, acc);
-        acc = __builtin_fmaf(ev[32 + 4 * j + 3], qb.w, acc);
+        for (int j = 0; j < 16; ++j) {
+          const float4 v = e4[j];
+          ev[4 * j + 0] = v.x; ev[4 * j + 1] = v.y; ev[4 * j + 2] = v.z; ev[4 * j + 3] = v.w;
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // s = 4 j .. 4 j + 3: fma(e[32 + s], q[32 + s], fma(e[s], q[s], acc))
+          const float4 qa = q4[j], qb = q4[8 + j];
+          acc = __builtin_fmaf(ev[4 * j + 0], qa.x, acc);
+          acc = __builtin_fmaf(ev[32 + 4 * j + 0], qb.x, acc);
+          acc = __builtin_fmaf(ev[4 * j + 1], qa.y, acc);
+          acc = __builtin_fmaf(ev[32 + 4 * j + 1], qb.y, acc);
+          acc = __builtin_fmaf(ev[4 * j + 2], qa.z, acc);
+          acc = __builtin_fmaf(ev[32 + 4 * j + 2], qb.z, acc);
+          acc = __builtin_fmaf(ev[4 * j + 3], qa.w, acc);
+          acc = __builtin_fmaf(ev[32 + 4 * j + 3], qb.w, acc);
+        }
+        const float score = acc + bias[item];
+        ok = score >= T;
+        key = lr_rank_key(score, (uint32_t)item);
       }
-      key = lr_rank_key(acc + bias[item], (uint32_t)item);
-      ++valid;
     }
-    keys[wave][c] = key;
+    const unsigned long long bal = __ballot(ok);
+    if (ok) keys[wave][m + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    m += __popcll(bal);
   }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) valid += __shfl_xor(valid, s, 64);
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
-  for (int j = valid + lane; j < K; j += 64) {   // fewer than K eligible candidates (overflow only): the open slots
+  for (int j = m + lane; j < K; j += 64) {   // fewer than K eligible candidates (overflow only): the open slots
     out_idx[(size_t)user * K + j] = -1;
     if (out_score) out_score[(size_t)user * K + j] = -__builtin_inff();
   }
-  for (int c = lane; c < n; c += 64) {
+  for (int c = lane; c < m; c += 64) {
     const unsigned long long key = keys[wave][c];
-    if (key == 0ull) continue;
     int rank = 0;
-    for (int j = 0; j < n; ++j) rank += keys[wave][j] > key ? 1 : 0;
+    for (int j = 0; j < m; ++j) rank += keys[wave][j] > key ? 1 : 0;
     if (rank < K) {
       out_idx[(size_t)user * K + rank] = (int32_t)lr_key_item(key);
       if (out_score) out_score[(size_t)user * K + rank] = lr_key_score(key);
@@ -1050,7 +1061,7 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
     cp.tiles_per_chunk = bp.tiles_per_chunk;
     if (int rc = lr_launch_item_cand(cp, chunks, st)) return rc;
     hipLaunchKernelGGL(cand_rescore_kernel, dim3((B + 3) / 4), dim3(256), 0, st, p.emb, p.bias, q, p.hist_sorted, L,
-                       p.exclude, B, K, p.n_rows, cand_count, cand, overflow_flag, out_idx, out_score);
+                       p.exclude, B, K, p.n_rows, cand_count, cand, thresh, overflow_flag, out_idx, out_score);
     LR_CHECK_LAUNCH("cand_rescore_kernel");
     // behind the candidate path: the exact full pass, which runs only if a candidate list overflowed
     p.thresh = thresh;
