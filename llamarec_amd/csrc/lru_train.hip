@@ -146,15 +146,15 @@ struct lr_lru_train {
 // Tile BM x BN (64 or 128 each), 4 waves (2 x 2) of (BM/64) x (BN/64) MFMA blocks of 32 x 32: the three V-sized products
 // of a step (scores, d hidden, d table: 4.95 GFLOP each on Beauty = 31 us at the f32 MFMA peak) run on 128-row tiles --
 // on 64 x 64 a K step is 16 MFMAs per wave between two barriers and 16 LDS stores per thread, and they took 82-110 us.
-template <int BM, int BN, bool SWAP>
+template <int BM, int BN, bool SWAP, int BK = TG_BK>   // BK: K depth of a staged tile (32; 64 for the few-tile K >= 128 products)
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, long long sam, long long sak,
                                                          const float* __restrict__ B, long long sbk, long long sbn,
                                                          float* C, long long ldc, const float* bias, int M, int N,
                                                          int K, int accumulate, float* rowsum) {
   constexpr int MI = BM / 64, NI = BN / 64, LDA = BM + 4, LDB = BN + 4;
-  constexpr int NA = BM * TG_BK / 256, NB = BN * TG_BK / 256;   // tile elements per thread
-  __shared__ float As[TG_BK][LDA];
-  __shared__ float Bs[TG_BK][LDB];
+  constexpr int NA = BM * BK / 256, NB = BN * BK / 256;   // tile elements per thread
+  __shared__ float As[BK][LDA];
+  __shared__ float Bs[BK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
-  const int ksteps = (K + TG_BK - 1) / TG_BK;
+  const int ksteps = (K + BK - 1) / BK;
   const int ks0 = (int)((long long)blockIdx.z * ksteps / gridDim.z), ks1 = (int)((long long)(blockIdx.z + 1) * ksteps / gridDim.z);
   const bool want_rowsum = rowsum != nullptr && blockIdx.x == 0;
   float rs[MI];
@@ -178,33 +178,33 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
-      const int kk = a_kfast ? (e & 31) : (e / BM), mm = a_kfast ? (e >> 5) : (e % BM);
+      const int kk = a_kfast ? (e % BK) : (e / BM), mm = a_kfast ? (e / BK) : (e % BM);
       const int gm = m0 + mm, gk = k0 + kk;
       va[i] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + 256 * i;
-      const int kk = b_kfast ? (e & 31) : (e / BN), nn = b_kfast ? (e >> 5) : (e % BN);
+      const int kk = b_kfast ? (e % BK) : (e / BN), nn = b_kfast ? (e / BK) : (e % BN);
       const int gn = n0 + nn, gk = k0 + kk;
       vb[i] = (gn < N && gk < K) ? B[gk * sbk + gn * sbn] : 0.f;
     }
   };
-  if (ks0 < ks1) load_tile(ks0 * TG_BK);
-  for (int k0 = ks0 * TG_BK; k0 < ks1 * TG_BK; k0 += TG_BK) {
+  if (ks0 < ks1) load_tile(ks0 * BK);
+  for (int k0 = ks0 * BK; k0 < ks1 * BK; k0 += BK) {
     __syncthreads();  // previous tile consumed
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + 256 * i;
-      As[a_kfast ? (e & 31) : (e / BM)][a_kfast ? (e >> 5) : (e % BM)] = va[i];
+      As[a_kfast ? (e % BK) : (e / BM)][a_kfast ? (e / BK) : (e % BM)] = va[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + 256 * i;
-      Bs[b_kfast ? (e & 31) : (e / BN)][b_kfast ? (e >> 5) : (e % BN)] = vb[i];
+      Bs[b_kfast ? (e % BK) : (e / BN)][b_kfast ? (e / BK) : (e % BN)] = vb[i];
     }
     __syncthreads();
-    if (k0 + TG_BK < ks1 * TG_BK) load_tile(k0 + TG_BK);
+    if (k0 + BK < ks1 * BK) load_tile(k0 + BK);
     if (want_rowsum) {   // thread = (row tid & 63 (+ 64 i), k quarter tid >> 6): 8 independent LDS reads per K step and row.
                          // (One thread per row walking all 32 k of the step was a chain of 32 dependent reads, ~2 us per K
                          // step, with the other three waves parked at the next barrier: the eight weight-gradient
@@ -212,10 +212,10 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int kk = 0; kk < TG_BK / 4; ++kk) rs[i] += As[(tid >> 6) * (TG_BK / 4) + kk][(tid & 63) + 64 * i];
+        for (int kk = 0; kk < BK / 4; ++kk) rs[i] += As[(tid >> 6) * (BK / 4) + kk][(tid & 63) + 64 * i];
     }
 #pragma unroll
-    for (int s = 0; s < TG_BK / 2; ++s) {
+    for (int s = 0; s < BK / 2; ++s) {
       float a[MI], b[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) a[i] = As[2 * s + (lane >> 5)][wm * (BM / 2) + i * 32 + (lane & 31)];
@@ -304,16 +304,31 @@ static int tr_gemm(const float* A, long long sam, long long sak, const float* B,
                    bool split_ok = false, float* rowsum = nullptr) {
   if (M <= 0 || N <= 0) return LR_OK;
   dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
+  const int tiles = grid.x * grid.y;
+  // Few tiles and a long K: the launch is a chain of K steps, each one exposed global latency (one step of register
+  // prefetch) -- [3 200 x 256] x [256 -> 64] is 50 workgroups walking 8 steps in 17 us for 0.1 GFLOP, the weight
+  // gradients (K = 3 200 over 12 splits) 8 steps in 21-23 us (tools/gpu_train_trace.sh). Deep tiles (BK = 64: half of
+  // the steps, twice the loads in flight per step; 128 would need 70 KB of static LDS) for those; the V-sized products keep BK = 32 (they live on occupancy).
+  const bool deep = tiles <= 128 && K >= 128 && K <= 4096;   // (the V-sized d hidden product, K = V + 1 over 20 splits, loses: 86 -> 101 us)
+  const int bk = deep ? 64 : TG_BK;
   if (split_ok) {
-    const int tiles = grid.x * grid.y, ksteps = (K + TG_BK - 1) / TG_BK;
-    int S = 1024 / tiles;                // ~4 workgroups per CU
-    if (S > ksteps / 8) S = ksteps / 8;  // >= 8 K steps per split
+    const int ksteps = (K + bk - 1) / bk;
+    int S = 1024 / tiles;                          // ~4 workgroups per CU
+    const int min_steps = deep ? 2 : 8;            // K steps per split
+    if (S > ksteps / min_steps) S = ksteps / min_steps;
     if (S > 1) grid.z = S;
   }
   // 64 x 64 tiles for every product: 128-row tiles (the template still takes them) were measured on the three V-sized
   // products of the Beauty step and lost -- scores 110 -> 127 us, the split products 82-88 -> 103 us (3 instead of 8
   // workgroups per CU, and these launches live on occupancy: K = 64 is two K steps between a cold start and the store)
-  if (grid.z > 1)
+  if (deep) {
+    if (grid.z > 1)
+      hipLaunchKernelGGL((train_gemm_kernel<64, 64, false, 64>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M,
+                         N, K, accumulate, rowsum);
+    else
+      hipLaunchKernelGGL((train_gemm_kernel<64, 64, true, 64>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M,
+                         N, K, accumulate, rowsum);
+  } else if (grid.z > 1)
     hipLaunchKernelGGL((train_gemm_kernel<64, 64, false>), grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, bias, M, N,
                        K, accumulate, rowsum);
   else
@@ -328,7 +343,7 @@ static int tr_linear_fwd(const float* X, const float* W, const float* b, float* 
 }
 // dX[R][K] = dY[R][N] W[N][K]      (accumulate optional)
 static int tr_linear_bwd_data(const float* dY, const float* W, float* dX, int R, int N, int K, int acc, hipStream_t st) {
-  return tr_gemm(dY, N, 1, W, K, 1, dX, K, nullptr, R, K, N, acc, st);
+  return tr_gemm(dY, N, 1, W, K, 1, dX, K, nullptr, R, K, N, acc, st, /*split_ok=*/acc != 0);   // adding onto dX: K may be split
 }
 // dW[N][K] += dY[R][N]^T X[R][K] and db[N] += column sums of dY   (both buffers pre-zeroed: K = R is split)
 static int tr_linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, int R, int N, int K,
