@@ -248,6 +248,35 @@ def test_grouped_bound_catalogs_vs_oracle(V, L):
     assert np.array_equal(got_i.cpu().numpy(), oi) and np.array_equal(got_s.cpu().numpy(), osc)
 
 
+@pytest.mark.parametrize("V,B", [(2047, 1), (2047, 513), (2079, 3), (2271, 513), (4097, 64), (65535, 2), (65537, 2)])
+def test_bf16_stage_ring_boundaries(V, B):
+    """The two bf16 passes stream the packed table through an LDS ring, 8 (bound) and 4 (candidates) tiles per stage, in
+    chunks of whole 4-tile groups; a workgroup is 512 users. Catalog sizes on every edge of that geometry -- 64 tiles (the
+    smallest catalog the bound serves), 65 and 71 tiles (ragged last stage, ragged last group of 4, a last tile with one /
+    thirty-one padding rows scoring -inf), 129 tiles, and 2 048 / 2 049 tiles (the switch from one maximum per tile to one
+    per group of 4) -- with one user, a few users, and one user more than a workgroup: ordered top-50 and score bits vs the
+    C oracle for every user, on the candidate path (lr_lru_topk_path = 1)."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+    from oracle import lru_oracle as O
+
+    L, K = 10, 50
+    rng = np.random.default_rng(V * 7 + B)
+    sd = init_lru_state_dict(V, seed=V % 97)
+    sd["model.bias"] = (rng.standard_normal(V + 1) * 0.05).astype(np.float32)   # non-trivial biases (the MFMA's C operand)
+    ids = np.zeros((B, L), np.int64)
+    for b in range(B):
+        n = int(rng.integers(1, L + 1))
+        ids[b, L - n:] = rng.integers(1, V + 1, size=n)
+    ids[0, -3:] = (V, V - 1, 1)                                              # the catalog's last items are history for user 0
+    model, orc = LRURec.from_state_dict(sd), O.LruOracle(sd)
+    idx, sc = model.retrieve_topk(ids, K, True)
+    assert model.last_topk_path(B, L, K, True) == 1
+    pick = np.unique(np.concatenate([np.arange(min(B, 6)), np.arange(max(0, B - 3), B), np.arange(0, B, 97)]))
+    oi, os_ = orc.retrieve_topk(ids[pick], K, True)
+    assert np.array_equal(idx.cpu().numpy()[pick], oi)
+    assert np.array_equal(_bits(sc.cpu().numpy()[pick]), _bits(os_))
+
+
 @pytest.mark.parametrize("variant", ["norms_and_bias", "history_is_the_top", "tie_blocks", "all_equal", "no_exclude_k7"])
 def test_candidate_path_adversarial(variant):
     """Catalogs of 64..2048 tiles take the bf16 bound + candidate + exact-rescore path (lru_topk.hip): its output must
