@@ -619,6 +619,20 @@ def item_gemm_roofline(dev, users=4096, reps=5):
     nbytes = (V + 1) * 65 * 4.0 + users * 64 * 4.0 + users * L * 8.0 + users * 50 * 8.0
     ach = flops / (item_ms * 1e-3) / 1e12
     del model
+    # fabric-side bytes of the item part per call, from the newest committed stage-1 PMC summary (same shape: 4 096 users)
+    traffic, traffic_src = None, None
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_stage1_pmc_summary.json")))
+    if paths:
+        import hashlib
+
+        pm = json.load(open(paths[-1]))
+        item_kernels = [k for k in pm if k.startswith(("item_", "bound_select", "cand_rescore", "hist_sort", "topk_merge"))
+                        and "hbm_bytes_per_launch" in pm[k]]
+        if item_kernels:
+            traffic = float(sum(pm[k]["hbm_bytes_per_launch"] for k in item_kernels))
+            traffic_src = (f"profiles/{os.path.basename(paths[-1])} sha256:{hashlib.sha256(open(paths[-1], 'rb').read()).hexdigest()[:16]} "
+                           f"(rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE in separate passes of tools/prof_stage1.py --only=synth-1m, "
+                           f"summed over {', '.join(sorted(item_kernels))}; not collected by this run)")
     return {"roofline_item_gemm": {
         "workload": (f"synth-1m (BASELINE.json configs[4] shape): LRURec(V={V}, L={L}, D=64, 2 blocks), {users} users "
                      f"(mean history {float(n_hist.mean()):.0f}), one retrieve_topk(ids, 50, exclude_history=1) call, median-free mean of "
@@ -632,7 +646,8 @@ def item_gemm_roofline(dev, users=4096, reps=5):
         "hbm_view": {"achieved_gbps": nbytes / (item_ms * 1e-3) / 1e9, "peak_gbps": PEAK_HBM_GBPS,
                      "frac": nbytes / (item_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                      "note": "bytes_alg once per call over the item time: the table stream is not what bounds 4 096 users"},
-        "traffic": None,
+        "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_over_bytes_alg": (traffic / nbytes) if traffic else None,
         "checks": {"top50_distinct_sampled": distinct, "no_history_item_sampled": no_hist}}}
 
 
