@@ -88,6 +88,11 @@ int lr_lru_create(const void* packed_dev, size_t packed_bytes, int32_t num_items
                   lr_lru_t** out);
 void lr_lru_destroy(lr_lru_t* h);
 
+/* Diagnostic switch: 1 (default) runs the encoder's LRU layer on the software-pipelined kernel (two 64-row tiles in
+ * flight, role-split waves), 0 on the one-tile-at-a-time kernel. Both produce the same bits (tests/test_gpu_lru.py
+ * compares them); the switch exists for that test and for A/B timing. No counterpart in the reference. */
+int lr_lru_set_encoder_pipeline(lr_lru_t* h, int32_t enable);
+
 /* Workspace (device) bytes needed by lr_lru_retrieve_topk / lr_lru_scores_last for up to
  * max_users histories of up to max_len ids per call (q rows, per-chunk partial top-K lists,
  * sorted history ids for the mask, the bound pre-pass's scratch for catalogs it serves). h must be a live handle

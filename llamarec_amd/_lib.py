@@ -27,6 +27,7 @@ PROTOTYPES = {
     "lr_lru_pack": (C.c_int, [C.POINTER(A.LrLruWeightsDesc), C.c_void_p, C.c_size_t]),
     "lr_lru_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "lr_lru_destroy": (None, [C.c_void_p]),
+    "lr_lru_set_encoder_pipeline": (C.c_int, [C.c_void_p, C.c_int32]),
     "lr_lru_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "lr_lru_encode_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),

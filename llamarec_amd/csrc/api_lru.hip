@@ -119,11 +119,18 @@ extern "C" int lr_lru_create(const void* packed_dev, size_t packed_bytes, int32_
   h->img = (const float*)packed_dev;
   h->lay = lr_lru_layout(num_items, num_blocks);
   h->device = attr.device;
+  h->encoder_pipeline = 1;
   *out = h;
   return LR_OK;
 }
 
 extern "C" void lr_lru_destroy(lr_lru_t* h) { free(h); }
+
+extern "C" int lr_lru_set_encoder_pipeline(lr_lru_t* h, int32_t enable) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_set_encoder_pipeline: null handle");
+  h->encoder_pipeline = enable ? 1 : 0;
+  return LR_OK;
+}
 
 static size_t q_bytes(int B) { return lr_align_up((size_t)B * 64 * sizeof(float), 256); }
 

@@ -123,6 +123,7 @@ struct lr_lru {
   const float* img;  // device image
   LrLruLayout lay;
   int device;
+  int encoder_pipeline;  // 1 (default): the LRU layer on em_pipe_kernel; 0: on em_layer_kernel (lr_lru_set_encoder_pipeline)
 };
 
 // ---- stage-1 launchers (lru_encoder.hip, lru_topk.hip, metrics.hip) -------------------------

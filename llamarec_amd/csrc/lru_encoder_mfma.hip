@@ -1158,9 +1158,9 @@ size_t lr_encoder_mfma_workspace_bytes(int B, int L) {
   return o;
 }
 
-// LR_EM_PIPE=0: the LRU layer and the feed-forward on em_layer_kernel (one tile at a time) instead of em_pipe_kernel -- A/B
-// runs and the bit-identity test of the two (tests/test_gpu_lru.py); both produce the same bits
-static bool em_use_pipe() {
+// LR_EM_PIPE=0 in the environment (A/B runs) or lr_lru_set_encoder_pipeline(h, 0) (the bit-identity test of the two kernels,
+// tests/test_gpu_lru.py): the LRU layer on em_layer_kernel (one tile at a time) instead of em_pipe_kernel. Same bits.
+static bool em_env_pipe() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("LR_EM_PIPE");
@@ -1170,7 +1170,7 @@ static bool em_use_pipe() {
 }
 
 template <int MODE>
-static int em_launch_layer(int grid, size_t lds, hipStream_t st, const EmLayer& p) {
+static int em_launch_layer(int grid, size_t lds, hipStream_t st, const EmLayer& p, bool pipe = true) {
   // The pipelined kernel serves the LRU layer only. Measured at Synth-1M / Beauty (gpurun_out/r4s5): LRU layer 425 -> 395 us /
   // 144 -> 139 us, feed-forward 409 -> 449 us / 152 -> 171 us. The stamps say why the gain is small and the feed-forward
   // loses: v_mfma_f32_32x32x2_f32 runs on the f32 vector datapath, so a SIMD's vector work (recurrence, LayerNorm, GELU) does
@@ -1179,7 +1179,7 @@ static int em_launch_layer(int grid, size_t lds, hipStream_t st, const EmLayer& 
   // cycles are spent: the SIMD whose A wave walks a long user's 64 rows carries 16.4 k + 5.5 k + epilogues while the others
   // wait at the barrier, and four A waves evaluate the GELU that eight waves shared.
   if constexpr (MODE == 0) {
-    if (em_use_pipe()) {
+    if (pipe && em_env_pipe()) {
       // [2][64][EM_US] intermediates | xs | hand-over | LayerNorm | 2 x tags | erf table | carry
       const size_t lds_pipe = (size_t)(2 * EM_ST * EM_US + EM_ST * EM_XS + 2 * 16 * 64 + 128 + 2 * EM_ST + LR_ERF_NINT * EM_ERF_ROW + 512) * sizeof(float);
       static bool lds_set_pipe[LR_MAX_DEVICES] = {};
@@ -1265,7 +1265,7 @@ int lr_launch_lru_encode_mfma(const lr_lru* h, const int64_t* ids, int B, int L,
       ffn.wb = img + BL.w2t; ffn.bb = img + BL.b2; ffn.lnw = img + BL.ln2_w; ffn.lnb = img + BL.ln2_b;
       if (b < nb - 1) {
         lru.OUT = Y;
-        if (int rc = em_launch_layer<0>(c.G, lds, st, lru)) return rc;
+        if (int rc = em_launch_layer<0>(c.G, lds, st, lru, h->encoder_pipeline != 0)) return rc;
         ffn.IN = Y; ffn.RES = Y; ffn.OUT = X; ffn.n_rows_ptr = c.off + c.users;  // no recurrence: super tiles strided over the rows
         if (int rc = em_launch_layer<1>(c.G, lds, st, ffn)) return rc;
       } else {  // only each user's last row is consumed after the last block

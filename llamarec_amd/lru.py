@@ -220,6 +220,11 @@ class LRURec:
                                              stream_ptr()), "lr_lru_retrieve_topk")
         return idx, sc
 
+    def set_encoder_pipeline(self, enable):
+        """Diagnostic (lr_lru_set_encoder_pipeline): the encoder's LRU layer on the pipelined kernel (default) or on the
+        one-tile-at-a-time kernel; same bits."""
+        check(lib().lr_lru_set_encoder_pipeline(self._h, int(bool(enable))), "lr_lru_set_encoder_pipeline")
+
     def last_topk_path(self, B, L, k, exclude_history=True):
         """Diagnostic (lr_lru_topk_path): which path the last retrieve_topk call of exactly this shape took -- 0 exact full
         pass, 1 bound -> candidates -> rescoring, 2 that path overflowed and the exact pass redid the call."""

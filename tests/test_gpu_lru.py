@@ -330,6 +330,33 @@ def test_candidate_path_adversarial(variant):
     assert np.array_equal(idx2.cpu().numpy(), oi[5:6]) and np.array_equal(_bits(sc2.cpu().numpy()), _bits(os_[5:6]))
 
 
+def test_pipelined_and_plain_encoder_kernels_are_bit_identical():
+    """em_pipe_kernel (two tiles in flight, phase B weights in registers, four-segment recurrence on the A waves) against
+    em_layer_kernel (one tile at a time, eight segments) for the LRU layer: the same chains in the same order, so the last
+    hidden state must be BIT-IDENTICAL -- on short users (many segments per tile), long users (one user per tile: the
+    recurrence's fast path and the carry across tiles), a mix, three blocks (two pipelined layers), and a batch small
+    enough that most workgroups own a single tile."""
+    from llamarec_amd.lru import LRURec, init_lru_state_dict
+
+    rng = np.random.default_rng(21)
+    for V, L, B, nb in ((900, 257, 3000, 2), (900, 50, 7000, 3), (500, 200, 40, 2)):
+        sd = init_lru_state_dict(V, seed=V + nb, num_blocks=nb)
+        ids = np.zeros((B, L), np.int64)
+        n = rng.integers(1, L + 1, size=B)
+        short = rng.random(B) < 0.5
+        n[short] = rng.integers(1, 10, size=int(short.sum()))
+        n[:3] = (L, 1, min(L, 65))
+        for b in range(B):
+            ids[b, L - n[b]:] = rng.integers(1, V + 1, size=n[b])
+        model = LRURec.from_state_dict(sd)
+        q_pipe = model.encode_last(ids).cpu().numpy()
+        model.set_encoder_pipeline(False)
+        q_plain = model.encode_last(ids).cpu().numpy()
+        model.set_encoder_pipeline(True)
+        assert np.isfinite(q_pipe).all()
+        assert np.array_equal(_bits(q_pipe), _bits(q_plain)), (V, L, B, nb)
+
+
 def test_encoder_chunks_segments_and_batch_independence():
     """The batched encoder beyond one chunk of users (2^21 row slots: 8 160 users at L = 257), with users of 1 .. 257 live
     rows so that super tiles hold anything from one slice of a long user (carry across tiles, no segment cut) to a
