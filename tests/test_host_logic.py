@@ -454,3 +454,43 @@ def test_bench_expected_metrics_helper_matches_the_oracle_formulas():
         for c, name in enumerate(("Recall", "MRR", "NDCG")):
             assert abs(got[f"{name}@{k}"] - sums[j, c] / n) < 1e-12
     assert got["NDCG@10"] > 0.05 and got["Recall@50"] == pytest.approx(50 / 60 * (n // 60 * 60) / n + (n % 60 if n % 60 < 50 else 50) / n, abs=1e-12)
+
+
+def test_bench_refuses_rank_mismatches_without_touching_a_gpu():
+    """bench.py's two refusal paths are decided before any HIP call (and before torch is imported in the first case), so they
+    run here: (1) under a launcher whose WORLD_SIZE differs from --gpus -> exit code 2 with a message and no result line;
+    (2) plain `python bench.py --gpus N` on a node that exposes fewer than N GPUs (this container: 0) -> exit code 2, "refusing",
+    no result line -- a smaller run is never reported as n_gpus = N."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], cwd=repo, capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and "{" not in r.stdout
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(max(n, 2))], cwd=repo, capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_expected_metrics_helpers():
+    """The float64 expectations bench.py compares the GPU's histogram metrics with (metrics_of_ranks, ndcg_at_10) against
+    trainer/utils.py:43-90's formulas for one relevant item per row, by hand."""
+    import importlib.util
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    pos = np.array([0, 4, 9, 10, 49, -1])          # 0-based ranks; -1 = not retrieved
+    m = b.metrics_of_ranks(pos, [10, 50])
+    assert abs(m["Recall@10"] - 3 / 6) < 1e-15 and abs(m["Recall@50"] - 5 / 6) < 1e-15
+    assert abs(m["MRR@10"] - (1 + 1 / 5 + 1 / 10) / 6) < 1e-15
+    assert abs(m["NDCG@10"] - (1 / np.log2(2) + 1 / np.log2(6) + 1 / np.log2(11)) / 6) < 1e-15
+    assert abs(m["NDCG@50"] - (1 / np.log2(2) + 1 / np.log2(6) + 1 / np.log2(11) + 1 / np.log2(12) + 1 / np.log2(51)) / 6) < 1e-15
+    ranked = np.array([[5, 3, 9], [1, 2, 3]])
+    assert abs(b.ndcg_at_10(ranked, [9, 7]) - (1 / np.log2(4) + 0.0) / 2) < 1e-15
