@@ -130,6 +130,12 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # torch first: it bundles its own libamdhip64, and whichever HIP runtime a process loads FIRST is the one that owns
+        # the devices -- with this library (linked against /opt/rocm's runtime) loaded before torch, its calls then fail with
+        # "no ROCm-capable device is detected" (seen when build() and smoke() ran in one process). Loaded after torch the
+        # library binds to the runtime torch already brought in, whatever the import order of the caller.
+        import torch  # noqa: F401
+
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)  # AttributeError here = header/library mismatch
