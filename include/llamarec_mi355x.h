@@ -412,6 +412,10 @@ int lr_lru_train_apply(lr_lru_train_t* h, float lr, float max_grad_norm, float* 
  * replay it afterwards (one graph launch instead of ~120 kernel launches per step). Pass the same device
  * buffers every step to stay on the replay path; any change re-captures. */
 int lr_lru_train_set_graph(lr_lru_train_t* h, int32_t enable);
+/* The LRU blocks of the step run as row-panel kernels (a 16-row panel of activations in LDS through every product of a
+ * block: 14 launches for two blocks instead of 42). enable = 0 selects the first form, one generic GEMM launch per
+ * product -- same mathematics, other summation order (the cross-check of tests/test_gpu_lru_train.py). Default 1. */
+int lr_lru_train_set_fused(lr_lru_train_t* h, int32_t enable);
 /* Device pointers of the flat parameter / gradient buffers and their length in floats. */
 int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_t* count);
 /* Offset and length (floats) of a parameter inside those buffers, by its reference state_dict name,

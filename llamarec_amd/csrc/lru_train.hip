@@ -22,10 +22,12 @@
 // atomics for the cross-row reductions (parameter-gradient sums); the item GEMM + cross-entropy is fused and
 // never materialises the logits (lru_train_ce.hip).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "lr_common.h"
 #include "lr_profile.h"
+#include "lru_train_blocks.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -127,6 +129,7 @@ struct lr_lru_train {
   int device;
   // optional hipGraph replay of the two launch sequences (keyed by every pointer and shape baked into them)
   int use_graph;
+  int fused;   // 1: the blocks run as row-panel kernels (lru_train_blocks.hip); 0: one generic GEMM launch per product
   hipGraphExec_t g_fb, g_opt;
   const void *k_tok, *k_lab, *k_out, *k_ws, *k_norm;
   int k_B, k_L;
@@ -352,21 +355,6 @@ static int tr_linear_bwd_weight(const float* dY, const float* X, float* dW, floa
 }
 
 // =============================================================================================
-// dropout: counter-based hash -> keep mask, identical in forward and backward
-// =============================================================================================
-__device__ __forceinline__ float tr_drop_scale(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
-  if (p <= 0.f) return 1.f;
-  unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * (site + 1)) ^ (idx * 0xD6E8FEB86659FD93ull);
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : 1.0f / (1.0f - p);
-}
-
-// =============================================================================================
 // row kernels (one wave per 64-feature row)
 // =============================================================================================
 __device__ __forceinline__ float tr_wave_sum(float v) {
@@ -546,7 +534,11 @@ __global__ __launch_bounds__(64) void tr_unprep_kernel(const float* plog, const 
 // =============================================================================================
 // the recurrence: forward in place (u -> h), backward in place (g -> du) + d lambda
 // =============================================================================================
-// grid: B blocks of 128 threads (thread = complex channel); rows b*L .. b*L+L-1, columns c (re) and 128+c (im)
+// grid: B blocks of 128 threads (thread = complex channel); rows b*L .. b*L+L-1, columns c (re) and 128+c (im).
+// The recurrence is a dependent chain of L steps, but its INPUTS are not: written load -> step -> store per t, every
+// step waited for its own loads (one memory latency per step: 15 us forward, 32 us backward for L = 50). A chunk of
+// TR_SCAN_T steps now has all its loads in flight before the first step runs (one exposed latency per chunk).
+#define TR_SCAN_T 32
 __global__ __launch_bounds__(128) void tr_scan_fwd(float* uh, const long long* ids, const float* lam, int L) {
   extern __shared__ unsigned char live[];  // live[t] = ids[b][t] > 0 (kept out of the dependent chain)
   const int b = blockIdx.x, c = threadIdx.x;
@@ -555,16 +547,27 @@ __global__ __launch_bounds__(128) void tr_scan_fwd(float* uh, const long long* i
   const float lr_ = lam[c], li = lam[128 + c];
   float hr = 0.f, hi = 0.f;
   float* base = uh + (size_t)b * L * 256;
-#pragma unroll 4
-  for (int t = 0; t < L; ++t) {
-    const float ur = base[t * 256 + c], ui = base[t * 256 + 128 + c];
-    const bool carry = t > 0 && live[t - 1];
-    const float nr = carry ? ur + (lr_ * hr - li * hi) : ur;
-    const float ni = carry ? ui + (lr_ * hi + li * hr) : ui;
-    hr = nr;
-    hi = ni;
-    base[t * 256 + c] = hr;
-    base[t * 256 + 128 + c] = hi;
+  for (int t0 = 0; t0 < L; t0 += TR_SCAN_T) {
+    float ur[TR_SCAN_T], ui[TR_SCAN_T];
+#pragma unroll
+    for (int i = 0; i < TR_SCAN_T; ++i) {
+      const int t = min(t0 + i, L - 1);
+      ur[i] = base[t * 256 + c];
+      ui[i] = base[t * 256 + 128 + c];
+    }
+#pragma unroll
+    for (int i = 0; i < TR_SCAN_T; ++i) {
+      const int t = t0 + i;
+      if (t < L) {
+        const bool carry = t > 0 && live[t - 1];
+        const float nr = carry ? ur[i] + (lr_ * hr - li * hi) : ur[i];
+        const float ni = carry ? ui[i] + (lr_ * hi + li * hr) : ui[i];
+        hr = nr;
+        hi = ni;
+        base[t * 256 + c] = hr;
+        base[t * 256 + 128 + c] = hi;
+      }
+    }
   }
 }
 __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, const long long* ids, const float* lam,
@@ -577,21 +580,34 @@ __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, con
   float Gr = 0.f, Gi = 0.f, dr = 0.f, di = 0.f;
   float* gb = g + (size_t)b * L * 256;
   const float* hb = h + (size_t)b * L * 256;
-#pragma unroll 4
-  for (int t = L - 1; t >= 0; --t) {
-    float gr = gb[t * 256 + c], gi = gb[t * 256 + 128 + c];
-    if (t < L - 1 && live[t]) {  // h_{t+1} = u_{t+1} + lambda h_t : G_t += conj(lambda) G_{t+1}
-      gr += lr_ * Gr + li * Gi;
-      gi += lr_ * Gi - li * Gr;
+  for (int t1 = L - 1; t1 >= 0; t1 -= TR_SCAN_T) {   // chunk t1, t1 - 1, .. (descending)
+    float vr[TR_SCAN_T], vi[TR_SCAN_T], pr[TR_SCAN_T], pi[TR_SCAN_T];
+#pragma unroll
+    for (int i = 0; i < TR_SCAN_T; ++i) {
+      const int t = max(t1 - i, 0), tp = max(t1 - i - 1, 0);
+      vr[i] = gb[t * 256 + c];
+      vi[i] = gb[t * 256 + 128 + c];
+      pr[i] = hb[tp * 256 + c];
+      pi[i] = hb[tp * 256 + 128 + c];
     }
-    Gr = gr;
-    Gi = gi;
-    gb[t * 256 + c] = Gr;
-    gb[t * 256 + 128 + c] = Gi;
-    if (t > 0 && live[t - 1]) {  // d lambda += conj(h_{t-1}) G_t
-      const float pr = hb[(t - 1) * 256 + c], pi = hb[(t - 1) * 256 + 128 + c];
-      dr += pr * Gr + pi * Gi;
-      di += pr * Gi - pi * Gr;
+#pragma unroll
+    for (int i = 0; i < TR_SCAN_T; ++i) {
+      const int t = t1 - i;
+      if (t >= 0) {
+        float gr = vr[i], gi = vi[i];
+        if (t < L - 1 && live[t]) {  // h_{t+1} = u_{t+1} + lambda h_t : G_t += conj(lambda) G_{t+1}
+          gr += lr_ * Gr + li * Gi;
+          gi += lr_ * Gi - li * Gr;
+        }
+        Gr = gr;
+        Gi = gi;
+        gb[t * 256 + c] = Gr;
+        gb[t * 256 + 128 + c] = Gi;
+        if (t > 0 && live[t - 1]) {  // d lambda += conj(h_{t-1}) G_t
+          dr += pr[i] * Gr + pi[i] * Gi;
+          di += pr[i] * Gi - pi[i] * Gr;
+        }
+      }
     }
   }
   atomicAdd(dlam + c, dr);
@@ -744,12 +760,14 @@ __global__ void tr_adamw_kernel(float* p, const float* g, float* m, float* v, co
 struct TrBlockWs {
   TrDerived d;
   float *h, *xhat1, *rstd1, *y, *a, *g, *xhat2, *rstd2, *xout;  // saved activations
+  TbTransposed t;                                                // transposed weights (row-panel path)
 };
 struct TrWs {
   float* derived;  // derived weights + their gradients, all blocks
   float *x0, *xhat0, *rstd0;
   TrBlockWs blk[LR_MAX_LRU_BLOCKS];
   float *d64a, *d64b, *d256;  // gradient scratch [R][64] x2, [R][256]
+  float *d64c, *d256b;        // row-panel path: dy0 and da stay live until the block's weight-gradient launch
   float* ce;                  // cross-entropy scratch: the fused path's partials + lse, or the stored logits
   bool materialise;           // small problem: store the [R][V+1] logits (<= 256 MB), three plain GEMM passes over them
   size_t total;
@@ -813,6 +831,15 @@ static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, ch
   w.d64a = take(r * 64);
   w.d64b = take(r * 64);
   w.d256 = take(r * 256);
+  w.d64c = take(r * 64);
+  w.d256b = take(r * 256);
+  for (int b = 0; b < lay.nb; ++b) {
+    TbTransposed& t = w.blk[b].t;
+    t.wiT = take(16384);
+    t.woT = take(16384);
+    t.w1T = take(16384);
+    t.w2T = take(16384);
+  }
   w.materialise = tr_use_materialised(cfg, R, lay.V + 1);
   // stored logits: rows padded to a multiple of 4 floats, so that the score product's 16-byte stores are aligned
   w.ce = take(w.materialise ? (size_t)R * (((size_t)lay.V + 1 + 3) & ~(size_t)3) : lr_train_ce_part_floats(R, lay.V + 1));
@@ -865,6 +892,8 @@ extern "C" int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrai
   if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_create: out of host memory");
   h->lay = tr_layout(init->num_items, init->num_blocks);
   h->cfg = *cfg;
+  h->fused = 1;
+  if (const char* e = getenv("LR_TRAIN_FUSED")) h->fused = atoi(e) != 0;   // A/B knob; lr_lru_train_set_fused is the API
   const size_t n = h->lay.total;
   h->p = (float*)state_dev;
   h->g = h->p + n;
@@ -945,6 +974,13 @@ extern "C" int lr_lru_train_set_graph(lr_lru_train_t* h, int32_t enable) {
   return LR_OK;
 }
 
+extern "C" int lr_lru_train_set_fused(lr_lru_train_t* h, int32_t enable) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_set_fused: null handle");
+  if ((enable != 0) != (h->fused != 0)) tr_drop_graphs(h);   // a captured step holds the other launch sequence
+  h->fused = enable ? 1 : 0;
+  return LR_OK;
+}
+
 extern "C" size_t lr_lru_train_workspace_bytes(const lr_lru_train_t* h, int32_t B, int32_t L) {
   if (!h || B < 1 || L < 1) return 0;
   return tr_carve(h->lay, h->cfg, B * L, nullptr).total;
@@ -1016,6 +1052,21 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     const TrBlockOff& o = lay.blk[b];
     TrBlockWs& W = ws.blk[b];
     const float* D = ws.derived;
+    if (h->fused) {
+      TR_RUN(tb_launch_transposes(D + W.d.wi, D + W.d.wo, P + o.w1, P + o.w2, W.t, st));
+      TR_RUN(tb_launch_in_proj(x, D + W.d.wi, D + W.d.bi, W.h, R, st));
+      hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), (size_t)L, st, W.h, ids, D + W.d.lam, L);
+      LR_CHECK_LAUNCH("tr_scan_fwd");
+      TbBlockFwd f;
+      f.h = W.h; f.x = x;
+      f.wo = D + W.d.wo; f.bo = D + W.d.bo; f.ln1_w = P + o.ln1_w; f.ln1_b = P + o.ln1_b;
+      f.w1 = P + o.w1; f.b1 = P + o.b1; f.w2 = P + o.w2; f.b2 = P + o.b2; f.ln2_w = P + o.ln2_w; f.ln2_b = P + o.ln2_b;
+      f.y = W.y; f.xhat1 = W.xhat1; f.rstd1 = W.rstd1; f.a = W.a; f.g = W.g; f.xout = W.xout; f.xhat2 = W.xhat2; f.rstd2 = W.rstd2;
+      f.R = R; f.seed = seed; f.site0 = 10u + 4u * b; f.p_attn = pa; f.p_drop = pd;
+      TR_RUN(tb_launch_block_fwd(f, st));
+      x = W.xout;
+      continue;
+    }
     TR_RUN(tr_linear_fwd(x, D + W.d.wi, D + W.d.bi, W.h, R, 256, 64, st));
     hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), (size_t)L, st, W.h, ids, D + W.d.lam, L);
     LR_CHECK_LAUNCH("tr_scan_fwd");
@@ -1058,6 +1109,31 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     TrBlockWs& W = ws.blk[b];
     float* D = ws.derived;
     const float* xin = b ? ws.blk[b - 1].xout : ws.x0;
+    if (h->fused) {
+      TbBlockBwd q;
+      q.dx = dx;
+      q.xhat2 = W.xhat2; q.rstd2 = W.rstd2; q.ln2_w = P + o.ln2_w; q.a = W.a; q.xhat1 = W.xhat1; q.rstd1 = W.rstd1; q.ln1_w = P + o.ln1_w;
+      q.w2T = W.t.w2T; q.w1T = W.t.w1T; q.woT = W.t.woT;
+      q.dz0 = ws.d64a; q.da = ws.d256b; q.dy0 = ws.d64c; q.dh = ws.d256;
+      q.dln2_w = G + o.ln2_w; q.dln2_b = G + o.ln2_b; q.dln1_w = G + o.ln1_w; q.dln1_b = G + o.ln1_b;
+      q.R = R; q.seed = seed; q.site0 = 10u + 4u * b; q.p_attn = pa; q.p_drop = pd;
+      TR_RUN(tb_launch_block_bwd(q, st));
+      hipLaunchKernelGGL(tr_scan_bwd, dim3(B), dim3(128), (size_t)L, st, ws.d256, W.h, ids, D + W.d.lam, D + W.d.dlam, L);
+      LR_CHECK_LAUNCH("tr_scan_bwd");
+      TR_RUN(tb_launch_in_proj_bwd(ws.d256, W.t.wiT, dx, R, st));
+      TbWeightGrads wg;
+      wg.P[0] = ws.d64a;  wg.Q[0] = W.g;  wg.dW[0] = G + o.w2;      wg.db[0] = G + o.b2;
+      wg.P[1] = ws.d256b; wg.Q[1] = W.y;  wg.dW[1] = G + o.w1;      wg.db[1] = G + o.b1;
+      wg.P[2] = ws.d64c;  wg.Q[2] = W.h;  wg.dW[2] = D + W.d.dwo;   wg.db[2] = D + W.d.dbo;
+      wg.P[3] = ws.d256;  wg.Q[3] = xin;  wg.dW[3] = D + W.d.dwi;   wg.db[3] = D + W.d.dbi;
+      wg.R = R;
+      TR_RUN(tb_launch_weight_grads(wg, st));
+      hipLaunchKernelGGL(tr_unprep_kernel, dim3(128), dim3(64), 0, st, P + o.plog, P + o.in_w, P + o.in_b, D + W.d.lam,
+                         D + W.d.dwi, D + W.d.dbi, D + W.d.dwo, D + W.d.dbo, D + W.d.dlam, G + o.plog, G + o.in_w, G + o.in_b,
+                         G + o.out_w, G + o.out_b);
+      LR_CHECK_LAUNCH("tr_unprep_kernel");
+      continue;
+    }
     float* dz0 = ws.d64a;
     // LN2: dx -> dz0 (gradient of W2 g + b2 (dropped) + y)
     // dy (residual branch, written back into dx) = the LN gradient; the W2 branch sees dropout(that) in dz0

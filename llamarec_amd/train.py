@@ -72,6 +72,10 @@ class LRUTrainEngine:
         self._tok = self._lab = None
         check(lib().lr_lru_train_set_graph(self._h, int(bool(use_graph))), "lr_lru_train_set_graph")
 
+    def set_fused(self, enable):
+        """Row-panel kernels for the LRU blocks (default) or one generic GEMM launch per product (the cross-check)."""
+        check(lib().lr_lru_train_set_fused(self._h, int(bool(enable))), "lr_lru_train_set_fused")
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:

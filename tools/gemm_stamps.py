@@ -73,6 +73,17 @@ def main():
         dur = (end - start)[:, 0]
         print(f"  workgroup wall time us: median {np.median(dur):.1f}  p5 {np.percentile(dur, 5):.1f}  p95 {np.percentile(dur, 95):.1f}; "
               f"launch span {end.max():.0f} us; sum(workgroup time) / (256 CUs x span) = {dur.sum() / (256 * end.max()):.3f}")
+        # how synchronised are the epilogues? real-time interval of each workgroup's epilogue (K loop end .. last store
+        # drained, wave group 1 = the later one), and for each the number of OTHER workgroups inside theirs at its midpoint
+        ck = np.maximum(clock[:, 1], 1e-3) * 1e3               # cycles per us
+        es = start[:, 1] + (t2 - t0)[:, 1] / ck
+        ee = start[:, 1] + (t4 - t0)[:, 1] / ck
+        mid = 0.5 * (es + ee)
+        order = np.argsort(es)
+        es_s, ee_s = es[order], np.sort(ee)
+        conc = np.searchsorted(es_s, mid, side="right") - np.searchsorted(ee_s, mid, side="left") - 1
+        print(f"  epilogue: median {np.median(ee - es):.2f} us; other workgroups in their epilogue at its midpoint: median "
+              f"{np.median(conc):.0f}  p10 {np.percentile(conc, 10):.0f}  p90 {np.percentile(conc, 90):.0f} (of {min(nwg, 256) - 1})")
         rounds = np.sort(start[:, 0])
         print("  workgroup start times (us), every 256th:", rounds[::256][:16])
 
