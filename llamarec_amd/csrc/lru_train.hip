@@ -28,6 +28,7 @@
 #include "lr_common.h"
 #include "lr_profile.h"
 #include "lru_train_blocks.h"
+#include "lru_train_scores.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -842,7 +843,10 @@ static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, ch
   }
   w.materialise = tr_use_materialised(cfg, R, lay.V + 1);
   // stored logits: rows padded to a multiple of 4 floats, so that the score product's 16-byte stores are aligned
-  w.ce = take(w.materialise ? (size_t)R * (((size_t)lay.V + 1 + 3) & ~(size_t)3) : lr_train_ce_part_floats(R, lay.V + 1));
+  {
+    const size_t generic = (size_t)R * (((size_t)lay.V + 1 + 3) & ~(size_t)3), panels = lr_train_scores_ws_floats(R, lay.V + 1);
+    w.ce = take(w.materialise ? (generic > panels ? generic : panels) : lr_train_ce_part_floats(R, lay.V + 1));
+  }
   w.total = o;
   return w;
 }
@@ -1087,8 +1091,11 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, V, h->scal);
   LR_CHECK_LAUNCH("tr_count_valid");
   float* dx = ws.d64b;
-  TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // item chunks add into it
-  if (ws.materialise) {
+  if (ws.materialise && h->fused) {
+    TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // the item splits of the d x pass add into it
+    TR_RUN(lr_launch_train_scores(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
+  } else if (ws.materialise) {
+    TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // the split product adds into it
     float* logits = ws.ce;
     const long long ldl = ((long long)C + 3) & ~3LL;   // padded row pitch (see the workspace carve)
     TR_RUN(tr_gemm(x, 64, 1, P + lay.emb, 1, 64, logits, ldl, P + lay.bias, R, C, 64, 0, st));  // scores (model/lru.py:85)
@@ -1098,6 +1105,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     // d table += d logits^T x, and d bias += column sums of d logits (the row sums of the A operand)
     TR_RUN(tr_gemm(logits, 1, ldl, x, 64, 1, G + lay.emb, 64, nullptr, C, 64, R, 1, st, true, G + lay.bias));
   } else {
+    TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // item chunks add into it
     TR_RUN(lr_launch_train_ce(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
   }
   hipLaunchKernelGGL(tr_finish_loss, dim3(1), dim3(1), 0, st, h->scal, out_loss);
