@@ -36,6 +36,21 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define TS_LOG2E 1.4426950408889634f
 #define TS_LP 68           // LDS pitch (floats) of a wave's [16][64] logits tile: 17 chunks of 16 B, conflict-free both ways
 
+
+// -DTS_STAMP (experiment builds only): s_memtime around the load-issue and compute sections of a wave's loop, printed for a few waves
+#ifdef TS_STAMP
+#include <stdio.h>
+#define TS_STAMP_DECL unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tl_ = 0, tc_ = 0, n_ = 0, tb_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
+#define TS_T(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");
+#define TS_ACC tl_ += (t1 - t0) + (t3 - t2); tc_ += (t2 - t1) + (t4 - t3); n_ += 2;
+#define TS_REPORT(name) { unsigned long long te_; TS_T(te_) if ((threadIdx.x & 63) == 0 && blockIdx.x % 61 == 0 && blockIdx.y == 0) printf(name " wg %d wave %d: %llu computes, load issue %llu, compute %llu, loop total %llu cycles -> %llu per compute\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), n_, tl_, tc_, te_ - tb_, n_ ? tc_ / n_ : 0ull); }
+#else
+#define TS_STAMP_DECL
+#define TS_T(x)
+#define TS_ACC
+#define TS_REPORT(name)
+#endif
+
 struct TsArgs {
   const float *x, *E, *bias;
   const long long* labels;
@@ -226,10 +241,6 @@ __device__ __forceinline__ float4 ts_p4(float4 l, float lse2) {
 // grid (row tiles of 64, a.ns2 item splits): a wave owns a 16-row panel, the four waves walk the same super-blocks; the splits
 // add into the pre-zeroed d x (a.ns2 adders per element). Columns past C: the logits read there are finite (clamped
 // addresses), E^T's fragments are 0. The one-hot term of dl is -E[label] / n, added once by split 0.
-struct TsDxLoads {
-  float4 l[4];       // logits rows 4 i + g of the panel, items v0 + 4 li ..  (4 rows x 256 B per instruction)
-  float4 w[4][4];    // ETf[sb][j][nb][lane]
-};
 __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
   __shared__ __attribute__((aligned(16))) float lt[4][16 * TS_LP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
@@ -239,46 +250,52 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
   const int nsb = (a.ldl + 63) >> 6;
   const int sb0 = (int)((long long)blockIdx.y * nsb / a.ns2), sb1 = (int)((long long)(blockIdx.y + 1) * nsb / a.ns2);
   float* tile = lt[wave];
-  const float* lrow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) lrow[i] = a.logits + (size_t)min(row0 + 4 * i + g, a.R - 1) * a.ldl;
+  const float* lrow0 = a.logits + (size_t)min(row0 + g, a.R - 1) * a.ldl;   // rows 4 i + g of the panel: i = 0 .. 3
+  const float* lrow1 = a.logits + (size_t)min(row0 + 4 + g, a.R - 1) * a.ldl;
+  const float* lrow2 = a.logits + (size_t)min(row0 + 8 + g, a.R - 1) * a.ldl;
+  const float* lrow3 = a.logits + (size_t)min(row0 + 12 + g, a.R - 1) * a.ldl;
   floatx4 acc[4];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-  auto load = [&](int sb, TsDxLoads& L) {
-    const int col = min((sb << 6) + 4 * li, a.ldl - 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) L.l[i] = *reinterpret_cast<const float4*>(lrow[i] + col);
-    const float* f = a.ETf + (size_t)min(sb, nsb - 1) * 4096 + lane * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) L.w[nb][j] = *reinterpret_cast<const float4*>(f + (j * 4 + nb) * 256);
-  };
-  auto compute = [&](const TsDxLoads& L) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(tile + (4 * i + g) * TS_LP + 4 * li) = L.l[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 dl = ts_p4(*reinterpret_cast<const float4*>(tile + li * TS_LP + 16 * j + 4 * g), lse2);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ts_e(L.w[nb][j], e), ts_e(dl, e), acc[nb], 0, 0, 0);
-    }
-  };
-  TsDxLoads A, B;   // unconditional loads, see ts_scores_kernel (load() clamps the addresses itself)
-  int sb = sb0;
-  load(sb, A);
-  for (; sb < sb1; sb += 2) {
-    load(sb + 1, B);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(A);
-    load(sb + 2, A);
-    __builtin_amdgcn_sched_barrier(0);
-    if (sb + 1 < sb1) compute(B);
+  // (macros, not lambdas over a struct: with the logits' registers inside a struct passed by reference hipcc kept them on the
+  // stack -- scratch_store / scratch_load round trips in front of every MFMA block)
+#define DX_LOAD(sb_, l_, w_)                                                                                      \
+  {                                                                                                               \
+    const int col_ = min(((sb_) << 6) + 4 * li, a.ldl - 4);                                                       \
+    l_##0 = *reinterpret_cast<const float4*>(lrow0 + col_);                                                       \
+    l_##1 = *reinterpret_cast<const float4*>(lrow1 + col_);                                                       \
+    l_##2 = *reinterpret_cast<const float4*>(lrow2 + col_);                                                       \
+    l_##3 = *reinterpret_cast<const float4*>(lrow3 + col_);                                                       \
+    const float* f_ = a.ETf + (size_t)min((sb_), nsb - 1) * 4096 + lane * 4;                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) w_[nb][j] = *reinterpret_cast<const float4*>(f_ + (j * 4 + nb) * 256); \
   }
+#define DX_COMPUTE(l_, w_)                                                                                        \
+  {                                                                                                               \
+    *reinterpret_cast<float4*>(tile + (0 + g) * TS_LP + 4 * li) = l_##0;                                          \
+    *reinterpret_cast<float4*>(tile + (4 + g) * TS_LP + 4 * li) = l_##1;                                          \
+    *reinterpret_cast<float4*>(tile + (8 + g) * TS_LP + 4 * li) = l_##2;                                          \
+    *reinterpret_cast<float4*>(tile + (12 + g) * TS_LP + 4 * li) = l_##3;                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+      const float4 dl = ts_p4(*reinterpret_cast<const float4*>(tile + li * TS_LP + 16 * j + 4 * g), lse2);        \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                               \
+      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                            \
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ts_e(w_[nb][j], e), ts_e(dl, e), acc[nb], 0, 0, 0);        \
+    }                                                                                                             \
+  }
+  float4 la0, la1, la2, la3, lb0, lb1, lb2, lb3, wa[4][4], wb[4][4];   // unconditional loads, see ts_scores_kernel (DX_LOAD clamps the addresses itself)
+  int sb = sb0;
+  DX_LOAD(sb, la, wa)
+  for (; sb < sb1; sb += 2) {
+    DX_LOAD(sb + 1, lb, wb)
+    __builtin_amdgcn_sched_barrier(0);
+    DX_COMPUTE(la, wa)
+    DX_LOAD(sb + 2, la, wa)
+    __builtin_amdgcn_sched_barrier(0);
+    if (sb + 1 < sb1) DX_COMPUTE(lb, wb)
+  }
+#undef DX_LOAD
+#undef DX_COMPUTE
   if (row < a.R) {
     const int lab = a.lab32[row];
     const float nv = a.scal[1];
@@ -354,15 +371,23 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   };
   TsDeLoads A, B;   // unconditional loads, see ts_scores_kernel
   int it = wave;
+  TS_STAMP_DECL
   load(min(it, nit - 1), A);
   for (; it < nit; it += 8) {
+    TS_T(t0)
     load(min(it + 4, nit - 1), B);
     __builtin_amdgcn_sched_barrier(0);
+    TS_T(t1)
     compute(A);
+    TS_T(t2)
     load(min(it + 8, nit - 1), A);
     __builtin_amdgcn_sched_barrier(0);
+    TS_T(t3)
     if (it + 4 < nit) compute(B);
+    TS_T(t4)
+    TS_ACC
   }
+  TS_REPORT("de")
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
 #pragma unroll
