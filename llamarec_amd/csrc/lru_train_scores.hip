@@ -56,7 +56,7 @@ struct TsArgs {
   const long long* labels;
   int R, C, ldl, Rpad;
   int ns, ns2;   // item splits of the score pass / of the d x pass
-  float *logits, *Ef, *ETf, *xTf, *lse, *part, *scal;
+  float *logits, *Ef, *ETf, *xTf, *biasf, *lse, *part, *scal;   // logits: [Rpad][ldl], in the log2 domain (x log2 e)
   int* lab32;
   float *dX, *dE, *dbias;
 };
@@ -67,6 +67,8 @@ __device__ __forceinline__ float ts_e(const float4& v, int e) { return e == 0 ? 
 //   Ef [sb][nb][j][lane] = E[64 sb + 16 nb + li][16 j + 4 g ..]             (0 for items >= C)
 //   ETf[sb][j][nb][lane] = E[64 sb + 16 j + 4 g + e][16 nb + li], e = 0..3   (0 for items >= C)
 //   xTf[it][nb][lane]    = x[16 it + 4 g + e][16 nb + li], e = 0..3          (0 for rows >= R)
+//   biasf[v]             = bias[v] log2 e                                   (0 for items >= C): the logits are kept in the
+//                          log2 domain (x and the bias scaled by log2 e), so every exponential downstream is one v_exp_f32
 __global__ __launch_bounds__(256) void ts_fragments_kernel(TsArgs a) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int nsb = (a.ldl + 63) >> 6, nit = a.Rpad >> 4;
@@ -87,7 +89,10 @@ __global__ __launch_bounds__(256) void ts_fragments_kernel(TsArgs a) {
     v.z = item + 2 < a.C ? a.E[(size_t)(item + 2) * 64 + d] : 0.f;
     v.w = item + 3 < a.C ? a.E[(size_t)(item + 3) * 64 + d] : 0.f;
     *reinterpret_cast<float4*>(a.ETf + u * 4) = v;
-  } else if (t < 2 * nE + nX) {
+  } else if (t >= 2 * nE + nX) {
+    const long long u = t - 2 * nE - nX;   // bias x log2 e, 0 on the padding columns
+    if (u < a.ldl) a.biasf[u] = u < a.C ? a.bias[u] * TS_LOG2E : 0.f;
+  } else {
     const long long u = t - 2 * nE;
     const int it = (int)(u >> 8), nb = (int)(u >> 6) & 3;
     const int row = 16 * it + 4 * g, d = 16 * nb + li;
@@ -117,15 +122,18 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
   float* tile = lt[wave];
   float4 xa[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * 64 + 16 * j + 4 * g);
-  float m = TS_NEG, s = 0.f;   // running maximum and sum of 2^(v log2 e - m): the statistics live in the log2 domain
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * 64 + 16 * j + 4 * g);
+    xa[j] = make_float4(t.x * TS_LOG2E, t.y * TS_LOG2E, t.z * TS_LOG2E, t.w * TS_LOG2E);
+  }
+  float m = TS_NEG, s = 0.f;   // running maximum and sum of 2^(v - m), v = logit log2 e
   auto load = [&](int sb, TsScLoads& L) {
     const float* f = a.Ef + (size_t)sb * 4096 + lane * 4;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) L.w[nb][j] = *reinterpret_cast<const float4*>(f + (nb * 4 + j) * 256);
-      L.b[nb] = *reinterpret_cast<const float4*>(a.bias + min((sb << 6) + 16 * nb + 4 * g, a.ldl - 4));   // the bias segment is padded to 64 floats
+      L.b[nb] = *reinterpret_cast<const float4*>(a.biasf + (sb << 6) + 16 * nb + 4 * g);
     }
   };
   auto compute = [&](int sb, const TsScLoads& L) {
@@ -145,8 +153,6 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
       const int n = v0 + 16 * nb + 4 * g;   // this lane's 4 items of the block
       float v[4] = {acc[nb][0] + L.b[nb].x, acc[nb][1] + L.b[nb].y, acc[nb][2] + L.b[nb].z, acc[nb][3] + L.b[nb].w};
       *reinterpret_cast<float4*>(tile + li * TS_LP + 16 * nb + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= TS_LOG2E;
       if (n + 4 > a.C) {   // the row's last items: padding columns do not count
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (n + e < a.C) ? v[e] : TS_NEG;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * i + g;
       const float4 o = *reinterpret_cast<const float4*>(tile + r * TS_LP + 4 * li);
-      if (row0 + r < a.R && col < a.ldl) *reinterpret_cast<float4*>(a.logits + (size_t)(row0 + r) * a.ldl + col) = o;
+      if (row0 + r < a.Rpad) *reinterpret_cast<float4*>(a.logits + (size_t)(row0 + r) * a.ldl + col) = o;   // padding rows: finite values
     }
   };
   // One register set of loads ahead. The sched_barrier keeps hipcc from sinking the next set's loads below the MFMAs (it
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void ts_combine_kernel(TsArgs a) {
         for (int k = 0; k < a.ns; ++k) S += p[2 * k + 1] * exp2f(p[2 * k] - M);
         const float l2 = M + log2f(S);              // log2 of the sum of exp(logit)
         lab = (int)l;
-        loss = l2 * 0.6931471805599453f - a.logits[(size_t)row * a.ldl + l];
+        loss = (l2 - a.logits[(size_t)row * a.ldl + l]) * 0.6931471805599453f;
         lse2 = l2 + log2f(a.scal[1]);               // scal[1] >= 1: this row is labelled
       }
     }
@@ -233,8 +239,8 @@ __global__ __launch_bounds__(256) void ts_combine_kernel(TsArgs a) {
 
 // softmax / n of 4 consecutive items of one row: fma + v_exp_f32 per element (0 for rows with lse2 = +inf)
 __device__ __forceinline__ float4 ts_p4(float4 l, float lse2) {
-  return make_float4(__builtin_amdgcn_exp2f(__builtin_fmaf(l.x, TS_LOG2E, -lse2)), __builtin_amdgcn_exp2f(__builtin_fmaf(l.y, TS_LOG2E, -lse2)),
-                     __builtin_amdgcn_exp2f(__builtin_fmaf(l.z, TS_LOG2E, -lse2)), __builtin_amdgcn_exp2f(__builtin_fmaf(l.w, TS_LOG2E, -lse2)));
+  return make_float4(__builtin_amdgcn_exp2f(l.x - lse2), __builtin_amdgcn_exp2f(l.y - lse2), __builtin_amdgcn_exp2f(l.z - lse2),
+                     __builtin_amdgcn_exp2f(l.w - lse2));
 }
 
 // ---- d x += dl E -------------------------------------------------------------------------------------------------------------
@@ -250,10 +256,9 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
   const int nsb = (a.ldl + 63) >> 6;
   const int sb0 = (int)((long long)blockIdx.y * nsb / a.ns2), sb1 = (int)((long long)(blockIdx.y + 1) * nsb / a.ns2);
   float* tile = lt[wave];
-  const float* lrow0 = a.logits + (size_t)min(row0 + g, a.R - 1) * a.ldl;   // rows 4 i + g of the panel: i = 0 .. 3
-  const float* lrow1 = a.logits + (size_t)min(row0 + 4 + g, a.R - 1) * a.ldl;
-  const float* lrow2 = a.logits + (size_t)min(row0 + 8 + g, a.R - 1) * a.ldl;
-  const float* lrow3 = a.logits + (size_t)min(row0 + 12 + g, a.R - 1) * a.ldl;
+  // rows 4 i + g of the panel, i = 0 .. 3: lane offsets (floats) from a per-super-block uniform base
+  const int lo0 = min(row0 + g, a.Rpad - 1) * a.ldl + 4 * li, lo1 = min(row0 + 4 + g, a.Rpad - 1) * a.ldl + 4 * li;
+  const int lo2 = min(row0 + 8 + g, a.Rpad - 1) * a.ldl + 4 * li, lo3 = min(row0 + 12 + g, a.Rpad - 1) * a.ldl + 4 * li;
   floatx4 acc[4];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -261,12 +266,13 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
   // stack -- scratch_store / scratch_load round trips in front of every MFMA block)
 #define DX_LOAD(sb_, l_, w_)                                                                                      \
   {                                                                                                               \
-    const int col_ = min(((sb_) << 6) + 4 * li, a.ldl - 4);                                                       \
-    l_##0 = *reinterpret_cast<const float4*>(lrow0 + col_);                                                       \
-    l_##1 = *reinterpret_cast<const float4*>(lrow1 + col_);                                                       \
-    l_##2 = *reinterpret_cast<const float4*>(lrow2 + col_);                                                       \
-    l_##3 = *reinterpret_cast<const float4*>(lrow3 + col_);                                                       \
-    const float* f_ = a.ETf + (size_t)min((sb_), nsb - 1) * 4096 + lane * 4;                                      \
+    const int sbc_ = min((sb_), nsb - 1);                                                                         \
+    const float* lb_ = a.logits + (sbc_ << 6);                                                                    \
+    l_##0 = *reinterpret_cast<const float4*>(lb_ + lo0);                                                          \
+    l_##1 = *reinterpret_cast<const float4*>(lb_ + lo1);                                                          \
+    l_##2 = *reinterpret_cast<const float4*>(lb_ + lo2);                                                          \
+    l_##3 = *reinterpret_cast<const float4*>(lb_ + lo3);                                                          \
+    const float* f_ = a.ETf + (size_t)sbc_ * 4096 + lane * 4;                                                     \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
     _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) w_[nb][j] = *reinterpret_cast<const float4*>(f_ + (j * 4 + nb) * 256); \
   }
@@ -319,7 +325,6 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
 struct TsDeLoads {
   float4 l[4];    // logits[r0 + 4 g + e][v0 + 4 li ..]
   float4 lse;     // lse2[r0 + 4 g ..]
-  int4 lab;
   float4 x[4];    // xTf[it][nb][lane]
 };
 __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
@@ -328,9 +333,9 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   float* bred = dyn + 4 * 64 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int v0 = blockIdx.x * 64, first = v0 + 4 * li;
-  const int vc = min(first, a.ldl - 4);
-  const float nv = a.scal[1];
-  const float inv_n = nv > 0.f ? 1.0f / nv : 0.f;
+  int lo[4];   // lane offsets (floats) of rows 4 g + e from a per-step uniform base
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lo[e] = (4 * g + e) * a.ldl + first;
   const int nit = a.Rpad >> 4;
   floatx4 acc[4][4];   // [sub-panel s][feature block nb]: D[d = 16 nb + 4 g + r][item v0 + 4 li + s]
 #pragma unroll
@@ -340,10 +345,10 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
   auto load = [&](int it, TsDeLoads& L) {
     const int r0 = (it << 4) + 4 * g;
+    const float* lb = a.logits + (size_t)(it << 4) * a.ldl;   // [Rpad] rows exist: no clamp
 #pragma unroll
-    for (int e = 0; e < 4; ++e) L.l[e] = *reinterpret_cast<const float4*>(a.logits + (size_t)min(r0 + e, a.R - 1) * a.ldl + vc);
+    for (int e = 0; e < 4; ++e) L.l[e] = *reinterpret_cast<const float4*>(lb + lo[e]);
     L.lse = *reinterpret_cast<const float4*>(a.lse + r0);
-    L.lab = *reinterpret_cast<const int4*>(a.lab32 + r0);
     const float* f = a.xTf + (size_t)it * 1024 + lane * 4;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) L.x[nb] = *reinterpret_cast<const float4*>(f + nb * 256);
@@ -351,13 +356,7 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   auto compute = [&](const TsDeLoads& L) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int lab = e == 0 ? L.lab.x : e == 1 ? L.lab.y : e == 2 ? L.lab.z : L.lab.w;
-      float4 dl = ts_p4(L.l[e], ts_e(L.lse, e));
-      const unsigned k = (unsigned)(lab - first);   // the row's label among this lane's 4 items? (label -1: never)
-      dl.x -= k == 0u ? inv_n : 0.f;
-      dl.y -= k == 1u ? inv_n : 0.f;
-      dl.z -= k == 2u ? inv_n : 0.f;
-      dl.w -= k == 3u ? inv_n : 0.f;
+      const float4 dl = ts_p4(L.l[e], ts_e(L.lse, e));   // softmax / n; the one-hot term: ts_onehot_kernel
       bs[0] += dl.x;
       bs[1] += dl.y;
       bs[2] += dl.z;
@@ -418,14 +417,25 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   if (tid < 64 && v0 + tid < a.C) a.dbias[v0 + tid] += (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]);
 }
 
+// ---- the one-hot term of dl for d E and d bias: d E[label[r]] -= x[r] / n, d bias[label[r]] -= 1 / n (a wave per row) -----------
+__global__ __launch_bounds__(256) void ts_onehot_kernel(TsArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.R) return;
+  const int lab = a.lab32[row];
+  if (lab < 0) return;
+  const float inv_n = 1.0f / a.scal[1];
+  atomicAdd(a.dE + (size_t)lab * 64 + lane, -inv_n * a.x[(size_t)row * 64 + lane]);
+  if (lane == 0) atomicAdd(a.dbias + lab, -inv_n);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------
-static inline int ts_ldl(int C) { return (C + 15) & ~15; }
+static inline int ts_ldl(int C) { return (C + 63) & ~63; }   // logits pitch: whole 64-item super-blocks
 static inline int ts_rpad(int R) { return (R + 15) & ~15; }
 static inline size_t ts_up64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 size_t lr_train_scores_ws_floats(int R, int C) {
   const size_t ldl = ts_ldl(C), rp = ts_rpad(R), nsb = (ldl + 63) / 64;
-  return ts_up64((size_t)R * ldl) + 2 * nsb * 4096 + (rp / 16) * 1024 + ts_up64(rp) + ts_up64(rp) + ts_up64((size_t)R * TS_NS_MAX * 2);
+  return ts_up64(rp * ldl) + 2 * nsb * 4096 + (rp / 16) * 1024 + ldl + ts_up64(rp) + ts_up64(rp) + ts_up64((size_t)R * TS_NS_MAX * 2);
 }
 
 int lr_launch_train_scores(const float* x, const float* E, const float* bias, const long long* labels, int R, int C, float* ws,
@@ -437,10 +447,11 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   a.R = R; a.C = C; a.ldl = ts_ldl(C); a.Rpad = ts_rpad(R);
   const int n64 = (R + 63) / 64, nsb = (a.ldl + 63) / 64;
   float* p = ws;
-  a.logits = p; p += ts_up64((size_t)R * a.ldl);
+  a.logits = p; p += ts_up64((size_t)a.Rpad * a.ldl);
   a.Ef = p;     p += (size_t)nsb * 4096;
   a.ETf = p;    p += (size_t)nsb * 4096;
   a.xTf = p;    p += (size_t)(a.Rpad / 16) * 1024;
+  a.biasf = p;  p += a.ldl;
   a.lse = p;    p += ts_up64(a.Rpad);
   a.lab32 = reinterpret_cast<int*>(p); p += ts_up64(a.Rpad);
   a.part = p;
@@ -451,7 +462,7 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   a.ns2 = 256 / n64 < 1 ? 1 : 256 / n64 > 8 ? 8 : 256 / n64;
   if (a.ns > nsb) a.ns = nsb;
   if (a.ns2 > nsb) a.ns2 = nsb;
-  const long long nt = 2LL * nsb * 1024 + (long long)(a.Rpad / 16) * 256;
+  const long long nt = 2LL * nsb * 1024 + (long long)(a.Rpad / 16) * 256 + a.ldl;
   hipLaunchKernelGGL(ts_fragments_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_fragments_kernel");
   hipLaunchKernelGGL(ts_scores_kernel, dim3(n64, a.ns), dim3(256), 0, st, a);
@@ -465,5 +476,7 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   if (rc) return rc;
   hipLaunchKernelGGL(ts_de_kernel, dim3((C + 63) / 64), dim3(256), de_lds, st, a);
   LR_CHECK_LAUNCH("ts_de_kernel");
+  hipLaunchKernelGGL(ts_onehot_kernel, dim3((R + 3) / 4), dim3(256), 0, st, a);
+  LR_CHECK_LAUNCH("ts_onehot_kernel");
   return LR_OK;
 }
