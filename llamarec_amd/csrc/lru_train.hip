@@ -409,7 +409,8 @@ __global__ __launch_bounds__(256) void tr_res_ln_fwd(const float* o, const float
 // one kernel instead of LN backward + copy + dropout backward.
 __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* w,
                                                  float* de, float* dw, float* db, int R, float* res = nullptr,
-                                                 const unsigned long long* seedp = nullptr, unsigned site = 0, float p = 0.f) {
+                                                 const unsigned long long* seedp = nullptr, unsigned site = 0, float p = 0.f,
+                                                 const long long* ids = nullptr, int V = 0, float* dE = nullptr) {
   __shared__ float sw[4][64], sb[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float wl = w[lane];
@@ -426,7 +427,13 @@ __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* x
       const float m1 = tr_wave_sum(dxh) * (1.0f / 64);
       const float m2 = tr_wave_sum(dxh * xh) * (1.0f / 64);
       const float d = rstd[row] * (dxh - m1 - xh * m2);
-      if (res) {
+      if (dE) {   // the embedding LayerNorm: the row's gradient goes straight into its table row (through the embedding
+                  // dropout's mask; unlabelled pad positions have an exactly zero gradient and are skipped)
+        long long id = ids[row];
+        if (id < 0 || id > V) id = 0;
+        const float v = d * tr_drop_scale(*seedp, site, i, p);
+        if (v != 0.f) atomicAdd(dE + id * 64 + lane, v);
+      } else if (res) {
         res[i] = d;
         de[i] = d * tr_drop_scale(*seedp, site, i, p);
       } else {
@@ -473,8 +480,21 @@ struct TrDerived {  // offsets (floats) inside the workspace's derived region, p
   size_t dwi, dbi, dwo, dbo, dlam;
 };
 
-__global__ void tr_prep_kernel(const float* plog, const float* in_w, const float* in_b, const float* out_w,
-                               const float* out_b, float* wi, float* bi, float* wo, float* bo, float* lam) {
+struct TrPrepBlock {
+  const float *plog, *in_w, *in_b, *out_w, *out_b, *w1, *w2;
+  float *wi, *bi, *wo, *bo, *lam;
+  TbTransposed t;
+};
+struct TrPrepArgs {
+  TrPrepBlock blk[LR_MAX_LRU_BLOCKS];
+};
+// grid (64, blocks): the derived weights of every block in one launch; with_t: also the transposed copies of the four
+// 64 x 256 matrices the row-panel kernels' data-gradient products read (tb_transpose_kernel's work: wi^T and wo^T are
+// written from the same registers as wi and wo)
+__global__ __launch_bounds__(256) void tr_prep_kernel(TrPrepArgs a, int with_t) {
+  const TrPrepBlock& q = a.blk[blockIdx.y];
+  const float *plog = q.plog, *in_w = q.in_w, *in_b = q.in_b, *out_w = q.out_w, *out_b = q.out_b;
+  float *wi = q.wi, *bi = q.bi, *wo = q.wo, *bo = q.bo, *lam = q.lam;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 16383
   if (i < 128) {
     const float nu = expf(plog[i]), th = expf(plog[128 + i]);
@@ -489,13 +509,27 @@ __global__ void tr_prep_kernel(const float* plog, const float* in_w, const float
   if (i < 128 * 64) {  // in_w[c][k] complex
     const int c = i >> 6, k = i & 63;
     const float ga = expf(plog[256 + c]);
-    wi[c * 64 + k] = ga * in_w[2 * i];
-    wi[(128 + c) * 64 + k] = ga * in_w[2 * i + 1];
+    const float re = ga * in_w[2 * i], im = ga * in_w[2 * i + 1];
+    wi[c * 64 + k] = re;
+    wi[(128 + c) * 64 + k] = im;
+    if (with_t) {
+      q.t.wiT[k * 256 + c] = re;
+      q.t.wiT[k * 256 + 128 + c] = im;
+    }
   }
   if (i < 64 * 128) {  // out_w[o][c] complex
     const int o = i >> 7, c = i & 127;
-    wo[o * 256 + c] = out_w[2 * i];
-    wo[o * 256 + 128 + c] = -out_w[2 * i + 1];
+    const float re = out_w[2 * i], im = -out_w[2 * i + 1];
+    wo[o * 256 + c] = re;
+    wo[o * 256 + 128 + c] = im;
+    if (with_t) {
+      q.t.woT[c * 64 + o] = re;
+      q.t.woT[(128 + c) * 64 + o] = im;
+    }
+  }
+  if (with_t) {   // w1 [256][64] -> w1T [64][256]; w2 [64][256] -> w2T [256][64]
+    q.t.w1T[(i & 63) * 256 + (i >> 6)] = q.w1[i];
+    q.t.w2T[(i & 255) * 64 + (i >> 8)] = q.w2[i];
   }
 }
 
@@ -620,22 +654,6 @@ __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, con
 // =============================================================================================
 // labels: 0 = ignored (CrossEntropyLoss(ignore_index=0)); a label outside [0, V] would index past the logit row --
 // torch raises there, here such rows are ignored too and counted in scal[3] (reported as out_loss[2])
-__global__ void tr_count_valid(const long long* labels, int R, int V, float* scal) {
-  __shared__ int s, bad;
-  if (threadIdx.x == 0) s = bad = 0;
-  __syncthreads();
-  int c = 0, b = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
-    const long long l = labels[i];
-    c += l > 0 && l <= V;
-    b += l < 0 || l > V;
-  }
-  atomicAdd(&s, c);
-  if (b) atomicAdd(&bad, b);
-  __syncthreads();
-  if (threadIdx.x == 0 && s) atomicAdd(scal + 1, (float)s);
-  if (threadIdx.x == 0 && bad) atomicAdd(scal + 3, (float)bad);
-}
 __device__ __forceinline__ float tr_block_reduce(float v, bool is_max, float* sh) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -658,7 +676,7 @@ __global__ __launch_bounds__(256) void tr_ce_kernel(float* logits, long long ld,
   const int row = blockIdx.x;
   float* x = logits + row * ld;
   const long long lab = labels[row];
-  if (lab <= 0 || lab >= C) {  // ignore_index (or out of range, see tr_count_valid): no loss, no gradient
+  if (lab <= 0 || lab >= C) {  // ignore_index (or out of range: counted in scal[3]): no loss, no gradient
     for (int j = threadIdx.x; j < C; j += 256) x[j] = 0.f;
     return;
   }
@@ -678,11 +696,7 @@ __global__ __launch_bounds__(256) void tr_ce_kernel(float* logits, long long ld,
   if (threadIdx.x == 0) atomicAdd(scal, logf(se) + mx - picked);
 }
 // device-side counters (so that a captured graph can be replayed): ctr[0] optimizer steps, ctr[1] forward passes,
-// ctr[2] dropout seed of the current pass
-__global__ void tr_begin_pass(unsigned long long* ctr, unsigned long long seedbase) {
-  ctr[2] = seedbase + ctr[1] * 0xA24BAED4963EE407ull;
-  ctr[1] += 1;
-}
+// ctr[2] dropout seed of the current pass (advanced by tr_pass_init_kernel)
 // zero / copy as kernels, not hipMemsetAsync / hipMemcpyAsync. Round 1 saw wrong gradients "from the second step on"
 // with memset / memcpy nodes in the captured step and blamed their ordering. tools/diag/graph_memset_order.cpp
 // (profiles/r02_graph_memset_order.txt) shows the ordering is fine on this stack -- a captured kernel -> memset ->
@@ -691,6 +705,44 @@ __global__ void tr_begin_pass(unsigned long long* ctr, unsigned long long seedba
 // stack variable; the first launch (same call) read it alive, every later replay read a dead stack slot. The scalars
 // now travel as launch arguments of a 1-thread kernel (tr_set_step_scalars, outside the captured part), and zeroing /
 // copying stays in kernels so that nothing in the replayed graph refers to host memory at all.
+// Start of a pass in ONE launch (they were six: the seed, three zero fills, the label count, the zero fill of d x): every
+// workgroup zeroes its share of the gradient buffer, of the derived-weight gradients and of d x; workgroup 0 also advances
+// the dropout seed, zeroes the step scalars and counts the labelled rows (scal[1]) and the out-of-range labels (scal[3])
+// by itself -- no atomics onto words another workgroup of this launch might still be zeroing.
+__global__ __launch_bounds__(256) void tr_pass_init_kernel(float* G, size_t n_g, float* dgrad, size_t n_d, float* dx, size_t n_x,
+                                                           float* scal, unsigned long long* ctr, unsigned long long seedbase,
+                                                           const long long* labels, int R, int V) {
+  const size_t stride = (size_t)gridDim.x * 256, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (size_t i = t; i < n_g; i += stride) G[i] = 0.f;
+  for (size_t i = t; i < n_d; i += stride) dgrad[i] = 0.f;
+  for (size_t i = t; i < n_x; i += stride) dx[i] = 0.f;
+  if (blockIdx.x != 0) return;
+  __shared__ int s_ok[4], s_bad[4];
+  int c = 0, b = 0;
+  for (int i = threadIdx.x; i < R; i += 256) {
+    const long long l = labels[i];
+    c += l > 0 && l <= V;
+    b += l < 0 || l > V;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    c += __shfl_xor(c, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_ok[threadIdx.x >> 6] = c;
+    s_bad[threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ctr[2] = seedbase + ctr[1] * 0xA24BAED4963EE407ull;   // this pass's dropout seed
+    ctr[1] += 1;
+    scal[0] = 0.f;
+    scal[1] = (float)(s_ok[0] + s_ok[1] + s_ok[2] + s_ok[3]);
+    scal[2] = 0.f;
+    scal[3] = (float)(s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3]);
+  }
+}
 __global__ void tr_zero_kernel(float* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -707,20 +759,6 @@ __global__ void tr_finish_loss(float* scal, float* out) {
   out[0] = scal[0] / fmaxf(scal[1], 1.0f);
   out[1] = scal[1];
   out[2] = scal[3];
-}
-
-// embedding backward: dE[id] += de[row]
-__global__ __launch_bounds__(256) void tr_embed_bwd(const float* de, const long long* ids, int V, float* dE, int R,
-                                                    const unsigned long long* seedp, float p) {
-  const unsigned long long seed = *seedp;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R) return;
-  long long id = ids[row];
-  if (id < 0 || id > V) id = 0;
-  // unlabelled pad positions have an exactly zero gradient; skipping them keeps hundreds of waves off the 64
-  // addresses of table row 0
-  const float v = de[(size_t)row * 64 + lane] * tr_drop_scale(seed, 0, (unsigned long long)row * 64 + lane, p);
-  if (v != 0.f) atomicAdd(dE + id * 64 + lane, v);
 }
 
 // =============================================================================================
@@ -1029,24 +1067,31 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   const long long* lab = (const long long*)labels;
   float *P = h->p, *G = h->g;
   const unsigned long long* seed = h->ctr + 2;
-  hipLaunchKernelGGL(tr_begin_pass, dim3(1), dim3(1), 0, st, h->ctr, h->cfg.seed * 0x9E3779B97F4A7C15ull);
-  LR_CHECK_LAUNCH("tr_begin_pass");
   const float pd = h->cfg.dropout, pa = h->cfg.attn_dropout;
   const unsigned grid_rows = (unsigned)((R + 3) / 4);
-
-  TR_EW(tr_zero_kernel, lay.total, G, lay.total);
-  TR_EW(tr_zero_kernel, (size_t)4, h->scal, (size_t)4);
-  {  // gradients of the derived weights start from zero as well
+  float* dx = ws.d64b;   // gradient of the blocks' output, then of each block's input
+  {  // seed, zero fills (gradients, derived-weight gradients, d x), label counts
     const TrDerived& d0 = ws.blk[0].d;
     const TrDerived& dl = ws.blk[lay.nb - 1].d;
-    TR_EW(tr_zero_kernel, dl.dlam + 256 - d0.wi, ws.derived + d0.wi, dl.dlam + 256 - d0.wi);
+    hipLaunchKernelGGL(tr_pass_init_kernel, dim3(512), dim3(256), 0, st, G, lay.total, ws.derived + d0.wi, dl.dlam + 256 - d0.wi, dx,
+                       (size_t)R * 64, h->scal, h->ctr, h->cfg.seed * 0x9E3779B97F4A7C15ull, lab, R, V);
+    LR_CHECK_LAUNCH("tr_pass_init_kernel");
   }
   // ---- forward
-  for (int b = 0; b < lay.nb; ++b) {
-    const TrBlockOff& o = lay.blk[b];
-    const TrDerived& d = ws.blk[b].d;
-    TR_EW(tr_prep_kernel, 128 * 64, P + o.plog, P + o.in_w, P + o.in_b, P + o.out_w, P + o.out_b, ws.derived + d.wi,
-          ws.derived + d.bi, ws.derived + d.wo, ws.derived + d.bo, ws.derived + d.lam);
+  {  // derived weights of every block (and, for the row-panel kernels, the transposed matrices): one launch
+    TrPrepArgs pa_;
+    for (int b = 0; b < LR_MAX_LRU_BLOCKS; ++b) {
+      const int bb = b < lay.nb ? b : 0;
+      const TrBlockOff& o = lay.blk[bb];
+      const TrDerived& d = ws.blk[bb].d;
+      TrPrepBlock& q = pa_.blk[b];
+      q.plog = P + o.plog; q.in_w = P + o.in_w; q.in_b = P + o.in_b; q.out_w = P + o.out_w; q.out_b = P + o.out_b;
+      q.w1 = P + o.w1; q.w2 = P + o.w2;
+      q.wi = ws.derived + d.wi; q.bi = ws.derived + d.bi; q.wo = ws.derived + d.wo; q.bo = ws.derived + d.bo; q.lam = ws.derived + d.lam;
+      q.t = ws.blk[bb].t;
+    }
+    hipLaunchKernelGGL(tr_prep_kernel, dim3(64, lay.nb), dim3(256), 0, st, pa_, h->fused);
+    LR_CHECK_LAUNCH("tr_prep_kernel");
   }
   hipLaunchKernelGGL(tr_embed_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ids, P + lay.emb, V, P + lay.eln_w,
                      P + lay.eln_b, ws.x0, ws.xhat0, ws.rstd0, R, seed, pd);
@@ -1057,7 +1102,6 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     TrBlockWs& W = ws.blk[b];
     const float* D = ws.derived;
     if (h->fused) {
-      TR_RUN(tb_launch_transposes(D + W.d.wi, D + W.d.wo, P + o.w1, P + o.w2, W.t, st));
       TR_RUN(tb_launch_in_proj(x, D + W.d.wi, D + W.d.bi, W.h, R, st));
       hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), (size_t)L, st, W.h, ids, D + W.d.lam, L);
       LR_CHECK_LAUNCH("tr_scan_fwd");
@@ -1088,14 +1132,10 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   }
   // ---- item GEMM + cross-entropy, fused (lru_train_ce.hip): the [R x (V+1)] logits are never stored.
   // d x_final -> d64b, d table and d bias are added into the gradient buffer
-  hipLaunchKernelGGL(tr_count_valid, dim3(64), dim3(256), 0, st, lab, R, V, h->scal);
-  LR_CHECK_LAUNCH("tr_count_valid");
-  float* dx = ws.d64b;
+  // (d x was zeroed and the labelled rows were counted by tr_pass_init_kernel: every variant below adds into d x)
   if (ws.materialise && h->fused) {
-    TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // the item splits of the d x pass add into it
     TR_RUN(lr_launch_train_scores(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
   } else if (ws.materialise) {
-    TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // the split product adds into it
     float* logits = ws.ce;
     const long long ldl = ((long long)C + 3) & ~3LL;   // padded row pitch (see the workspace carve)
     TR_RUN(tr_gemm(x, 64, 1, P + lay.emb, 1, 64, logits, ldl, P + lay.bias, R, C, 64, 0, st));  // scores (model/lru.py:85)
@@ -1105,7 +1145,6 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     // d table += d logits^T x, and d bias += column sums of d logits (the row sums of the A operand)
     TR_RUN(tr_gemm(logits, 1, ldl, x, 64, 1, G + lay.emb, 64, nullptr, C, 64, R, 1, st, true, G + lay.bias));
   } else {
-    TR_EW(tr_zero_kernel, (size_t)R * 64, dx, (size_t)R * 64);  // item chunks add into it
     TR_RUN(lr_launch_train_ce(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
   }
   hipLaunchKernelGGL(tr_finish_loss, dim3(1), dim3(1), 0, st, h->scal, out_loss);
@@ -1173,10 +1212,9 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   }
   // ---- embedding LayerNorm and the lookup
   hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, ws.xhat0, ws.rstd0, P + lay.eln_w, ws.d64a,
-                     G + lay.eln_w, G + lay.eln_b, R);
+                     G + lay.eln_w, G + lay.eln_b, R, nullptr, seed, 0u, pd, ids, V, G + lay.emb);
   LR_CHECK_LAUNCH("tr_ln_bwd");
-  hipLaunchKernelGGL(tr_embed_bwd, dim3(grid_rows), dim3(256), 0, st, ws.d64a, ids, V, G + lay.emb, R, seed, pd);
-  LR_CHECK_LAUNCH("tr_embed_bwd");
+  (void)grid_rows;
   return LR_OK;
 }
 

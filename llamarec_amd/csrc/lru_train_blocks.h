@@ -20,11 +20,11 @@ __device__ __forceinline__ float tr_drop_scale(unsigned long long seed, unsigned
   return u < p ? 0.f : 1.0f / (1.0f - p);
 }
 
-// transposed copies of a block's four weight matrices (the data-gradient products read W[n][k] along n)
+// transposed copies of a block's four weight matrices (the data-gradient products read W[n][k] along n), written by
+// tr_prep_kernel (lru_train.hip) together with the derived weights
 struct TbTransposed {
   float *wiT, *woT, *w1T, *w2T;   // [64][256], [256][64], [64][256], [256][64]
 };
-int tb_launch_transposes(const float* wi, const float* wo, const float* w1, const float* w2, const TbTransposed& t, hipStream_t st);
 
 // u[R][256] = x[R][64] wi[256][64]^T + bi
 int tb_launch_in_proj(const float* x, const float* wi, const float* bi, float* u, int R, hipStream_t st);

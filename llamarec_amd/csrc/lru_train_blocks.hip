@@ -69,26 +69,6 @@ __device__ __forceinline__ float4 tb_ld4(const float* p, bool ok) {
 }
 
 // =============================================================================================
-// transposes of the four weight matrices (once per pass)
-// =============================================================================================
-__global__ __launch_bounds__(256) void tb_transpose_kernel(const float* wi, const float* wo, const float* w1, const float* w2,
-                                                           TbTransposed t) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // 0 .. 16383
-  const int m = blockIdx.y;
-  const float* src = m == 0 ? wi : m == 1 ? wo : m == 2 ? w1 : w2;
-  float* dst = m == 0 ? t.wiT : m == 1 ? t.woT : m == 2 ? t.w1T : t.w2T;
-  // wi, w1: [256][64] -> [64][256];  wo, w2: [64][256] -> [256][64]
-  const int cols = (m == 0 || m == 2) ? 64 : 256, rows = 16384 / cols;
-  const int r = i / cols, c = i % cols;
-  dst[c * rows + r] = src[i];
-}
-int tb_launch_transposes(const float* wi, const float* wo, const float* w1, const float* w2, const TbTransposed& t, hipStream_t st) {
-  hipLaunchKernelGGL(tb_transpose_kernel, dim3(64, 4), dim3(256), 0, st, wi, wo, w1, w2, t);
-  LR_CHECK_LAUNCH("tb_transpose_kernel");
-  return LR_OK;
-}
-
-// =============================================================================================
 // in_proj forward: u = x wi^T + bi        (no LDS: the panel's rows go from global memory into operand registers)
 // =============================================================================================
 __global__ __launch_bounds__(256) void tb_in_proj_kernel(const float* __restrict__ x, const float* __restrict__ wi,

@@ -7,10 +7,10 @@
 // 4.95 GFLOP each = 31.5 us at the fp32 MFMA peak. Here:
 //   ts_scores_kernel   a wave holds a 16-row panel of x in operand registers, the table streams through as the other MFMA
 //                      operand; writes the logits and, per (row, item split), the running (max, sum) -- no softmax pass
-//   ts_combine_kernel  per row: lse from the partials, the loss term, lse = +inf / label = -1 for unlabelled rows
+//   ts_combine_kernel  per row: lse from the partials, the loss term, lse = +inf / label = -1 for unlabelled rows, and the
+//                      one-hot half of dl = softmax / n - onehot / n as rank-1 updates of d x, d E and d bias
 //   ts_dx_kernel       d x = dl E: 16-row panels per wave, dl = softmax / n formed in the operand registers from the stored
-//                      logits (one fma + v_exp_f32 per element), E^T streamed; the one-hot term is a rank-1 correction at
-//                      the end; item splits add with atomics
+//                      logits (one v_exp_f32 per element), E^T streamed; item splits add with atomics
 //   ts_de_kernel       d E = dl^T x, d bias: 64-item panels, rows streamed, the four waves of a workgroup split the rows
 //                      and meet in LDS; every (item, feature) has one owner: no atomics
 // v_mfma_f32_16x16x4_f32 with the K index permuted inside groups of 16 (see lru_train_blocks.hip): both operands of a
@@ -201,35 +201,45 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
   }
 }
 
-// ---- per row: lse, loss term, and what the gradient kernels want ---------------------------------------------------------
-//   lse2[row] = lse log2 e + log2 n  (so that 2^(logit log2 e - lse2) = softmax / n), +inf for unlabelled and padding rows
+// ---- per row (a wave each): lse, the loss term, what the gradient kernels want, and the one-hot half of dl -----------------
+//   lse2[row] = log2 sum 2^logit2 + log2 n  (so that 2^(logit2 - lse2) = softmax / n), +inf for unlabelled and padding rows
+//   dl = softmax / n - onehot / n: the three gradient products use the first term; the second is rank 1 per row and is added
+//   here: d x[row] = -E[label] / n (d x is zero before this launch), d E[label] -= x[row] / n, d bias[label] -= 1 / n
 __global__ __launch_bounds__(256) void ts_combine_kernel(TsArgs a) {
   __shared__ float sh[4];
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   float loss = 0.f;
   if (row < a.Rpad) {
     float lse2 = __builtin_inff();
     int lab = -1;
     if (row < a.R) {
       const long long l = a.labels[row];
-      if (l > 0 && l < a.C) {   // 0 = ignore_index; out of range: ignored and counted by tr_count_valid
+      if (l > 0 && l < a.C) {   // 0 = ignore_index; out of range: ignored (and counted in scal[3])
         const float* p = a.part + (size_t)row * a.ns * 2;
-        float M = p[0];
-        for (int k = 1; k < a.ns; ++k) M = fmaxf(M, p[2 * k]);
-        float S = 0.f;
-        for (int k = 0; k < a.ns; ++k) S += p[2 * k + 1] * exp2f(p[2 * k] - M);
-        const float l2 = M + log2f(S);              // log2 of the sum of exp(logit)
+        const float mk = lane < a.ns ? p[2 * lane] : TS_NEG, sk = lane < a.ns ? p[2 * lane + 1] : 0.f;
+        float M = mk;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+        float S = sk * exp2f(mk - M);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) S += __shfl_xor(S, o, 64);
+        const float l2 = M + log2f(S);              // log2 of the sum of 2^logit2
         lab = (int)l;
+        const float nv = a.scal[1];                 // >= 1: this row is labelled
         loss = (l2 - a.logits[(size_t)row * a.ldl + l]) * 0.6931471805599453f;
-        lse2 = l2 + log2f(a.scal[1]);               // scal[1] >= 1: this row is labelled
+        lse2 = l2 + log2f(nv);
+        const float inv_n = 1.0f / nv;
+        a.dX[(size_t)row * 64 + lane] = -inv_n * a.E[(size_t)lab * 64 + lane];
+        atomicAdd(a.dE + (size_t)lab * 64 + lane, -inv_n * a.x[(size_t)row * 64 + lane]);
+        if (lane == 0) atomicAdd(a.dbias + lab, -inv_n);
       }
     }
-    a.lse[row] = lse2;
-    a.lab32[row] = lab;
+    if (lane == 0) {
+      a.lse[row] = lse2;
+      a.lab32[row] = lab;
+    }
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) loss += __shfl_xor(loss, o, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = loss;
+  if (lane == 0) sh[threadIdx.x >> 6] = loss;
   __syncthreads();
   if (threadIdx.x == 0) {
     const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
@@ -245,8 +255,8 @@ __device__ __forceinline__ float4 ts_p4(float4 l, float lse2) {
 
 // ---- d x += dl E -------------------------------------------------------------------------------------------------------------
 // grid (row tiles of 64, a.ns2 item splits): a wave owns a 16-row panel, the four waves walk the same super-blocks; the splits
-// add into the pre-zeroed d x (a.ns2 adders per element). Columns past C: the logits read there are finite (clamped
-// addresses), E^T's fragments are 0. The one-hot term of dl is -E[label] / n, added once by split 0.
+// add into d x (a.ns2 adders per element; ts_combine_kernel left the one-hot term there). Columns past C: the logits there
+// are finite, E^T's fragments are 0.
 __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
   __shared__ __attribute__((aligned(16))) float lt[4][16 * TS_LP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
@@ -303,18 +313,10 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
 #undef DX_LOAD
 #undef DX_COMPUTE
   if (row < a.R) {
-    const int lab = a.lab32[row];
-    const float nv = a.scal[1];
-    const float inv_n = (blockIdx.y == 0 && lab >= 0 && nv > 0.f) ? 1.0f / nv : 0.f;
-    const float* er = a.E + (size_t)max(lab, 0) * 64 + 4 * g;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const float4 ev = *reinterpret_cast<const float4*>(er + 16 * nb);
-      atomicAdd(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + 0, acc[nb][0] - inv_n * ev.x);
-      atomicAdd(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + 1, acc[nb][1] - inv_n * ev.y);
-      atomicAdd(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + 2, acc[nb][2] - inv_n * ev.z);
-      atomicAdd(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + 3, acc[nb][3] - inv_n * ev.w);
-    }
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + e, acc[nb][e]);
   }
 }
 
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   auto compute = [&](const TsDeLoads& L) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float4 dl = ts_p4(L.l[e], ts_e(L.lse, e));   // softmax / n; the one-hot term: ts_onehot_kernel
+      const float4 dl = ts_p4(L.l[e], ts_e(L.lse, e));   // softmax / n; the one-hot term: ts_combine_kernel
       bs[0] += dl.x;
       bs[1] += dl.y;
       bs[2] += dl.z;
@@ -417,17 +419,6 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   if (tid < 64 && v0 + tid < a.C) a.dbias[v0 + tid] += (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]);
 }
 
-// ---- the one-hot term of dl for d E and d bias: d E[label[r]] -= x[r] / n, d bias[label[r]] -= 1 / n (a wave per row) -----------
-__global__ __launch_bounds__(256) void ts_onehot_kernel(TsArgs a) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= a.R) return;
-  const int lab = a.lab32[row];
-  if (lab < 0) return;
-  const float inv_n = 1.0f / a.scal[1];
-  atomicAdd(a.dE + (size_t)lab * 64 + lane, -inv_n * a.x[(size_t)row * 64 + lane]);
-  if (lane == 0) atomicAdd(a.dbias + lab, -inv_n);
-}
-
 // ---- host side --------------------------------------------------------------------------------------------------------------
 static inline int ts_ldl(int C) { return (C + 63) & ~63; }   // logits pitch: whole 64-item super-blocks
 static inline int ts_rpad(int R) { return (R + 15) & ~15; }
@@ -467,7 +458,7 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   LR_CHECK_LAUNCH("ts_fragments_kernel");
   hipLaunchKernelGGL(ts_scores_kernel, dim3(n64, a.ns), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_scores_kernel");
-  hipLaunchKernelGGL(ts_combine_kernel, dim3((a.Rpad + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ts_combine_kernel, dim3((a.Rpad + 3) / 4), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_combine_kernel");
   hipLaunchKernelGGL(ts_dx_kernel, dim3(n64, a.ns2), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_dx_kernel");
@@ -476,7 +467,5 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   if (rc) return rc;
   hipLaunchKernelGGL(ts_de_kernel, dim3((C + 63) / 64), dim3(256), de_lds, st, a);
   LR_CHECK_LAUNCH("ts_de_kernel");
-  hipLaunchKernelGGL(ts_onehot_kernel, dim3((R + 3) / 4), dim3(256), 0, st, a);
-  LR_CHECK_LAUNCH("ts_onehot_kernel");
   return LR_OK;
 }

@@ -9,8 +9,8 @@ python3 - $OUT <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# one pass = from a tr_begin_pass launch to the next
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("tr_begin_pass")]
+# one pass = from a tr_pass_init_kernel launch to the next
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("tr_pass_init")]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
