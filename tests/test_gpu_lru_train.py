@@ -173,7 +173,7 @@ def test_gradients_with_dropout_match_the_oracle_under_the_same_masks(golden_dir
     assert abs(o_loss - float(z["step0/loss"])) > 1e-3            # the masks matter
 
 
-@pytest.mark.parametrize("B,L", [(3, 7), (5, 50), (64, 50)])   # 21 and 250 rows: ragged 16-row panels and 64-row slices
+@pytest.mark.parametrize("B,L", [(3, 7), (5, 50), (64, 50), (130, 200), (340, 200)])   # 21 / 250 rows: ragged 16-row panels, 64-row slices; 26 000 / 68 000 rows: the 128- and 256-row weight-gradient slices, one item split
 def test_row_panel_and_generic_block_kernels_agree(golden_dir, B, L):
     """The LRU blocks run as row-panel kernels (csrc/lru_train_blocks.hip) by default; lr_lru_train_set_fused(h, 0) selects
     one generic GEMM launch per product. Same mathematics and the same dropout masks (same seed, same (site, element)
