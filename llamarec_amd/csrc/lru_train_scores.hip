@@ -11,8 +11,8 @@
 //                      one-hot half of dl = softmax / n - onehot / n as rank-1 updates of d x, d E and d bias
 //   ts_dx_kernel       d x = dl E: 16-row panels per wave, dl = softmax / n formed in the operand registers from the stored
 //                      logits (one v_exp_f32 per element), E^T streamed; item splits add with atomics
-//   ts_de_kernel       d E = dl^T x, d bias: 64-item panels, rows streamed, the four waves of a workgroup split the rows
-//                      and meet in LDS; every (item, feature) has one owner: no atomics
+//   ts_de_kernel       d E = dl^T x, d bias: 64-item panels x row parts, rows streamed, the four waves of a workgroup split
+//                      their rows and meet in LDS; the row parts add with atomics (whole 256-byte rows per instruction)
 // v_mfma_f32_16x16x4_f32 with the K index permuted inside groups of 16 (see lru_train_blocks.hip): both operands of a
 // product are read as float4 along their contiguous axis. In ts_de_kernel the ITEM index is permuted the same way (a lane
 // reads 4 consecutive items of a row; element s of the float4 belongs to sub-panel s).
@@ -55,7 +55,7 @@ struct TsArgs {
   const float *x, *E, *bias;
   const long long* labels;
   int R, C, ldl, Rpad;
-  int ns, ns2;   // item splits of the score pass / of the d x pass
+  int ns, ns2, nq;   // item splits of the score pass / of the d x pass; row parts of the d E pass
   float *logits, *Ef, *ETf, *xTf, *biasf, *lse, *part, *scal;   // logits: [Rpad][ldl], in the log2 domain (x log2 e)
   int* lab32;
   float *dX, *dE, *dbias;
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   int lo[4];   // lane offsets (floats) of rows 4 g + e from a per-step uniform base
 #pragma unroll
   for (int e = 0; e < 4; ++e) lo[e] = (4 * g + e) * a.ldl + first;
-  const int nit = a.Rpad >> 4;
+  const int nit_all = a.Rpad >> 4;   // 16-row groups; this workgroup's part (grid.y = a.nq parts):
+  const int it0 = (int)((long long)blockIdx.y * nit_all / a.nq), nit = (int)((long long)(blockIdx.y + 1) * nit_all / a.nq);
   floatx4 acc[4][4];   // [sub-panel s][feature block nb]: D[d = 16 nb + 4 g + r][item v0 + 4 li + s]
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
     }
   };
   TsDeLoads A, B;   // unconditional loads, see ts_scores_kernel
-  int it = wave;
+  int it = it0 + wave;
   TS_STAMP_DECL
   load(min(it, nit - 1), A);
   for (; it < nit; it += 8) {
@@ -401,22 +402,18 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
     if (g == 0) bred[wave * 64 + 4 * li + s] = b;
   }
   __syncthreads();
+  // the row parts of a panel add into d E / d bias (pre-zeroed; the one-hot term is already there): 64 consecutive lanes
+  // cover one item's 256-byte row per atomic instruction
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i, item = idx >> 4, c = (idx & 15) * 4;
+  for (int i = 0; i < 16; ++i) {
+    const int el = tid + 256 * i, item = el >> 6, d = el & 63;
     if (v0 + item < a.C) {
-      float4 o = *reinterpret_cast<const float4*>(red + (size_t)item * 64 + c);
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(red + ((size_t)w * 64 + item) * 64 + c);
-        o = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
-      }
-      float4* d = reinterpret_cast<float4*>(a.dE + (size_t)(v0 + item) * 64 + c);
-      const float4 old = *d;
-      *d = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
+      const float o = (red[(size_t)item * 64 + d] + red[(size_t)(64 + item) * 64 + d]) +
+                      (red[(size_t)(128 + item) * 64 + d] + red[(size_t)(192 + item) * 64 + d]);
+      atomicAdd(a.dE + (size_t)(v0 + item) * 64 + d, o);
     }
   }
-  if (tid < 64 && v0 + tid < a.C) a.dbias[v0 + tid] += (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]);
+  if (tid < 64 && v0 + tid < a.C) atomicAdd(a.dbias + v0 + tid, (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]));
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
@@ -453,6 +450,16 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   a.ns2 = 256 / n64 < 1 ? 1 : 256 / n64 > 8 ? 8 : 256 / n64;
   if (a.ns > nsb) a.ns = nsb;
   if (a.ns2 > nsb) a.ns2 = nsb;
+  {  // d E: P item panels x nq row parts, nq chosen for the shortest makespan on 256 CUs (a CU's workgroups run one after
+     // the other: f32 MFMA and vector work do not overlap across waves), parts of at least 8 row groups
+    const int P = (C + 63) / 64, nit = a.Rpad / 16;
+    a.nq = 1;
+    double best = 1e30;
+    for (int q = 1; q <= 8 && nit / q >= 8; ++q) {
+      const double span = (double)((P * q + 255) / 256) / q;   // rounds of workgroups x work per workgroup
+      if (span < best - 1e-9) { best = span; a.nq = q; }
+    }
+  }
   const long long nt = 2LL * nsb * 1024 + (long long)(a.Rpad / 16) * 256 + a.ldl;
   hipLaunchKernelGGL(ts_fragments_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_fragments_kernel");
@@ -465,7 +472,7 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   const int de_lds = (4 * 64 * 64 + 4 * 64) * (int)sizeof(float);
   int rc = lr_ensure_dynamic_lds((const void*)ts_de_kernel, de_lds, lds_done);
   if (rc) return rc;
-  hipLaunchKernelGGL(ts_de_kernel, dim3((C + 63) / 64), dim3(256), de_lds, st, a);
+  hipLaunchKernelGGL(ts_de_kernel, dim3((C + 63) / 64, a.nq), dim3(256), de_lds, st, a);
   LR_CHECK_LAUNCH("ts_de_kernel");
   return LR_OK;
 }
