@@ -534,11 +534,18 @@ __global__ __launch_bounds__(256) void tr_prep_kernel(TrPrepArgs a, int with_t) 
 }
 
 // gradients of the stored parameters from those of the derived ones: workgroup = complex channel c, thread = k / o
-__global__ __launch_bounds__(64) void tr_unprep_kernel(const float* plog, const float* in_w, const float* in_b,
-                                                       const float* lam, const float* dwi, const float* dbi,
-                                                       const float* dwo, const float* dbo, const float* dlam,
-                                                       float* g_plog, float* g_in_w, float* g_in_b, float* g_out_w,
-                                                       float* g_out_b) {
+struct TrUnprepBlock {
+  const float *plog, *in_w, *in_b, *lam, *dwi, *dbi, *dwo, *dbo, *dlam;
+  float *g_plog, *g_in_w, *g_in_b, *g_out_w, *g_out_b;
+};
+struct TrUnprepArgs {
+  TrUnprepBlock blk[LR_MAX_LRU_BLOCKS];
+};
+__global__ __launch_bounds__(64) void tr_unprep_kernel(TrUnprepArgs a) {   // grid (128 channels, blocks)
+  const TrUnprepBlock& q = a.blk[blockIdx.y];
+  const float *plog = q.plog, *in_w = q.in_w, *in_b = q.in_b, *lam = q.lam, *dwi = q.dwi, *dbi = q.dbi, *dwo = q.dwo, *dbo = q.dbo,
+              *dlam = q.dlam;
+  float *g_plog = q.g_plog, *g_in_w = q.g_in_w, *g_in_b = q.g_in_b, *g_out_w = q.g_out_w, *g_out_b = q.g_out_b;
   const int c = blockIdx.x, k = threadIdx.x;
   const float nu = expf(plog[c]), th = expf(plog[128 + c]), ga = expf(plog[256 + c]);
   const float dre = dwi[c * 64 + k], dim = dwi[(128 + c) * 64 + k];
@@ -1093,16 +1100,25 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     hipLaunchKernelGGL(tr_prep_kernel, dim3(64, lay.nb), dim3(256), 0, st, pa_, h->fused);
     LR_CHECK_LAUNCH("tr_prep_kernel");
   }
-  hipLaunchKernelGGL(tr_embed_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ids, P + lay.emb, V, P + lay.eln_w,
-                     P + lay.eln_b, ws.x0, ws.xhat0, ws.rstd0, R, seed, pd);
-  LR_CHECK_LAUNCH("tr_embed_ln_fwd");
+  if (h->fused) {   // embedding + LayerNorm + block 0's in_proj
+    TbEmbedInProj e;
+    e.ids = ids; e.E = P + lay.emb; e.ln_w = P + lay.eln_w; e.ln_b = P + lay.eln_b;
+    e.wi = ws.derived + ws.blk[0].d.wi; e.bi = ws.derived + ws.blk[0].d.bi;
+    e.x = ws.x0; e.xhat = ws.xhat0; e.rstd = ws.rstd0; e.u = ws.blk[0].h;
+    e.R = R; e.V = V; e.seed = seed; e.p_drop = pd;
+    TR_RUN(tb_launch_embed_in_proj(e, st));
+  } else {
+    hipLaunchKernelGGL(tr_embed_ln_fwd, dim3(grid_rows), dim3(256), 0, st, ids, P + lay.emb, V, P + lay.eln_w,
+                       P + lay.eln_b, ws.x0, ws.xhat0, ws.rstd0, R, seed, pd);
+    LR_CHECK_LAUNCH("tr_embed_ln_fwd");
+  }
   const float* x = ws.x0;
   for (int b = 0; b < lay.nb; ++b) {
     const TrBlockOff& o = lay.blk[b];
     TrBlockWs& W = ws.blk[b];
     const float* D = ws.derived;
     if (h->fused) {
-      TR_RUN(tb_launch_in_proj(x, D + W.d.wi, D + W.d.bi, W.h, R, st));
+      // (W.h already holds u = in_proj(x): written by the kernel in front -- the embedding kernel or the previous block's)
       hipLaunchKernelGGL(tr_scan_fwd, dim3(B), dim3(128), (size_t)L, st, W.h, ids, D + W.d.lam, L);
       LR_CHECK_LAUNCH("tr_scan_fwd");
       TbBlockFwd f;
@@ -1111,6 +1127,10 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
       f.w1 = P + o.w1; f.b1 = P + o.b1; f.w2 = P + o.w2; f.b2 = P + o.b2; f.ln2_w = P + o.ln2_w; f.ln2_b = P + o.ln2_b;
       f.y = W.y; f.xhat1 = W.xhat1; f.rstd1 = W.rstd1; f.a = W.a; f.g = W.g; f.xout = W.xout; f.xhat2 = W.xhat2; f.rstd2 = W.rstd2;
       f.R = R; f.seed = seed; f.site0 = 10u + 4u * b; f.p_attn = pa; f.p_drop = pd;
+      f.next_wi = f.next_bi = nullptr; f.next_u = nullptr;
+      if (b + 1 < lay.nb) {
+        f.next_wi = D + ws.blk[b + 1].d.wi; f.next_bi = D + ws.blk[b + 1].d.bi; f.next_u = ws.blk[b + 1].h;
+      }
       TR_RUN(tb_launch_block_fwd(f, st));
       x = W.xout;
       continue;
@@ -1167,18 +1187,13 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
       TR_RUN(tb_launch_block_bwd(q, st));
       hipLaunchKernelGGL(tr_scan_bwd, dim3(B), dim3(128), (size_t)L, st, ws.d256, W.h, ids, D + W.d.lam, D + W.d.dlam, L);
       LR_CHECK_LAUNCH("tr_scan_bwd");
-      TR_RUN(tb_launch_in_proj_bwd(ws.d256, W.t.wiT, dx, R, st));
       TbWeightGrads wg;
       wg.P[0] = ws.d64a;  wg.Q[0] = W.g;  wg.dW[0] = G + o.w2;      wg.db[0] = G + o.b2;
       wg.P[1] = ws.d256b; wg.Q[1] = W.y;  wg.dW[1] = G + o.w1;      wg.db[1] = G + o.b1;
       wg.P[2] = ws.d64c;  wg.Q[2] = W.h;  wg.dW[2] = D + W.d.dwo;   wg.db[2] = D + W.d.dbo;
       wg.P[3] = ws.d256;  wg.Q[3] = xin;  wg.dW[3] = D + W.d.dwi;   wg.db[3] = D + W.d.dbi;
       wg.R = R;
-      TR_RUN(tb_launch_weight_grads(wg, st));
-      hipLaunchKernelGGL(tr_unprep_kernel, dim3(128), dim3(64), 0, st, P + o.plog, P + o.in_w, P + o.in_b, D + W.d.lam,
-                         D + W.d.dwi, D + W.d.dbi, D + W.d.dwo, D + W.d.dbo, D + W.d.dlam, G + o.plog, G + o.in_w, G + o.in_b,
-                         G + o.out_w, G + o.out_b);
-      LR_CHECK_LAUNCH("tr_unprep_kernel");
+      TR_RUN(tb_launch_bwd_tail(wg, ws.d256, W.t.wiT, dx, st));   // + dx_in += du Wi
       continue;
     }
     float* dz0 = ws.d64a;
@@ -1205,9 +1220,20 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     // in_proj (derived, gamma folded): du in d256
     TR_RUN(tr_linear_bwd_weight(ws.d256, xin, D + W.d.dwi, D + W.d.dbi, R, 256, 64, st));
     TR_RUN(tr_linear_bwd_data(ws.d256, D + W.d.wi, dx, R, 256, 64, 1, st));  // dx_in += du Wi
-    hipLaunchKernelGGL(tr_unprep_kernel, dim3(128), dim3(64), 0, st, P + o.plog, P + o.in_w, P + o.in_b, D + W.d.lam,
-                       D + W.d.dwi, D + W.d.dbi, D + W.d.dwo, D + W.d.dbo, D + W.d.dlam, G + o.plog, G + o.in_w, G + o.in_b,
-                       G + o.out_w, G + o.out_b);
+  }
+  {  // gradients of the stored parameters from those of the derived weights, every block in one launch
+    TrUnprepArgs ua;
+    for (int b = 0; b < LR_MAX_LRU_BLOCKS; ++b) {
+      const int bb = b < lay.nb ? b : 0;
+      const TrBlockOff& o = lay.blk[bb];
+      const TrDerived& d = ws.blk[bb].d;
+      float* D = ws.derived;
+      TrUnprepBlock& q = ua.blk[b];
+      q.plog = P + o.plog; q.in_w = P + o.in_w; q.in_b = P + o.in_b; q.lam = D + d.lam;
+      q.dwi = D + d.dwi; q.dbi = D + d.dbi; q.dwo = D + d.dwo; q.dbo = D + d.dbo; q.dlam = D + d.dlam;
+      q.g_plog = G + o.plog; q.g_in_w = G + o.in_w; q.g_in_b = G + o.in_b; q.g_out_w = G + o.out_w; q.g_out_b = G + o.out_b;
+    }
+    hipLaunchKernelGGL(tr_unprep_kernel, dim3(128, lay.nb), dim3(64), 0, st, ua);
     LR_CHECK_LAUNCH("tr_unprep_kernel");
   }
   // ---- embedding LayerNorm and the lookup

@@ -26,13 +26,26 @@ struct TbTransposed {
   float *wiT, *woT, *w1T, *w2T;   // [64][256], [256][64], [64][256], [256][64]
 };
 
-// u[R][256] = x[R][64] wi[256][64]^T + bi
+// u[R][256] = x[R][64] wi[256][64]^T + bi   (stand-alone form; the step runs in_proj inside the kernel in front of it)
 int tb_launch_in_proj(const float* x, const float* wi, const float* bi, float* u, int R, hipStream_t st);
+
+// x = LN(dropout(E[id])) (saves xhat, rstd) and block 0's in_proj u = x wi^T + bi, one launch
+struct TbEmbedInProj {
+  const long long* ids;
+  const float *E, *ln_w, *ln_b, *wi, *bi;
+  float *x, *xhat, *rstd, *u;
+  int R, V;
+  const unsigned long long* seed;
+  float p_drop;
+};
+int tb_launch_embed_in_proj(const TbEmbedInProj& p, hipStream_t st);
 
 struct TbBlockFwd {
   const float *h, *x;   // [R][256] the recurrence's output (Re | Im), [R][64] the block's input
   const float *wo, *bo, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b;
   float *y, *xhat1, *rstd1, *a, *g, *xout, *xhat2, *rstd2;   // saved for the backward pass
+  const float *next_wi, *next_bi;   // the NEXT block's in_proj (null for the last block): next_u = xout next_wi^T + next_bi
+  float* next_u;
   int R;
   const unsigned long long* seed;
   unsigned site0;        // dropout sites: site0 (after out_proj), site0 + 1 (after GELU), site0 + 2 (after W2)
@@ -42,7 +55,7 @@ int tb_launch_block_fwd(const TbBlockFwd& p, hipStream_t st);
 
 struct TbBlockBwd {
   float* dx;                        // [R][64] in: gradient of the block's output; out: gradient reaching the block's input
-                                    //         through the residual path (tb_launch_in_proj_bwd adds the recurrence's share)
+                                    //         through the residual path (tb_launch_bwd_tail adds the recurrence's share)
   const float *xhat2, *rstd2, *ln2_w, *a, *xhat1, *rstd1, *ln1_w;
   const float *w2T, *w1T, *woT;
   float *dz0, *da, *dy0, *dh;       // [R][64], [R][256], [R][64], [R][256]: operands of the weight gradients / the recurrence
@@ -54,8 +67,6 @@ struct TbBlockBwd {
 };
 int tb_launch_block_bwd(const TbBlockBwd& p, hipStream_t st);
 
-// dx[R][64] += du[R][256] wi[256][64]   (wiT = wi transposed)
-int tb_launch_in_proj_bwd(const float* du, const float* wiT, float* dx, int R, hipStream_t st);
 
 // The four weight gradients of a block in one launch: dW[i][N][K] += P[i]^T Q[i], db[i][N] += column sums of P[i]
 // (i = 0, 2: N = 64, K = 256; i = 1, 3: N = 256, K = 64), atomics onto pre-zeroed buffers.
@@ -66,4 +77,5 @@ struct TbWeightGrads {
   float* db[4];
   int R;
 };
-int tb_launch_weight_grads(const TbWeightGrads& p, hipStream_t st);
+// ... and, in the same launch, the data gradient of in_proj: dx[R][64] += du[R][256] wi[256][64] (wiT = wi transposed)
+int tb_launch_bwd_tail(const TbWeightGrads& p, const float* du, const float* wiT, float* dx, hipStream_t st);

@@ -105,11 +105,66 @@ int tb_launch_in_proj(const float* x, const float* wi, const float* bi, float* u
   return LR_OK;
 }
 
-// in_proj backward (data): dx += du wi     (wiT [64][256]: the product has the forward form with N = 64, K = 256)
-__global__ __launch_bounds__(256) void tb_in_proj_bwd_kernel(const float* __restrict__ du, const float* __restrict__ wiT,
-                                                             float* dx, int R) {
+// Block 0's in_proj with the embedding lookup + dropout + LayerNorm in front of it (one launch instead of two): a wave per
+// row for the LayerNorm (the arithmetic of lru_train.hip's tr_embed_ln_fwd), the 16 rows meet in LDS for the MFMAs.
+__global__ __launch_bounds__(256) void tb_embed_in_proj_kernel(TbEmbedInProj p) {
+  __shared__ __attribute__((aligned(16))) float Xs[TB_ROWS][TB_LD64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * TB_ROWS;
+  const unsigned long long seed = *p.seed;
+  float4 wf[4][4];
+  tb_load_w<64, 4>(p.wi, 64 * wave, li, g, wf);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * i + wave, row = row0 + r;   // wave-uniform
+    float xv = 0.f;
+    if (row < p.R) {
+      long long id = p.ids[row];
+      if (id < 0 || id > p.V) id = 0;
+      const float e = p.E[id * 64 + lane] * tr_drop_scale(seed, 0, (unsigned long long)row * 64 + lane, p.p_drop);
+      float s1 = e;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+      const float mu = s1 * (1.0f / 64);
+      const float d = e - mu;
+      float s2 = d * d;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+      const float rs = 1.0f / sqrtf(s2 * (1.0f / 64) + LR_LN_EPS);
+      const float xh = d * rs;
+      xv = xh * p.ln_w[lane] + p.ln_b[lane];
+      p.xhat[(size_t)row * 64 + lane] = xh;
+      p.x[(size_t)row * 64 + lane] = xv;
+      if (lane == 0) p.rstd[row] = rs;
+    }
+    Xs[r][lane] = xv;
+  }
+  __syncthreads();
+  floatx4 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+  tb_mma_n4(&Xs[li][4 * g], wf, acc);
+  const int row = row0 + li;
+  if (row >= p.R) return;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = 64 * wave + 16 * nb + 4 * g;
+    const float4 b = *reinterpret_cast<const float4*>(p.bi + n);
+    *reinterpret_cast<float4*>(p.u + (size_t)row * 256 + n) = make_float4(acc[nb][0] + b.x, acc[nb][1] + b.y, acc[nb][2] + b.z, acc[nb][3] + b.w);
+  }
+}
+int tb_launch_embed_in_proj(const TbEmbedInProj& p, hipStream_t st) {
+  hipLaunchKernelGGL(tb_embed_in_proj_kernel, dim3((p.R + TB_ROWS - 1) / TB_ROWS), dim3(256), 0, st, p);
+  LR_CHECK_LAUNCH("tb_embed_in_proj_kernel");
+  return LR_OK;
+}
+
+// in_proj backward (data): dx += du wi     (wiT [64][256]: the product has the forward form with N = 64, K = 256); one
+// 16-row panel per workgroup; runs as the first workgroups of tb_bwd_tail_kernel
+__device__ __forceinline__ void tb_in_proj_bwd_body(const float* __restrict__ du, const float* __restrict__ wiT, float* dx, int R,
+                                                    int panel) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-  const int row = blockIdx.x * TB_ROWS + li;
+  const int row = panel * TB_ROWS + li;
   const bool ok = row < R;
   float4 wf[1][16];
   tb_load_w<256, 1>(wiT, 16 * wave, li, g, wf);
@@ -129,11 +184,6 @@ __global__ __launch_bounds__(256) void tb_in_proj_bwd_kernel(const float* __rest
   float4* d = reinterpret_cast<float4*>(dx + (size_t)row * 64 + 16 * wave + 4 * g);
   const float4 o = *d;
   *d = make_float4(o.x + s[0], o.y + s[1], o.z + s[2], o.w + s[3]);
-}
-int tb_launch_in_proj_bwd(const float* du, const float* wiT, float* dx, int R, hipStream_t st) {
-  hipLaunchKernelGGL(tb_in_proj_bwd_kernel, dim3((R + TB_ROWS - 1) / TB_ROWS), dim3(256), 0, st, du, wiT, dx, R);
-  LR_CHECK_LAUNCH("tb_in_proj_bwd_kernel");
-  return LR_OK;
 }
 
 // =============================================================================================
@@ -252,6 +302,24 @@ __global__ __launch_bounds__(256) void tb_block_fwd_kernel(TbBlockFwd p) {
       *reinterpret_cast<float4*>(p.xhat2 + (size_t)rrow * 64 + c) = xh;
       *reinterpret_cast<float4*>(p.xout + (size_t)rrow * 64 + c) = out;
       if ((tid & 15) == 0) p.rstd2[rrow] = rs;
+    }
+    if (p.next_wi) *reinterpret_cast<float4*>(&Ys[r][c]) = out;   // every LN2 read of Ys (yv) happened before LN1's barrier
+  }
+  if (!p.next_wi) return;
+  // the next block's in_proj on the panel that is already here (one launch and one round trip of x less)
+  float4 wfn[4][4];
+  tb_load_w<64, 4>(p.next_wi, 64 * wave, li, g, wfn);
+  __syncthreads();
+  floatx4 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+  tb_mma_n4(&Ys[li][4 * g], wfn, acc);
+  if (mok) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int n = 64 * wave + 16 * nb + 4 * g;
+      const float4 b = *reinterpret_cast<const float4*>(p.next_bi + n);
+      *reinterpret_cast<float4*>(p.next_u + (size_t)mrow * 256 + n) = make_float4(acc[nb][0] + b.x, acc[nb][1] + b.y, acc[nb][2] + b.z, acc[nb][3] + b.w);
     }
   }
 }
@@ -477,19 +545,29 @@ __device__ __forceinline__ void tb_wgrad(const float* __restrict__ P, const floa
         atomicAdd(dW + (size_t)m * K + (kb0 + j) * 32 + (lane & 31), acc[i][j][e]);
       }
 }
-__global__ __launch_bounds__(256) void tb_weight_grads_kernel(TbWeightGrads p, int rows_per_wg) {
+// After the recurrence's backward pass two things are ready to run and independent of each other: the data gradient of
+// in_proj (n_panels workgroups of 16 rows) and the block's four weight gradients (4 x row slices). One launch: the first
+// n_panels workgroups do the former (they are the short ones and finish under the others).
+__global__ __launch_bounds__(256) void tb_bwd_tail_kernel(TbWeightGrads p, int rows_per_wg, const float* du, const float* wiT,
+                                                          float* dx, int n_panels) {
   __shared__ __attribute__((aligned(16))) float smem[TB_WG_CHUNK * (64 + 32 + 256 + 32)];
-  const int i = blockIdx.y;
-  const int r0 = blockIdx.x * rows_per_wg, r1 = min(p.R, r0 + rows_per_wg);
+  if ((int)blockIdx.x < n_panels) {
+    tb_in_proj_bwd_body(du, wiT, dx, p.R, blockIdx.x);
+    return;
+  }
+  const int w = blockIdx.x - n_panels;
+  const int i = w & 3;
+  const int r0 = (w >> 2) * rows_per_wg, r1 = min(p.R, r0 + rows_per_wg);
   if (r0 >= r1) return;
   if (i & 1) tb_wgrad<256, 64>(p.P[i], p.Q[i], p.dW[i], p.db[i], p.R, r0, r1, smem);
   else tb_wgrad<64, 256>(p.P[i], p.Q[i], p.dW[i], p.db[i], p.R, r0, r1, smem);
 }
-int tb_launch_weight_grads(const TbWeightGrads& p, hipStream_t st) {
+int tb_launch_bwd_tail(const TbWeightGrads& p, const float* du, const float* wiT, float* dx, hipStream_t st) {
   // 64-row slices while that keeps the launch under ~4 workgroups per CU (Beauty: 50 slices x 4 = 200 workgroups, 13 MB of
   // adds); 128 and 256 rows beyond
   const int rows = p.R <= 16384 ? 64 : p.R <= 65536 ? 128 : 256;
-  hipLaunchKernelGGL(tb_weight_grads_kernel, dim3((p.R + rows - 1) / rows, 4), dim3(256), 0, st, p, rows);
-  LR_CHECK_LAUNCH("tb_weight_grads_kernel");
+  const int n_panels = (p.R + TB_ROWS - 1) / TB_ROWS, slices = (p.R + rows - 1) / rows;
+  hipLaunchKernelGGL(tb_bwd_tail_kernel, dim3(n_panels + 4 * slices), dim3(256), 0, st, p, rows, du, wiT, dx, n_panels);
+  LR_CHECK_LAUNCH("tb_bwd_tail_kernel");
   return LR_OK;
 }
