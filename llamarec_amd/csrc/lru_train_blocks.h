@@ -26,9 +26,6 @@ struct TbTransposed {
   float *wiT, *woT, *w1T, *w2T;   // [64][256], [256][64], [64][256], [256][64]
 };
 
-// u[R][256] = x[R][64] wi[256][64]^T + bi   (stand-alone form; the step runs in_proj inside the kernel in front of it)
-int tb_launch_in_proj(const float* x, const float* wi, const float* bi, float* u, int R, hipStream_t st);
-
 // x = LN(dropout(E[id])) (saves xhat, rstd) and block 0's in_proj u = x wi^T + bi, one launch
 struct TbEmbedInProj {
   const long long* ids;

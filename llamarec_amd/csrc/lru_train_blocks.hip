@@ -69,42 +69,8 @@ __device__ __forceinline__ float4 tb_ld4(const float* p, bool ok) {
 }
 
 // =============================================================================================
-// in_proj forward: u = x wi^T + bi        (no LDS: the panel's rows go from global memory into operand registers)
+// in_proj forward: u = x wi^T + bi -- inside the kernel that produces x
 // =============================================================================================
-__global__ __launch_bounds__(256) void tb_in_proj_kernel(const float* __restrict__ x, const float* __restrict__ wi,
-                                                         const float* __restrict__ bi, float* __restrict__ u, int R) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-  const int row = blockIdx.x * TB_ROWS + li;
-  const bool ok = row < R;
-  float4 wf[4][4];
-  tb_load_w<64, 4>(wi, 64 * wave, li, g, wf);
-  float4 xa[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) xa[j] = tb_ld4(x + (size_t)row * 64 + 16 * j + 4 * g, ok);
-  floatx4 acc[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb_e(wf[nb][j], e), tb_e(xa[j], e), acc[nb], 0, 0, 0);
-  if (!ok) return;
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    const int n = 64 * wave + 16 * nb + 4 * g;
-    const float4 b = *reinterpret_cast<const float4*>(bi + n);
-    *reinterpret_cast<float4*>(u + (size_t)row * 256 + n) = make_float4(acc[nb][0] + b.x, acc[nb][1] + b.y, acc[nb][2] + b.z, acc[nb][3] + b.w);
-  }
-}
-int tb_launch_in_proj(const float* x, const float* wi, const float* bi, float* u, int R, hipStream_t st) {
-  hipLaunchKernelGGL(tb_in_proj_kernel, dim3((R + TB_ROWS - 1) / TB_ROWS), dim3(256), 0, st, x, wi, bi, u, R);
-  LR_CHECK_LAUNCH("tb_in_proj_kernel");
-  return LR_OK;
-}
-
 // Block 0's in_proj with the embedding lookup + dropout + LayerNorm in front of it (one launch instead of two): a wave per
 // row for the LayerNorm (the arithmetic of lru_train.hip's tr_embed_ln_fwd), the 16 rows meet in LDS for the MFMAs.
 __global__ __launch_bounds__(256) void tb_embed_in_proj_kernel(TbEmbedInProj p) {
