@@ -410,7 +410,13 @@ __global__ __launch_bounds__(256) void tr_res_ln_fwd(const float* o, const float
 __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* w,
                                                  float* de, float* dw, float* db, int R, float* res = nullptr,
                                                  const unsigned long long* seedp = nullptr, unsigned site = 0, float p = 0.f,
-                                                 const long long* ids = nullptr, int V = 0, float* dE = nullptr) {
+                                                 const long long* ids = nullptr, int V = 0, float* dE = nullptr,
+                                                 const float* scal = nullptr, float* out_loss = nullptr) {
+  if (out_loss && blockIdx.x == 0 && threadIdx.x == 0) {   // the loss the pass reports (its last launch carries it)
+    out_loss[0] = scal[0] / fmaxf(scal[1], 1.0f);
+    out_loss[1] = scal[1];
+    out_loss[2] = scal[3];
+  }
   __shared__ float sw[4][64], sb[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float wl = w[lane];
@@ -488,9 +494,8 @@ struct TrPrepBlock {
 struct TrPrepArgs {
   TrPrepBlock blk[LR_MAX_LRU_BLOCKS];
 };
-// grid (64, blocks): the derived weights of every block in one launch; with_t: also the transposed copies of the four
-// 64 x 256 matrices the row-panel kernels' data-gradient products read (tb_transpose_kernel's work: wi^T and wo^T are
-// written from the same registers as wi and wo)
+// grid (64, blocks): the derived weights of every block in one launch; with_t: also the four 64 x 256 matrices and their
+// transposes in the fragment order the row-panel kernels read (TbTransposed)
 __global__ __launch_bounds__(256) void tr_prep_kernel(TrPrepArgs a, int with_t) {
   const TrPrepBlock& q = a.blk[blockIdx.y];
   const float *plog = q.plog, *in_w = q.in_w, *in_b = q.in_b, *out_w = q.out_w, *out_b = q.out_b;
@@ -512,9 +517,11 @@ __global__ __launch_bounds__(256) void tr_prep_kernel(TrPrepArgs a, int with_t) 
     const float re = ga * in_w[2 * i], im = ga * in_w[2 * i + 1];
     wi[c * 64 + k] = re;
     wi[(128 + c) * 64 + k] = im;
-    if (with_t) {
-      q.t.wiT[k * 256 + c] = re;
-      q.t.wiT[k * 256 + 128 + c] = im;
+    if (with_t) {   // wi [256][64] and wi^T [64][256], fragment order
+      q.t.wiF[tb_frag_pos(c, k, 64)] = re;
+      q.t.wiF[tb_frag_pos(128 + c, k, 64)] = im;
+      q.t.wiT[tb_frag_pos(k, c, 256)] = re;
+      q.t.wiT[tb_frag_pos(k, 128 + c, 256)] = im;
     }
   }
   if (i < 64 * 128) {  // out_w[o][c] complex
@@ -522,14 +529,19 @@ __global__ __launch_bounds__(256) void tr_prep_kernel(TrPrepArgs a, int with_t) 
     const float re = out_w[2 * i], im = -out_w[2 * i + 1];
     wo[o * 256 + c] = re;
     wo[o * 256 + 128 + c] = im;
-    if (with_t) {
-      q.t.woT[c * 64 + o] = re;
-      q.t.woT[(128 + c) * 64 + o] = im;
+    if (with_t) {   // wo [64][256] and wo^T [256][64]
+      q.t.woF[tb_frag_pos(o, c, 256)] = re;
+      q.t.woF[tb_frag_pos(o, 128 + c, 256)] = im;
+      q.t.woT[tb_frag_pos(c, o, 64)] = re;
+      q.t.woT[tb_frag_pos(128 + c, o, 64)] = im;
     }
   }
-  if (with_t) {   // w1 [256][64] -> w1T [64][256]; w2 [64][256] -> w2T [256][64]
-    q.t.w1T[(i & 63) * 256 + (i >> 6)] = q.w1[i];
-    q.t.w2T[(i & 255) * 64 + (i >> 8)] = q.w2[i];
+  if (with_t) {   // w1 [256][64], w1^T [64][256]; w2 [64][256], w2^T [256][64]
+    const float a1 = q.w1[i], a2 = q.w2[i];
+    q.t.w1F[tb_frag_pos(i >> 6, i & 63, 64)] = a1;
+    q.t.w1T[tb_frag_pos(i & 63, i >> 6, 256)] = a1;
+    q.t.w2F[tb_frag_pos(i >> 8, i & 255, 256)] = a2;
+    q.t.w2T[tb_frag_pos(i & 255, i >> 8, 64)] = a2;
   }
 }
 
@@ -762,11 +774,6 @@ __global__ void tr_set_step_scalars(float* scal, float lr, float max_norm) {
   scal[4] = lr;
   scal[5] = max_norm;
 }
-__global__ void tr_finish_loss(float* scal, float* out) {
-  out[0] = scal[0] / fmaxf(scal[1], 1.0f);
-  out[1] = scal[1];
-  out[2] = scal[3];
-}
 
 // =============================================================================================
 // optimizer
@@ -881,6 +888,10 @@ static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, ch
   w.d256b = take(r * 256);
   for (int b = 0; b < lay.nb; ++b) {
     TbTransposed& t = w.blk[b].t;
+    t.wiF = take(16384);
+    t.woF = take(16384);
+    t.w1F = take(16384);
+    t.w2F = take(16384);
     t.wiT = take(16384);
     t.woT = take(16384);
     t.w1T = take(16384);
@@ -1103,7 +1114,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   if (h->fused) {   // embedding + LayerNorm + block 0's in_proj
     TbEmbedInProj e;
     e.ids = ids; e.E = P + lay.emb; e.ln_w = P + lay.eln_w; e.ln_b = P + lay.eln_b;
-    e.wi = ws.derived + ws.blk[0].d.wi; e.bi = ws.derived + ws.blk[0].d.bi;
+    e.wi = ws.blk[0].t.wiF; e.bi = ws.derived + ws.blk[0].d.bi;
     e.x = ws.x0; e.xhat = ws.xhat0; e.rstd = ws.rstd0; e.u = ws.blk[0].h;
     e.R = R; e.V = V; e.seed = seed; e.p_drop = pd;
     TR_RUN(tb_launch_embed_in_proj(e, st));
@@ -1123,13 +1134,13 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
       LR_CHECK_LAUNCH("tr_scan_fwd");
       TbBlockFwd f;
       f.h = W.h; f.x = x;
-      f.wo = D + W.d.wo; f.bo = D + W.d.bo; f.ln1_w = P + o.ln1_w; f.ln1_b = P + o.ln1_b;
-      f.w1 = P + o.w1; f.b1 = P + o.b1; f.w2 = P + o.w2; f.b2 = P + o.b2; f.ln2_w = P + o.ln2_w; f.ln2_b = P + o.ln2_b;
+      f.wo = W.t.woF; f.bo = D + W.d.bo; f.ln1_w = P + o.ln1_w; f.ln1_b = P + o.ln1_b;
+      f.w1 = W.t.w1F; f.b1 = P + o.b1; f.w2 = W.t.w2F; f.b2 = P + o.b2; f.ln2_w = P + o.ln2_w; f.ln2_b = P + o.ln2_b;
       f.y = W.y; f.xhat1 = W.xhat1; f.rstd1 = W.rstd1; f.a = W.a; f.g = W.g; f.xout = W.xout; f.xhat2 = W.xhat2; f.rstd2 = W.rstd2;
       f.R = R; f.seed = seed; f.site0 = 10u + 4u * b; f.p_attn = pa; f.p_drop = pd;
       f.next_wi = f.next_bi = nullptr; f.next_u = nullptr;
       if (b + 1 < lay.nb) {
-        f.next_wi = D + ws.blk[b + 1].d.wi; f.next_bi = D + ws.blk[b + 1].d.bi; f.next_u = ws.blk[b + 1].h;
+        f.next_wi = ws.blk[b + 1].t.wiF; f.next_bi = D + ws.blk[b + 1].d.bi; f.next_u = ws.blk[b + 1].h;
       }
       TR_RUN(tb_launch_block_fwd(f, st));
       x = W.xout;
@@ -1167,8 +1178,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   } else {
     TR_RUN(lr_launch_train_ce(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
   }
-  hipLaunchKernelGGL(tr_finish_loss, dim3(1), dim3(1), 0, st, h->scal, out_loss);
-  LR_CHECK_LAUNCH("tr_finish_loss");
+  // (loss = scal[0] / scal[1] is written to out_loss by the pass's last launch, the embedding LayerNorm's backward)
 
   // ---- backward through the blocks; dx = gradient of the block's output
   for (int b = lay.nb - 1; b >= 0; --b) {
@@ -1238,7 +1248,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   }
   // ---- embedding LayerNorm and the lookup
   hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, ws.xhat0, ws.rstd0, P + lay.eln_w, ws.d64a,
-                     G + lay.eln_w, G + lay.eln_b, R, nullptr, seed, 0u, pd, ids, V, G + lay.emb);
+                     G + lay.eln_w, G + lay.eln_b, R, nullptr, seed, 0u, pd, ids, V, G + lay.emb, h->scal, out_loss);
   LR_CHECK_LAUNCH("tr_ln_bwd");
   (void)grid_rows;
   return LR_OK;

@@ -20,16 +20,23 @@ __device__ __forceinline__ float tr_drop_scale(unsigned long long seed, unsigned
   return u < p ? 0.f : 1.0f / (1.0f - p);
 }
 
-// transposed copies of a block's four weight matrices (the data-gradient products read W[n][k] along n), written by
-// tr_prep_kernel (lru_train.hip) together with the derived weights
+// A block's four 64 x 256 weight matrices and their transposes in MFMA FRAGMENT ORDER ([n / 16][k / 16][lane][4], see
+// tb_load_w), written once per pass by tr_prep_kernel (lru_train.hip) together with the derived weights. The forward
+// products read wiF [256][64], woF [64][256], w1F [256][64], w2F [64][256]; the data-gradient products read the
+// transposes wiT [64][256], woT [256][64], w1T [64][256], w2T [256][64] (they read W[n][k] along n).
 struct TbTransposed {
-  float *wiT, *woT, *w1T, *w2T;   // [64][256], [256][64], [64][256], [256][64]
+  float *wiF, *woF, *w1F, *w2F;
+  float *wiT, *woT, *w1T, *w2T;
 };
+// position (floats) of element (n, k) of a matrix with K columns in fragment order
+__host__ __device__ __forceinline__ int tb_frag_pos(int n, int k, int K) {
+  return (((n >> 4) * (K >> 4) + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3);
+}
 
 // x = LN(dropout(E[id])) (saves xhat, rstd) and block 0's in_proj u = x wi^T + bi, one launch
 struct TbEmbedInProj {
   const long long* ids;
-  const float *E, *ln_w, *ln_b, *wi, *bi;
+  const float *E, *ln_w, *ln_b, *wi, *bi;   // wi: fragment order (TbTransposed::wiF)
   float *x, *xhat, *rstd, *u;
   int R, V;
   const unsigned long long* seed;
@@ -39,9 +46,9 @@ int tb_launch_embed_in_proj(const TbEmbedInProj& p, hipStream_t st);
 
 struct TbBlockFwd {
   const float *h, *x;   // [R][256] the recurrence's output (Re | Im), [R][64] the block's input
-  const float *wo, *bo, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b;
+  const float *wo, *bo, *ln1_w, *ln1_b, *w1, *b1, *w2, *b2, *ln2_w, *ln2_b;   // wo, w1, w2: fragment order (woF, w1F, w2F)
   float *y, *xhat1, *rstd1, *a, *g, *xout, *xhat2, *rstd2;   // saved for the backward pass
-  const float *next_wi, *next_bi;   // the NEXT block's in_proj (null for the last block): next_u = xout next_wi^T + next_bi
+  const float *next_wi, *next_bi;   // the NEXT block's in_proj, wiF (null for the last block): next_u = xout next_wi^T + next_bi
   float* next_u;
   int R;
   const unsigned long long* seed;

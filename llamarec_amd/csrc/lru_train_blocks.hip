@@ -21,14 +21,17 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define TB_LD64 68     // LDS row pitch (floats) of a [16][64] panel: 16 rows x 4 banks = all 64 banks per 16-lane b128 read
 #define TB_LD256 260
 
-// wf[nb][j] = W[n0 + 16 nb + li][16 j + 4 g .. + 3] for a row-major W[N][K]
+// wf[nb][j] = W[n0 + 16 nb + li][16 j + 4 g .. + 3] of a matrix W[N][K] stored in FRAGMENT ORDER by tr_prep_kernel
+// (lru_train.hip): [n / 16][k / 16][lane = 16 g + li][4] -- the 64 lanes of one operand load read 1 KB contiguous. (Read
+// from the row-major matrix the same fragment is 16 rows x 64 B per wave-instruction, the shape a CU moves at a third of
+// the rate: lru_train_scores.hip.)
 template <int K, int NB>
-__device__ __forceinline__ void tb_load_w(const float* __restrict__ W, int n0, int li, int g, float4 (&wf)[NB][K / 16]) {
+__device__ __forceinline__ void tb_load_w(const float* __restrict__ Wf, int n0, int lane, float4 (&wf)[NB][K / 16]) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int j = 0; j < K / 16; ++j)
-      wf[nb][j] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + 16 * nb + li) * K + 16 * j + 4 * g);
+      wf[nb][j] = *reinterpret_cast<const float4*>(Wf + ((size_t)((n0 >> 4) + nb) * (K / 16) + j) * 256 + lane * 4);
 }
 __device__ __forceinline__ float tb_e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void tb_embed_in_proj_kernel(TbEmbedInProj p) 
   const int row0 = blockIdx.x * TB_ROWS;
   const unsigned long long seed = *p.seed;
   float4 wf[4][4];
-  tb_load_w<64, 4>(p.wi, 64 * wave, li, g, wf);
+  tb_load_w<64, 4>(p.wi, 64 * wave, lane, wf);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 4 * i + wave, row = row0 + r;   // wave-uniform
@@ -133,7 +136,7 @@ __device__ __forceinline__ void tb_in_proj_bwd_body(const float* __restrict__ du
   const int row = panel * TB_ROWS + li;
   const bool ok = row < R;
   float4 wf[1][16];
-  tb_load_w<256, 1>(wiT, 16 * wave, li, g, wf);
+  tb_load_w<256, 1>(wiT, 16 * wave, lane, wf);
   floatx4 part[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[e] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void tb_block_fwd_kernel(TbBlockFwd p) {
   const bool mok = mrow < p.R;
 
   float4 wfo[1][16];
-  tb_load_w<256, 1>(p.wo, 16 * wave, li, g, wfo);
+  tb_load_w<256, 1>(p.wo, 16 * wave, lane, wfo);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i, hr = idx >> 6, hc = (idx & 63) * 4;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void tb_block_fwd_kernel(TbBlockFwd p) {
     *reinterpret_cast<float4*>(&Os[li][n]) = make_float4(s[0] + b.x, s[1] + b.y, s[2] + b.z, s[3] + b.w);
   }
   float4 wf1[4][4];
-  tb_load_w<64, 4>(p.w1, 64 * wave, li, g, wf1);
+  tb_load_w<64, 4>(p.w1, 64 * wave, lane, wf1);
   __syncthreads();
   float4 yv;
   {  // LN1
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void tb_block_fwd_kernel(TbBlockFwd p) {
     }
   }
   float4 wf2[1][16];
-  tb_load_w<256, 1>(p.w2, 16 * wave, li, g, wf2);
+  tb_load_w<256, 1>(p.w2, 16 * wave, lane, wf2);
   __syncthreads();
   {  // W2
     const floatx4 s = tb_mma_n1(&Hs[li][4 * g], wf2);
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void tb_block_fwd_kernel(TbBlockFwd p) {
   if (!p.next_wi) return;
   // the next block's in_proj on the panel that is already here (one launch and one round trip of x less)
   float4 wfn[4][4];
-  tb_load_w<64, 4>(p.next_wi, 64 * wave, li, g, wfn);
+  tb_load_w<64, 4>(p.next_wi, 64 * wave, lane, wfn);
   __syncthreads();
   floatx4 acc[4];
 #pragma unroll
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void tb_block_bwd_kernel(TbBlockBwd p) {
   const bool mok = mrow < p.R;
 
   float4 wf2[4][4];
-  tb_load_w<64, 4>(p.w2T, 64 * wave, li, g, wf2);
+  tb_load_w<64, 4>(p.w2T, 64 * wave, lane, wf2);
   {  // LN2 backward
     const float4 gy = tb_ld4(p.dx + (size_t)rrow * 64 + c, rok);
     const float4 xh = tb_ld4(p.xhat2 + (size_t)rrow * 64 + c, rok);
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void tb_block_bwd_kernel(TbBlockBwd p) {
     }
   }
   float4 wf1[1][16];
-  tb_load_w<256, 1>(p.w1T, 16 * wave, li, g, wf1);
+  tb_load_w<256, 1>(p.w1T, 16 * wave, lane, wf1);
   __syncthreads();   // DAs complete; DZs and red are free again
   {  // dy = d + da w1
     const floatx4 s = tb_mma_n1(&DAs[li][4 * g], wf1);
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void tb_block_bwd_kernel(TbBlockBwd p) {
     *reinterpret_cast<float4*>(&DZs[li][n]) = make_float4(d.x + s[0], d.y + s[1], d.z + s[2], d.w + s[3]);
   }
   float4 wfo[4][4];
-  tb_load_w<64, 4>(p.woT, 64 * wave, li, g, wfo);
+  tb_load_w<64, 4>(p.woT, 64 * wave, lane, wfo);
   __syncthreads();
   {  // LN1 backward
     const float4 gy = *reinterpret_cast<const float4*>(&DZs[r][c]);
