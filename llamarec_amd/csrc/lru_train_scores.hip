@@ -292,12 +292,18 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
     *reinterpret_cast<float4*>(tile + (4 + g) * TS_LP + 4 * li) = l_##1;                                          \
     *reinterpret_cast<float4*>(tile + (8 + g) * TS_LP + 4 * li) = l_##2;                                          \
     *reinterpret_cast<float4*>(tile + (12 + g) * TS_LP + 4 * li) = l_##3;                                         \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
-      const float4 dl = ts_p4(*reinterpret_cast<const float4*>(tile + li * TS_LP + 16 * j + 4 * g), lse2);        \
+    /* all 16 softmax values first, then the 64 MFMAs back to back: left to itself hipcc forms one value per four MFMAs */ \
+    /* in ONE register, the subtract -> v_exp_f32 chain behind every fourth MFMA (67-68 -> 65-66 us; the same regrouping in */ \
+    /* ts_de_kernel, whose values feed sixteen MFMAs each, cost 57 -> 77 us: there the interleaved form hides them)      */ \
+    float4 dl_[4];                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+      dl_[j] = ts_p4(*reinterpret_cast<const float4*>(tile + li * TS_LP + 16 * j + 4 * g), lse2);                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                               \
       _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                            \
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ts_e(w_[nb][j], e), ts_e(dl, e), acc[nb], 0, 0, 0);        \
-    }                                                                                                             \
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ts_e(w_[nb][j], e), ts_e(dl_[j], e), acc[nb], 0, 0, 0);    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
   }
   float4 la0, la1, la2, la3, lb0, lb1, lb2, lb3, wa[4][4], wb[4][4];   // unconditional loads, see ts_scores_kernel (DX_LOAD clamps the addresses itself)
   int sb = sb0;
