@@ -31,7 +31,7 @@
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-#define TS_NS_MAX 16       // most item splits of the score pass (grid.y)
+#define TS_NS_MAX 32       // most item splits of the score pass (grid.y)
 #define TS_NEG (-3.0e38f)  // finite stand-in for -inf in the running maxima (2^(TS_NEG - TS_NEG) = 1, never NaN)
 #define TS_LOG2E 1.4426950408889634f
 #define TS_LP 68           // LDS pitch (floats) of a wave's [16][64] logits tile: 17 chunks of 16 B, conflict-free both ways
@@ -111,22 +111,32 @@ struct TsScLoads {
 // ---- scores + running (max, sum exp) -------------------------------------------------------------------------------------
 // grid (row tiles of 64, a.ns item splits). A WAVE owns a 16-row panel; the four waves of a workgroup walk the same 64-item
 // super-blocks of the split (the table fragments come from L2 once per workgroup and from L1 for the other three waves).
+#define TS_P 2   // 16-row panels per wave in the score pass: a fragment load of the table feeds TS_P x 64 MFMAs. With one panel
+                 // the loop moved 20 KB per 64 MFMAs and wave = 6.4 flop per byte, and a CU's vector memory path delivers
+                 // ~30 B/clk whatever it hits (tools/diag/mfma_f32_issue.hip: 16 coalesced loads per 64 MFMAs already cost 2
+                 // waves per SIMD 83-93 instead of 64 cycles per MFMA) against 256 flop/clk of f32 MFMA: 85 -> 74 us. The same
+                 // change in the d x pass (whose second stream, the logits, doubles with the rows): 66 -> 82 us, not kept.
 __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
-  __shared__ __attribute__((aligned(16))) float lt[4][16 * TS_LP];
+  __shared__ __attribute__((aligned(16))) float lt[4][TS_P * 16 * TS_LP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int row0 = blockIdx.x * 64 + wave * 16;
-  const int row = row0 + li;
-  const int rowc = min(row, a.R - 1);
+  const int row0 = (blockIdx.x * 4 + wave) * (16 * TS_P);
   const int nsb = (a.ldl + 63) >> 6;
   const int sb0 = (int)((long long)blockIdx.y * nsb / a.ns), sb1 = (int)((long long)(blockIdx.y + 1) * nsb / a.ns);
   float* tile = lt[wave];
-  float4 xa[4];
+  float4 xa[TS_P][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 t = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * 64 + 16 * j + 4 * g);
-    xa[j] = make_float4(t.x * TS_LOG2E, t.y * TS_LOG2E, t.z * TS_LOG2E, t.w * TS_LOG2E);
+  for (int q = 0; q < TS_P; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(a.x + (size_t)min(row0 + 16 * q + li, a.R - 1) * 64 + 16 * j + 4 * g);
+      xa[q][j] = make_float4(t.x * TS_LOG2E, t.y * TS_LOG2E, t.z * TS_LOG2E, t.w * TS_LOG2E);
+    }
+  float m[TS_P], s[TS_P];   // running maximum and sum of 2^(v - m), v = logit log2 e
+#pragma unroll
+  for (int q = 0; q < TS_P; ++q) {
+    m[q] = TS_NEG;
+    s[q] = 0.f;
   }
-  float m = TS_NEG, s = 0.f;   // running maximum and sum of 2^(v - m), v = logit log2 e
   auto load = [&](int sb, TsScLoads& L) {
     const float* f = a.Ef + (size_t)sb * 4096 + lane * 4;
 #pragma unroll
@@ -138,34 +148,37 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
   };
   auto compute = [&](int sb, const TsScLoads& L) {
     const int v0 = sb << 6;
-    floatx4 acc[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < TS_P; ++q) {
+      floatx4 acc[4];   // the bias is the MFMA chain's C operand: D[n = 4 g + r][row] starts at biasf[n], the float4 this lane loaded
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int nb = 0; nb < 4; ++nb) acc[nb] = floatx4{L.b[nb].x, L.b[nb].y, L.b[nb].z, L.b[nb].w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ts_e(L.w[nb][j], e), ts_e(xa[j], e), acc[nb], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const int n = v0 + 16 * nb + 4 * g;   // this lane's 4 items of the block
-      float v[4] = {acc[nb][0] + L.b[nb].x, acc[nb][1] + L.b[nb].y, acc[nb][2] + L.b[nb].z, acc[nb][3] + L.b[nb].w};
-      *reinterpret_cast<float4*>(tile + li * TS_LP + 16 * nb + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
-      if (n + 4 > a.C) {   // the row's last items: padding columns do not count
+          for (int nb = 0; nb < 4; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ts_e(L.w[nb][j], e), ts_e(xa[q][j], e), acc[nb], 0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (n + e < a.C) ? v[e] : TS_NEG;
+      for (int nb = 0; nb < 4; ++nb) {
+        const int n = v0 + 16 * nb + 4 * g;   // this lane's 4 items of the block
+        float v[4] = {acc[nb][0], acc[nb][1], acc[nb][2], acc[nb][3]};
+        *reinterpret_cast<float4*>(tile + (16 * q + li) * TS_LP + 16 * nb + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        if (n + 4 > a.C) {   // the row's last items: padding columns do not count
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (n + e < a.C) ? v[e] : TS_NEG;
+        }
+        const float mn = fmaxf(m[q], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        s[q] = s[q] * __builtin_amdgcn_exp2f(m[q] - mn) + ((__builtin_amdgcn_exp2f(v[0] - mn) + __builtin_amdgcn_exp2f(v[1] - mn)) +
+                                                           (__builtin_amdgcn_exp2f(v[2] - mn) + __builtin_amdgcn_exp2f(v[3] - mn)));
+        m[q] = mn;
       }
-      const float mn = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-      s = s * __builtin_amdgcn_exp2f(m - mn) + ((__builtin_amdgcn_exp2f(v[0] - mn) + __builtin_amdgcn_exp2f(v[1] - mn)) +
-                                                (__builtin_amdgcn_exp2f(v[2] - mn) + __builtin_amdgcn_exp2f(v[3] - mn)));
-      m = mn;
     }
-    // the wave's 16 x 64 tile leaves through LDS: 4 rows x 256 B per store instruction (lane = row 4 i + g, chunk li)
+    // the wave's (16 TS_P) x 64 tile leaves through LDS: 4 rows x 256 B per store instruction (lane = row 4 i + g, chunk li)
     const int col = v0 + 4 * li;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * TS_P; ++i) {
       const int r = 4 * i + g;
       const float4 o = *reinterpret_cast<const float4*>(tile + r * TS_LP + 4 * li);
       if (row0 + r < a.Rpad) *reinterpret_cast<float4*>(a.logits + (size_t)(row0 + r) * a.ldl + col) = o;   // padding rows: finite values
@@ -188,16 +201,21 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
     if (sb + 1 < sb1) compute(sb + 1, B);
   }
 #pragma unroll
-  for (int off = 16; off <= 32; off <<= 1) {   // the 4 lane groups of a row
-    const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
-    const float mn = fmaxf(m, m2);
-    s = s * __builtin_amdgcn_exp2f(m - mn) + s2 * __builtin_amdgcn_exp2f(m2 - mn);
-    m = mn;
-  }
-  if (g == 0 && row < a.R) {
-    float* p = a.part + ((size_t)row * a.ns + blockIdx.y) * 2;
-    p[0] = m;
-    p[1] = s;
+  for (int q = 0; q < TS_P; ++q) {
+    float mq = m[q], sq = s[q];
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {   // the 4 lane groups of a row
+      const float m2 = __shfl_xor(mq, off, 64), s2 = __shfl_xor(sq, off, 64);
+      const float mn = fmaxf(mq, m2);
+      sq = sq * __builtin_amdgcn_exp2f(mq - mn) + s2 * __builtin_amdgcn_exp2f(m2 - mn);
+      mq = mn;
+    }
+    const int row = row0 + 16 * q + li;
+    if (g == 0 && row < a.R) {
+      float* p = a.part + ((size_t)row * a.ns + blockIdx.y) * 2;
+      p[0] = mq;
+      p[1] = sq;
+    }
   }
 }
 
@@ -439,7 +457,7 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   TsArgs a;
   a.x = x; a.E = E; a.bias = bias; a.labels = labels;
   a.R = R; a.C = C; a.ldl = ts_ldl(C); a.Rpad = ts_rpad(R);
-  const int n64 = (R + 63) / 64, nsb = (a.ldl + 63) / 64;
+  const int nsb = (a.ldl + 63) / 64;
   float* p = ws;
   a.logits = p; p += ts_up64((size_t)a.Rpad * a.ldl);
   a.Ef = p;     p += (size_t)nsb * 4096;
@@ -450,9 +468,10 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   a.lab32 = reinterpret_cast<int*>(p); p += ts_up64(a.Rpad);
   a.part = p;
   a.scal = scal; a.dX = dX; a.dE = dE; a.dbias = dbias;
-  // Splits: a workgroup is 64 rows x (items / splits). ~3 workgroups per CU for the score pass, ~1 per CU for d x (MFMA-bound:
-  // what counts is that no CU gets a second workgroup while others have none)
-  a.ns = 768 / n64 < 1 ? 1 : 768 / n64 > TS_NS_MAX ? TS_NS_MAX : 768 / n64;
+  // Splits: a workgroup is 64 TS_P rows (score pass; 64 rows in d x) x (items / splits): one full round of the chip's 256
+  // workgroup slots per launch (both kernels hold > 128 registers per lane: one workgroup per CU)
+  const int nrt = (R + 64 * TS_P - 1) / (64 * TS_P), n64 = (R + 63) / 64;
+  a.ns = 256 / nrt < 1 ? 1 : 256 / nrt > TS_NS_MAX ? TS_NS_MAX : 256 / nrt;
   a.ns2 = 256 / n64 < 1 ? 1 : 256 / n64 > 8 ? 8 : 256 / n64;
   if (a.ns > nsb) a.ns = nsb;
   if (a.ns2 > nsb) a.ns2 = nsb;
@@ -469,7 +488,7 @@ int lr_launch_train_scores(const float* x, const float* E, const float* bias, co
   const long long nt = 2LL * nsb * 1024 + (long long)(a.Rpad / 16) * 256 + a.ldl;
   hipLaunchKernelGGL(ts_fragments_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_fragments_kernel");
-  hipLaunchKernelGGL(ts_scores_kernel, dim3(n64, a.ns), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ts_scores_kernel, dim3(nrt, a.ns), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_scores_kernel");
   hipLaunchKernelGGL(ts_combine_kernel, dim3((a.Rpad + 3) / 4), dim3(256), 0, st, a);
   LR_CHECK_LAUNCH("ts_combine_kernel");
