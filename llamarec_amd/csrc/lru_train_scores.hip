@@ -111,12 +111,13 @@ struct TsScLoads {
 // ---- scores + running (max, sum exp) -------------------------------------------------------------------------------------
 // grid (row tiles of 64, a.ns item splits). A WAVE owns a 16-row panel; the four waves of a workgroup walk the same 64-item
 // super-blocks of the split (the table fragments come from L2 once per workgroup and from L1 for the other three waves).
-#define TS_P 3   // 16-row panels per wave in the score pass: a fragment load of the table feeds TS_P x 64 MFMAs. With one panel
-                 // the loop moved 20 KB per 64 MFMAs and wave = 6.4 flop per byte, and a CU's vector memory path delivers
-                 // ~30 B/clk whatever it hits (tools/diag/mfma_f32_issue.hip: 16 coalesced loads per 64 MFMAs already cost 2
-                 // waves per SIMD 83-93 instead of 64 cycles per MFMA) against 256 flop/clk of f32 MFMA: 85 us with one panel, 73 with
-                 // two, 69 with three (319 registers; four: 366 and accumulator copies through AGPRs, not tried on the GPU). The same
-                 // change in the d x pass (two panels; its second stream, the logits, grows with the rows): 66 -> 82 us, not kept.
+#define TS_P 3   // 16-row panels per wave in the score pass: a fragment load of the table feeds TS_P x 64 MFMAs, so the loop's
+                 // per-block costs that do not overlap with f32 MFMAs (20 operand loads and their address arithmetic, the waits
+                 // in front of the first MFMA) are paid once per TS_P x 64: 85 us with one panel, 73 with two, 69 with three
+                 // (319 registers; four: 366 and accumulator copies through AGPRs, not tried on the GPU). The same change in
+                 // the d x pass (two panels; its second stream, the logits, grows with the rows): 66 -> 82 us, not kept.
+                 // (Not a bandwidth effect: tools/diag/mfma_f32_issue.hip pulls 59 B/clk per CU of coalesced loads under a full
+                 // MFMA stream at one wave per SIMD.)
 __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
   __shared__ __attribute__((aligned(16))) float lt[4][TS_P * 16 * TS_LP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;

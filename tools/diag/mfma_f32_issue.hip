@@ -81,6 +81,54 @@ __global__ __launch_bounds__(512) void k(const float* buf, float* out, unsigned 
   if (lane == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+
+// Sweep: NL coalesced 1 KB loads (one register set ahead, unconditional) per 64 MFMAs and wave -> what a CU's vector memory path
+// delivers under an MFMA stream. Addresses walk a 1 MB window (L2-resident) or stay inside 16 KB (L1-resident).
+template <int NL, bool L1>
+__global__ __launch_bounds__(512) void ksweep(const float* buf, float* out, unsigned long long* stamps, int iters) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long t0, t1;
+  floatx4 acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float4 w[2][NL];
+  const float* p = buf + lane * 4;
+  const int span = L1 ? 1 : 16;   // windows of NL KB
+  for (int i = 0; i < NL; ++i) w[0][i] = *reinterpret_cast<const float4*>(p + i * 256);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) w[half ^ 1][i] = *reinterpret_cast<const float4*>(p + ((it + half + 1) % span) * (NL * 256) + i * 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 64; ++k)
+        acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(el(w[half][(k >> 2) % NL], k & 3), 1.0f + lane, acc[k & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (lane == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+template <int NL, bool L1>
+void sweep(int threads, const float* buf, float* out, unsigned long long* st) {
+  const int iters = 256, grid = 256;
+  hipLaunchKernelGGL((ksweep<NL, L1>), dim3(grid), dim3(threads), 0, 0, buf, out, st, iters);
+  hipLaunchKernelGGL((ksweep<NL, L1>), dim3(grid), dim3(threads), 0, 0, buf, out, st, iters);
+  hipDeviceSynchronize();
+  const int n = grid * threads / 64;
+  std::vector<unsigned long long> h(n);
+  hipMemcpy(h.data(), st, n * 8, hipMemcpyDeviceToHost);
+  std::sort(h.begin(), h.end());
+  const double cyc = (double)h[n / 2] / (iters * 64);   // per MFMA and wave
+  const double bytes_per_clk = (double)(threads / 64) * NL * 1024 / (cyc * 64);   // per CU
+  printf("%2d x 1 KB loads per 64 MFMAs and wave, %s, %d waves/SIMD: %6.1f cycles per MFMA and wave -> %5.1f B/clk per CU\n", NL,
+         L1 ? "L1-resident" : "L2-resident", threads / 256, cyc, bytes_per_clk);
+}
+
 template <int V>
 void run(const char* name, int threads, const float* buf, float* out, unsigned long long* st, int mfma_per_iter) {
   const int iters = 256, grid = 256;
@@ -98,8 +146,8 @@ void run(const char* name, int threads, const float* buf, float* out, unsigned l
 int main() {
   float *buf, *out;
   unsigned long long* st;
-  hipMalloc(&buf, 64 * 4096 * 4 + 65536);
-  hipMemset(buf, 0, 64 * 4096 * 4 + 65536);
+  hipMalloc(&buf, 4 << 20);
+  hipMemset(buf, 0, 4 << 20);
   hipMalloc(&out, 256 * 512 * 4);
   hipMalloc(&st, 256 * 8 * 8);
   for (int threads : {256, 512}) {
@@ -110,6 +158,14 @@ int main() {
     run<4>("4 32x32x2, registers (16 per iteration)", threads, buf, out, st, 16);
     run<5>("5 variant 2 + label / padding branches (EXEC rewrites)", threads, buf, out, st, 64);
     run<6>("6 variant 2 + branch-free label select", threads, buf, out, st, 64);
+  }
+  for (int threads : {256, 512}) {
+    sweep<4, false>(threads, buf, out, st);
+    sweep<8, false>(threads, buf, out, st);
+    sweep<16, false>(threads, buf, out, st);
+    sweep<32, false>(threads, buf, out, st);
+    sweep<16, true>(threads, buf, out, st);
+    sweep<32, true>(threads, buf, out, st);
   }
   return 0;
 }
