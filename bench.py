@@ -653,7 +653,8 @@ def item_gemm_roofline(dev, users=4096, reps=5):
 
 def side_measurements(args, ranker, label_ids, dev, steps, shared):
     """Reported, never the metric: (1) BASELINE.json configs[1] (ML-100k shape) through the same pipeline, 4 steps;
-    (2) SURVEY.md 8(f) #4, three optimizer steps of the ranker's LoRA fine-tuning on the same weights."""
+    (2) SURVEY.md 8(f) #4, three optimizer steps of the ranker's LoRA fine-tuning on the same weights; (3) SURVEY.md 8(f) #2,
+    the retriever's training step at the reference's Beauty batch shape."""
     import torch
 
     from llamarec_amd.lru import LRURec, init_lru_state_dict
@@ -717,6 +718,33 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
                                "workspace_gb": eng._ws.numel() / 1e9,
                                "loss_finite": bool(np.isfinite(float(eng._out[0])))}
     del eng
+    # the retriever's training step at the reference's batch shape (config.py:103-111: 64 x 50 for Beauty),
+    # synthetic rows, half of them left-padded like short users; fp32, hipGraph replay as train_retriever.py runs it
+    from llamarec_amd.train import LRUTrainEngine
+
+    wb = WORKLOADS["beauty"]
+    rng = np.random.default_rng(0)
+    Bt, Lt = 64, wb["L"]
+    seq = rng.integers(1, wb["V"] + 1, size=(Bt, Lt + 1))
+    toks, labs = seq[:, :-1].copy(), seq[:, 1:].copy()
+    for i, n in enumerate(rng.integers(2, Lt, size=Bt // 2)):
+        toks[i, : Lt - n] = 0
+        labs[i, : Lt - n - 1] = 0
+    te = LRUTrainEngine(init_lru_state_dict(wb["V"], seed=1), seed=3, use_graph=True)
+    tt_, tl_ = torch.from_numpy(toks).to(dev), torch.from_numpy(labs).to(dev)
+    for _ in range(3):
+        te.train_step(tt_, tl_)
+    torch.cuda.synchronize()
+    n_it = 50
+    tr0 = time.perf_counter()
+    for _ in range(n_it):
+        loss_t = te.train_step(tt_, tl_)
+    torch.cuda.synchronize()
+    tr = (time.perf_counter() - tr0) / n_it
+    out["retriever_train_shape"] = {"workload": "beauty", "batch": Bt, "seq_len": Lt, "num_items": wb["V"], "dtype": "f32",
+                                    "optimizer_steps": n_it, "ms_per_step": tr * 1e3, "sequences_per_s": Bt / tr,
+                                    "loss_finite": bool(np.isfinite(float(loss_t)))}
+    del te
     return out
 
 
