@@ -86,3 +86,20 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_side_fields_carry_the_training_steps():
+    """The default run's side measurements (never part of `value`): the other BASELINE shape through the same pipeline, the
+    ranker's LoRA step and the retriever's training step. bench.py takes them at full depth only (32 layers), so this is the
+    default run with two timed steps and without the CPU and Synth-1M legs."""
+    r = _run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-item-roofline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rt = d["retriever_train_shape"]
+    assert rt["workload"] == "beauty" and rt["batch"] == 64 and rt["seq_len"] == 50 and rt["dtype"] == "f32"
+    assert rt["loss_finite"] is True and 0.0 < rt["ms_per_step"] < 5.0
+    assert abs(rt["sequences_per_s"] - 64 / (rt["ms_per_step"] * 1e-3)) < 1e-6 * rt["sequences_per_s"]
+    lt = d["lora_train_shape"]
+    assert lt["loss_finite"] is True and lt["workspace_allocations_in_timed_loop"] == 0 and lt["tokens_per_s"] > 0
+    assert d["ml100k_shape"]["users_per_s"] > 0
