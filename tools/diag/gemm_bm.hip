@@ -4,6 +4,10 @@
 // grid (2 x 4), same regions and recycling order of the LDS-DMA, same LDS image and MFMA; a 128-row tile has half the A
 // pieces (one per wave and region instead of two) and half the MFMAs per phase. Plain bf16 store; s_memtime around the K loop.
 //   C[M][N] = A[M][K] B[N][K]^T; M a multiple of BM, N of 256, K of 64.
+// A second kernel, gemm_bm_rs_kernel, stages the operand stream through REGISTERS instead of LDS-DMA (plain loads at the phase
+// where the product issues a region's DMA, ds_write_b128 one K tile later at the same phase): correct, but as written hipcc
+// waits for every phase's fresh loads in front of that phase's barrier (11-26 k cycles per K tile) -- the loads would have to
+// go through inline asm with hand-counted waits, as the DMAs of the attention and top-K kernels do. Kept as the starting point.
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/gemm_bm tools/diag/gemm_bm.hip && /tmp/gemm_bm
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -196,6 +200,186 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
   }
 }
 
+template <int BM>
+__global__ __launch_bounds__(512) void gemm_bm_rs_kernel(const u16* __restrict__ A, const u16* __restrict__ B, u16* __restrict__ C,
+                                                      int M, int N, int K, unsigned long long* stamps) {
+  constexpr int AP = BM / 128;      // A pieces per wave and region (2 / 1)
+  constexpr int MQ = BM / 64;       // 16-row blocks per quadrant (4 / 2)
+  constexpr int HALF = BM / 2;      // rows of a wave group
+  constexpr int WA = 3 * AP + 4, WB = 6 + 2 * AP;   // "all but my newest n" at phases 0, 2 / 1, 3 (10, 10 for the product's tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nkt = K >> 6;
+  const int tilesM = M / BM, tilesN = N >> 8, nwg = tilesM * tilesN;
+  int id;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int group_m = 8, per_group = group_m * tilesN;
+    const int g = id / per_group, rem = id % per_group, first_m = g * group_m;
+    const int gsz = min(group_m, tilesM - first_m);
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
+  }
+  const int m0 = tm * BM, n0 = tn << 8;
+
+  // DMA pieces of this wave (8 rows x 128 B): region 0 = A rows of quadrant row-half 0, 1 = B rows nh0, 2 = B rows nh1, 3 = A rows of
+  // row-half 1. A: AP pieces per wave (q = AP wave + j: group q / (8 AP / 2) ..), B: 2 per wave
+  const int srow = lane >> 3, spos = lane & 7;
+  const char* src[4][2];
+  int ldsoff[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qa = AP * wave + (j < AP ? j : 0);                 // 0 .. 8 AP - 1
+    const int ra = (qa / (4 * AP)) * HALF + (qa % (4 * AP)) * 8;  // row-half 0 rows of wave group qa / (4 AP)
+    const int qb = 2 * wave + j;
+    const int rb = (qb >> 2) * 64 + (qb & 3) * 8;
+    const int rows[4] = {ra, rb, rb + 32, ra + HALF / 2};
+    const bool isA[4] = {true, false, false, true};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = rows[t] + srow;
+      const int chunk = spos ^ ((row >> 1) & 7);
+      if (isA[t]) {
+        src[t][j] = reinterpret_cast<const char*>(A) + ((size_t)(m0 + row) * K) * 2 + chunk * 16;
+        ldsoff[t][j] = rows[t] * 128;
+      } else {
+        src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
+        ldsoff[t][j] = 32768 + rows[t] * 128;
+      }
+    }
+  }
+  // register-staged stream: a region's pieces are requested with plain loads at the phase where the product issues their DMA and
+  // written to LDS one K tile later at the same phase (two phases before their first reader); hipcc tracks these loads' vmcnt
+  float4 stg[4][2];
+#define RS_LOAD(reg, tile)                                                                            \
+  do {                                                                                                \
+    stg[(reg)][0] = *reinterpret_cast<const float4*>(src[(reg)][0] + (size_t)(tile)*128);             \
+    if (((reg) == 1 || (reg) == 2) || AP == 2) stg[(reg)][1] = *reinterpret_cast<const float4*>(src[(reg)][1] + (size_t)(tile)*128); \
+  } while (0)
+#define RS_WRITE(reg, tile)                                                                           \
+  do {                                                                                                \
+    char* dst_ = smem + ((tile)&1) * STAGE_BYTES + lane * 16;                                         \
+    *reinterpret_cast<float4*>(dst_ + ldsoff[(reg)][0]) = stg[(reg)][0];                              \
+    if (((reg) == 1 || (reg) == 2) || AP == 2) *reinterpret_cast<float4*>(dst_ + ldsoff[(reg)][1]) = stg[(reg)][1]; \
+  } while (0)
+#define RB_DMA(reg, tile)                                                                         \
+  do {                                                                                            \
+    char* dst_ = smem + ((tile)&1) * STAGE_BYTES;                                                 \
+    glds16(src[(reg)][0] + (size_t)(tile)*128, dst_ + ldsoff[(reg)][0]);                          \
+    if (((reg) == 1 || (reg) == 2) || AP == 2) glds16(src[(reg)][1] + (size_t)(tile)*128, dst_ + ldsoff[(reg)][1]); \
+  } while (0)
+
+  const int frow = lane & 15, fsw = frow >> 1;
+  const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
+  const int fo1 = frow * 128 + (((4 + (lane >> 4)) ^ fsw) << 4);
+  const int a_base = wm * HALF * 128;
+  const int b_base = 32768 + wn * 64 * 128;
+
+  floatx4 acc[2 * MQ][4];
+#pragma unroll
+  for (int i = 0; i < 2 * MQ; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 afr[2 * MQ], b0x[4], b0y[4], b1[4];
+
+#define RB_LOAD_A(buf, mh)                                                                                   \
+  _Pragma("unroll") for (int mt = 0; mt < MQ; ++mt) {                                                        \
+    afr[mt] = *reinterpret_cast<const bf16x8*>((buf) + a_base + ((mh)*(HALF / 2) + mt * 16) * 128 + fo0);      \
+    afr[MQ + mt] = *reinterpret_cast<const bf16x8*>((buf) + a_base + ((mh)*(HALF / 2) + mt * 16) * 128 + fo1); \
+  }
+#define RB_LOAD_B(dst, buf, nh)                                                                       \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                  \
+    dst[nt] = *reinterpret_cast<const bf16x8*>((buf) + b_base + ((nh)*32 + nt * 16) * 128 + fo0);     \
+    dst[2 + nt] = *reinterpret_cast<const bf16x8*>((buf) + b_base + ((nh)*32 + nt * 16) * 128 + fo1); \
+  }
+#define RB_MFMA(bfrag, mh, nh)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+  _Pragma("unroll") for (int mt = 0; mt < MQ; ++mt)                                                   \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
+    acc[(mh)*MQ + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                         \
+        bfrag[ks * 2 + nt], afr[ks * MQ + mt], acc[(mh)*MQ + mt][(nh)*2 + nt], 0, 0, 0);
+#define RB_TILE(kt, b0cur, b0nxt)                                                                     \
+  {                                                                                                   \
+    const char* cur = smem + ((kt)&1) * STAGE_BYTES;                                                   \
+    const char* nxt = smem + (((kt) + 1) & 1) * STAGE_BYTES;                                           \
+    const bool more = (kt) + 1 < nkt;                                                                 \
+    const bool more2 = (kt) + 2 < nkt;                                                                \
+    const bool first = (kt) == 0;                                                                     \
+    RB_LOAD_A(cur, 0)                                                                                 \
+    if (!first) RS_WRITE(3, (kt));                                                                    \
+    RS_LOAD(3, min((kt) + 1, nkt - 1));   /* unconditional (clamped): a conditional load voids hipcc's vmcnt bookkeeping */ \
+    BARRIER();                                                                                        \
+    RB_MFMA(b0cur, 0, 0)                                                                              \
+    BARRIER();                                                                                        \
+    RB_LOAD_B(b1, cur, 1)                                                                             \
+    if (!first && more) RS_WRITE(1, (kt) + 1);                                                        \
+    RS_LOAD(1, min((kt) + 2, nkt - 1));   /* unconditional (clamped): a conditional load voids hipcc's vmcnt bookkeeping */                                                                  \
+    BARRIER();                                                                                        \
+    RB_MFMA(b1, 0, 1)                                                                                 \
+    BARRIER();                                                                                        \
+    RB_LOAD_A(cur, 1)                                                                                 \
+    if (!first && more) RS_WRITE(0, (kt) + 1);                                                        \
+    RS_LOAD(0, min((kt) + 2, nkt - 1));   /* unconditional (clamped): a conditional load voids hipcc's vmcnt bookkeeping */                                                                  \
+    BARRIER();                                                                                        \
+    RB_MFMA(b1, 1, 1)                                                                                 \
+    BARRIER();                                                                                        \
+    if (more) { RB_LOAD_B(b0nxt, nxt, 0) }                                                            \
+    if (!first && more) RS_WRITE(2, (kt) + 1);                                                        \
+    RS_LOAD(2, min((kt) + 2, nkt - 1));   /* unconditional (clamped): a conditional load voids hipcc's vmcnt bookkeeping */                                                                  \
+    BARRIER();                                                                                        \
+    RB_MFMA(b0cur, 1, 0)                                                                              \
+    BARRIER();                                                                                        \
+  }
+
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) RB_DMA(reg, 0);
+  if (nkt > 1) {
+    RB_DMA(1, 1);
+    RB_DMA(0, 1);
+    RB_DMA(2, 1);
+    WAIT_VM(4 + AP);
+  } else {
+    WAIT_VM(0);
+  }
+  BARRIER();
+  RB_LOAD_B(b0x, smem, 0)
+  unsigned long long t_begin = 0, t_end = 0;
+  if (stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
+  if (wm == 1) {
+    __builtin_amdgcn_s_setprio(1);
+    BARRIER();   // group 1 runs one barrier behind group 0
+  }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    RB_TILE(kt, b0x, b0y)
+    if (kt + 1 < nkt) RB_TILE(kt + 1, b0y, b0x)
+  }
+  if (wm == 0) BARRIER();
+  if (stamps) {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+    if (lane == 0) stamps[blockIdx.x * 8 + wave] = t_end - t_begin;
+  }
+  const int quad = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2 * MQ; ++mt) {
+    const int row = m0 + wm * HALF + mt * 16 + (lane & 15);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = n0 + wn * 64 + nt * 16 + 4 * quad;
+      const unsigned lo = (unsigned)f2bf(acc[mt][nt][0]) | ((unsigned)f2bf(acc[mt][nt][1]) << 16);
+      const unsigned hi = (unsigned)f2bf(acc[mt][nt][2]) | ((unsigned)f2bf(acc[mt][nt][3]) << 16);
+      *reinterpret_cast<uint2*>(C + (size_t)row * N + col) = make_uint2(lo, hi);
+    }
+  }
+}
+
 static float bf2f(u16 b) {
   unsigned u = (unsigned)b << 16;
   float f;
@@ -209,8 +393,9 @@ static u16 f2bf_host(float f) {
   return (u16)(u >> 16);
 }
 
-template <int BM>
+template <int BM, bool RS>
 static void run(int M, int N, int K) {
+  auto kernel = RS ? gemm_bm_rs_kernel<BM> : gemm_bm_kernel<BM>;
   std::vector<u16> hA((size_t)M * K), hB((size_t)N * K);
   unsigned st = 12345u;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -223,19 +408,19 @@ static void run(int M, int N, int K) {
   hipMalloc(&dS, (size_t)nwg * 8 * 8);
   hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
-  hipFuncSetAttribute((const void*)gemm_bm_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_bm_kernel<BM>, dim3(nwg), dim3(512), 2 * STAGE_BYTES, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
+  hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), 2 * STAGE_BYTES, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
   const int reps = 10;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_bm_kernel<BM>, dim3(nwg), dim3(512), 2 * STAGE_BYTES, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), 2 * STAGE_BYTES, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
-  hipLaunchKernelGGL(gemm_bm_kernel<BM>, dim3(nwg), dim3(512), 2 * STAGE_BYTES, 0, dA, dB, dC, M, N, K, dS);
+  hipLaunchKernelGGL(kernel, dim3(nwg), dim3(512), 2 * STAGE_BYTES, 0, dA, dB, dC, M, N, K, dS);
   hipDeviceSynchronize();
   hipError_t err = hipGetLastError();
   std::vector<unsigned long long> hs((size_t)nwg * 8);
@@ -250,25 +435,30 @@ static void run(int M, int N, int K) {
     for (int k = 0; k < K; ++k) ref += (double)bf2f(hA[(size_t)m * K + k]) * bf2f(hB[(size_t)n * K + k]);
     worst = std::max(worst, std::fabs((double)bf2f(hC[(size_t)m * N + n]) - ref) / (std::fabs(ref) + 1e-3));
   }
-  printf("BM=%3d M=%5d N=%5d K=%5d: %4d workgroups, %7.1f us = %5.0f TF/s; K loop %5.0f cycles per K tile (median wave; MFMA-bound = %d); max rel err %.4f; %s\n",
-         BM, M, N, K, nwg, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, (double)hs[hs.size() / 2] / (K / 64), BM * 8, worst, hipGetErrorString(err));
+  printf("%s BM=%3d M=%5d N=%5d K=%5d: %4d workgroups, %7.1f us = %5.0f TF/s; K loop %5.0f cycles per K tile (median wave; MFMA-bound = %d); max rel err %.4f; %s\n",
+         RS ? "staged" : "LDS-DMA", BM, M, N, K, nwg, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, (double)hs[hs.size() / 2] / (K / 64), BM * 8, worst, hipGetErrorString(err));
   hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dS);
 }
 
 int main() {
-  // the batch shape (many rounds of tiles): per-K-tile cost of the two tiles at full occupancy
-  run<256>(32768, 4096, 4096);
-  run<128>(32768, 4096, 4096);
-  run<256>(32768, 4096, 11008);
-  run<128>(32768, 4096, 11008);
-  // the online shape, M = 460 padded to 512: gate-up (unsplit in latency mode), o, qkv, down as plain products
-  run<256>(512, 22016, 4096);
-  run<128>(512, 22016, 4096);
-  run<256>(512, 12288, 4096);
-  run<128>(512, 12288, 4096);
-  run<256>(512, 4096, 4096);
-  run<128>(512, 4096, 4096);
-  run<256>(512, 4096, 11008);
-  run<128>(512, 4096, 11008);
+  // the batch shape (many rounds of tiles): per-K-tile cost of the two tiles at full occupancy, LDS-DMA against register staging
+  run<256, false>(32768, 4096, 4096);
+  run<256, true>(32768, 4096, 4096);
+  run<128, false>(32768, 4096, 4096);
+  run<128, true>(32768, 4096, 4096);
+  run<256, false>(32768, 4096, 11008);
+  run<256, true>(32768, 4096, 11008);
+  run<128, false>(32768, 4096, 11008);
+  run<128, true>(32768, 4096, 11008);
+  // the online shape, M = 460 padded to 512: gate-up (unsplit in latency mode), qkv, o, down as plain products
+  run<256, false>(512, 22016, 4096);
+  run<128, false>(512, 22016, 4096);
+  run<128, true>(512, 22016, 4096);
+  run<256, false>(512, 12288, 4096);
+  run<128, false>(512, 12288, 4096);
+  run<256, false>(512, 4096, 4096);
+  run<128, false>(512, 4096, 4096);
+  run<256, false>(512, 4096, 11008);
+  run<128, false>(512, 4096, 11008);
   return 0;
 }
