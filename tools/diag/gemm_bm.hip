@@ -4,10 +4,11 @@
 // grid (2 x 4), same regions and recycling order of the LDS-DMA, same LDS image and MFMA; a 128-row tile has half the A
 // pieces (one per wave and region instead of two) and half the MFMAs per phase. Plain bf16 store; s_memtime around the K loop.
 //   C[M][N] = A[M][K] B[N][K]^T; M a multiple of BM, N of 256, K of 64.
-// A second kernel, gemm_bm_rs_kernel, stages the operand stream through REGISTERS instead of LDS-DMA (plain loads at the phase
-// where the product issues a region's DMA, ds_write_b128 one K tile later at the same phase): correct, but as written hipcc
-// waits for every phase's fresh loads in front of that phase's barrier (11-26 k cycles per K tile) -- the loads would have to
-// go through inline asm with hand-counted waits, as the DMAs of the attention and top-K kernels do. Kept as the starting point.
+// A second kernel, gemm_bm_rs_kernel, stages the operand stream through REGISTERS instead of LDS-DMA (global_load_dwordx4 at the
+// phase where the product issues a region's DMA, ds_write_b128 one K tile later at the same phase; both as inline asm with
+// hand-counted vmcnt: through plain C++ loads hipcc waited for every phase's fresh loads in front of that phase's barrier,
+// 11-26 k cycles per K tile). Result at 128 rows: 1 832 cycles per K tile against 1 856 with LDS-DMA -- the form of the request is
+// not what the LOAD phases wait for. (At 256 rows the variant spills 34 registers: timings meaningless.)
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/gemm_bm tools/diag/gemm_bm.hip && /tmp/gemm_bm
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -256,17 +257,21 @@ __global__ __launch_bounds__(512) void gemm_bm_rs_kernel(const u16* __restrict__
   }
   // register-staged stream: a region's pieces are requested with plain loads at the phase where the product issues their DMA and
   // written to LDS one K tile later at the same phase (two phases before their first reader); hipcc tracks these loads' vmcnt
-  float4 stg[4][2];
-#define RS_LOAD(reg, tile)                                                                            \
+  floatx4 stg[4][2];   // (the kernel has no static LDS: the dynamic array starts at LDS address 0, which the asm stores use)
+#define RS_LOAD(reg, tile)   /* inline asm: hipcc must not know these loads (it would wait for them in front of the next barrier) */ \
   do {                                                                                                \
-    stg[(reg)][0] = *reinterpret_cast<const float4*>(src[(reg)][0] + (size_t)(tile)*128);             \
-    if (((reg) == 1 || (reg) == 2) || AP == 2) stg[(reg)][1] = *reinterpret_cast<const float4*>(src[(reg)][1] + (size_t)(tile)*128); \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stg[(reg)][0]) : "v"(src[(reg)][0] + (size_t)(tile)*128) : "memory"); \
+    if (((reg) == 1 || (reg) == 2) || AP == 2)                                                        \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stg[(reg)][1]) : "v"(src[(reg)][1] + (size_t)(tile)*128) : "memory"); \
   } while (0)
+// the pieces requested four phases ago: all but the (pieces of the last three phases) newest loads have landed
 #define RS_WRITE(reg, tile)                                                                           \
   do {                                                                                                \
-    char* dst_ = smem + ((tile)&1) * STAGE_BYTES + lane * 16;                                         \
-    *reinterpret_cast<float4*>(dst_ + ldsoff[(reg)][0]) = stg[(reg)][0];                              \
-    if (((reg) == 1 || (reg) == 2) || AP == 2) *reinterpret_cast<float4*>(dst_ + ldsoff[(reg)][1]) = stg[(reg)][1]; \
+    const unsigned dst_ = (unsigned)(((tile)&1) * STAGE_BYTES + lane * 16);                           \
+    if ((reg) == 1 || (reg) == 2) { WAIT_VM(2 * AP + 2); } else { WAIT_VM(AP + 4); }                  \
+    asm volatile("ds_write_b128 %0, %1" ::"v"(dst_ + (unsigned)ldsoff[(reg)][0]), "v"(stg[(reg)][0]) : "memory"); \
+    if (((reg) == 1 || (reg) == 2) || AP == 2)                                                        \
+      asm volatile("ds_write_b128 %0, %1" ::"v"(dst_ + (unsigned)ldsoff[(reg)][1]), "v"(stg[(reg)][1]) : "memory"); \
   } while (0)
 #define RB_DMA(reg, tile)                                                                         \
   do {                                                                                            \
