@@ -29,10 +29,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define GB_SYNC() __builtin_amdgcn_s_barrier()
 #define BARRIER()                           \
   do {                                      \
     __builtin_amdgcn_sched_barrier(0);      \
-    __builtin_amdgcn_s_barrier();           \
+    GB_SYNC();                              \
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
 
