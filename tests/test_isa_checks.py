@@ -82,3 +82,41 @@ def test_inline_asm_lds_dma_kernels_keep_m0_and_vmcnt_by_hand(src, tmp_path):
                         break
                     assert not DMA.match(x), (src, name, "an LDS-DMA reaches an s_barrier without a vmcnt wait in between", x)
     assert checked >= 1, src
+
+
+TRAIN_FILES = {"lru_train_scores.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "lru_train_blocks.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
+@pytest.mark.parametrize("src", sorted(TRAIN_FILES))
+def test_training_panel_kernels_keep_their_operands_in_registers(src, tmp_path):
+    """The training step's panel kernels hold operand sets one step ahead of their MFMAs in registers. Twice this round hipcc put
+    such a set on the STACK instead (a struct of float4 passed by reference to the load / compute lambdas; an array written with
+    separate statements and read in a loop): scratch_store / scratch_load round trips in front of every MFMA block, no build
+    error, 25-50 % slower. Every kernel of these files must have an empty private segment and no spilled register."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC] + FLAGS + TRAIN_FILES[src] + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+                   check=True, capture_output=True, cwd=CSRC)
+    text = out.read_text()
+    names = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", text, flags=re.M)
+    assert len(names) >= 4, (src, names)
+    for n in names:
+        blk = re.search(r"^\s*\.amdhsa_kernel\s+%s\n(.*?)\.end_amdhsa_kernel" % re.escape(n), text, flags=re.M | re.S).group(1)
+        assert re.search(r"\.amdhsa_private_segment_fixed_size\s+0\b", blk), (src, n, "uses scratch")
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)] + [int(x) for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", text)]
+    assert spills and max(spills) == 0, (src, spills)
+    assert "scratch_" not in text, src
+
+
+def test_diag_prototypes_still_compile(tmp_path):
+    """tools/diag/*.hip are stand-alone measurement programs (the GEMM K-loop prototypes, the MFMA issue sweep, the store-rate
+    probe): they are evidence behind DESIGN.md's numbers and must keep building for gfx950."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    diag = os.path.join(REPO, "tools", "diag")
+    srcs = sorted(f for f in os.listdir(diag) if f.endswith(".hip"))
+    assert {"gemm4w.hip", "gemm_bm.hip", "mfma_f32_issue.hip", "store_rate.hip"} <= set(srcs)
+    for f in srcs:
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-c", "--cuda-device-only", os.path.join(diag, f), "-o", str(tmp_path / (f + ".o"))],
+                       check=True, capture_output=True)
