@@ -22,6 +22,9 @@ typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define STAGE_BYTES 65536
+#ifndef GB_ABL
+#define GB_ABL 0   // ablations of the LDS-DMA kernel (wrong results, timings only): 1 = the B operand neither streamed nor re-read after the first K tile, 2 = the same for A
+#endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -135,26 +138,26 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
     const char* nxt = smem + (((kt) + 1) & 1) * STAGE_BYTES;                                           \
     const bool more = (kt) + 1 < nkt;                                                                 \
     const bool more2 = (kt) + 2 < nkt;                                                                \
-    RB_LOAD_A(cur, 0)                                                                                 \
-    if (more) RB_DMA(3, (kt) + 1);                                                                    \
+    if (!(GB_ABL & 2) || (kt) == 0) { RB_LOAD_A(cur, 0) }                                             \
+    if (more && !(GB_ABL & 2)) RB_DMA(3, (kt) + 1);                                                   \
     if (more2) { WAIT_VM(WA); } else { WAIT_VM(0); }                                                  \
     BARRIER();                                                                                        \
     RB_MFMA(b0cur, 0, 0)                                                                              \
     BARRIER();                                                                                        \
-    RB_LOAD_B(b1, cur, 1)                                                                             \
-    if (more2) RB_DMA(1, (kt) + 2);                                                                   \
+    if (!(GB_ABL & 1) || (kt) == 0) { RB_LOAD_B(b1, cur, 1) }                                         \
+    if (more2 && !(GB_ABL & 1)) RB_DMA(1, (kt) + 2);                                                  \
     if (more2) { WAIT_VM(WB); } else { WAIT_VM(0); }                                                  \
     BARRIER();                                                                                        \
     RB_MFMA(b1, 0, 1)                                                                                 \
     BARRIER();                                                                                        \
-    RB_LOAD_A(cur, 1)                                                                                 \
-    if (more2) RB_DMA(0, (kt) + 2);                                                                   \
+    if (!(GB_ABL & 2) || (kt) == 0) { RB_LOAD_A(cur, 1) }                                             \
+    if (more2 && !(GB_ABL & 2)) RB_DMA(0, (kt) + 2);                                                  \
     if (more2) { WAIT_VM(WA); } else { WAIT_VM(0); }                                                  \
     BARRIER();                                                                                        \
     RB_MFMA(b1, 1, 1)                                                                                 \
     BARRIER();                                                                                        \
-    if (more) { RB_LOAD_B(b0nxt, nxt, 0) }                                                            \
-    if (more2) RB_DMA(2, (kt) + 2);                                                                   \
+    if (more && !(GB_ABL & 1)) { RB_LOAD_B(b0nxt, nxt, 0) }                                           \
+    if (more2 && !(GB_ABL & 1)) RB_DMA(2, (kt) + 2);                                                  \
     if (more2) { WAIT_VM(WB); } else { WAIT_VM(0); }                                                  \
     BARRIER();                                                                                        \
     RB_MFMA(b0cur, 1, 0)                                                                              \
