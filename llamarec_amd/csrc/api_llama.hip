@@ -42,8 +42,8 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
 
 extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
   if (!h || (gemm_variant != 0 && gemm_variant != 1 && gemm_variant != 4 && gemm_variant != 5) || attention_variant < 0 ||
-      attention_variant == 3 || attention_variant > 4)
-    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: gemm in {0, 1, 4, 5}, attention in {0, 1, 2, 4}");
+      attention_variant > 2)
+    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: gemm in {0, 1, 4, 5}, attention in {0, 1, 2}");
   h->gemm_variant = gemm_variant;
   h->attn_variant = attention_variant;
   return LR_OK;

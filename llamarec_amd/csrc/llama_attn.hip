@@ -24,9 +24,6 @@
 #include <stdlib.h>
 
 #include <type_traits>
-#include <algorithm>
-#include <mutex>
-#include <vector>
 
 #include "llama_kernels.h"
 #include "lr_profile.h"
@@ -139,11 +136,11 @@ __device__ __forceinline__ fa_int4 fa_make_rsrc(const void* base, int num_record
   return r;
 }
 __device__ __forceinline__ void fa_glds16(const void* gsrc, const void* lds_wave_base) {   // per-lane source address
-  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base));   // wave-uniform by construction; keeps hipcc from carrying it in a VGPR
+  const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory");
 }
 __device__ __forceinline__ void fa_dma16(fa_int4 rsrc, const void* lds_wave_base, unsigned voff) {
-  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base));   // wave-uniform by construction; keeps hipcc from carrying it in a VGPR
+  const unsigned m0v = (unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc)
                : "memory");
 }
@@ -228,18 +225,11 @@ __device__ unsigned long long g_attn_wg[8];   // never written: the stamped inst
 // a workgroup = one (prompt, head) walks all the prompt's key blocks with wave 0 computing (every lane of the wave holds
 // the same query row, so the tile arithmetic -- and with it the bits of that row -- is that of the full kernel) and all
 // four waves staging, and `out` receives one row per prompt ([prompt][nh * hd]).
-//
-// LISTED (lr_launch_attention variant 4): 2 workgroups per CU, each walking a host-made list of (segment, head, tile) items
-// (`items` = [workgroups][list_stride]: count, then 4 ints per item; fa_build_lists) instead of one tile per workgroup: no
-// dispatch between a workgroup's tiles, the next tile's Q rows and first K/V block requested before the current tile's
-// output leaves, and the lists balanced by the tiles' key-block counts, which the host knows. Same tile arithmetic, same bits.
-template <bool STAMP, bool LASTQ = false, bool LISTED = false>
+template <bool STAMP, bool LASTQ = false>
 __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restrict__ qkv, u16* out,
                                                               const int32_t* cu, int prefix_len, int nh, int nkv,
                                                               int max_qblocks, int n_pairs, float* lse,
-                                                              const u16* __restrict__ q_rows_last = nullptr,
-                                                              const int32_t* __restrict__ items = nullptr,
-                                                              int list_stride = 0) {
+                                                              const u16* __restrict__ q_rows_last = nullptr) {
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   unsigned long long rt_entry = 0, rt_pro = 0, rt_loop = 0, rt_exit = 0;
   FA_RT(rt_entry)
@@ -248,108 +238,84 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   // the XOR swizzles are applied to the SOURCE chunk: position p of row r holds chunk p ^ s(r).
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hd = 128;
+  // ---- workgroup -> (segment, head, query tile). A (segment, head) PAIR is bound to one of 8 dispatch streams
+  // (blocks b and b + 8 are observed to share an XCD: speed only, never correctness), so the 3..12 query tiles that
+  // re-read one pair's K/V hit that XCD's L2; inside a stream the pairs' heavy tiles (qb >= 2, heaviest first) run pair
+  // after pair, and the two lightest tiles of every pair are kept for the end, where they fill the tail of the launch
+  // (a causal tile costs ~ its key-block count 2 qb + 2: launched last, a heavy tile would leave most CUs idle).
+  int seg, h, qb;
+  if (LASTQ) {
+    const int id = blockIdx.x, stream = id & 7, pl = id >> 3;
+    const int pair = pl * 8 + stream;
+    if (pair >= n_pairs) return;
+    seg = __builtin_amdgcn_readfirstlane(pair / nh);
+    h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
+    if (prefix_len > 0 && seg == 0) return;   // segment 0 is the shared prefix, not a prompt
+    qb = 0;                                    // set below, once T is known
+  } else {
+    const int id = blockIdx.x, stream = id & 7, j = id >> 3;
+    const int ppx = (n_pairs + 7) >> 3;                  // pairs per stream
+    const int n_light = min(max_qblocks, 2), n_heavy = max_qblocks - n_light;
+    int pl;
+    if (j < ppx * n_heavy) {
+      pl = j / n_heavy;
+      qb = max_qblocks - 1 - j % n_heavy;
+    } else {
+      const int j2 = j - ppx * n_heavy;
+      pl = j2 / n_light;
+      qb = n_light - 1 - j2 % n_light;
+    }
+    const int pair = pl * 8 + stream;
+    if (pair >= n_pairs) return;
+    // the integer divisions above run on the vector ALU (there is no scalar divide): hand the wave-uniform results
+    // back to scalar registers, or every buffer descriptor built from them is wrapped in a waterfall loop
+    seg = __builtin_amdgcn_readfirstlane(pair / nh);
+    h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
+    qb = __builtin_amdgcn_readfirstlane(qb);
+  }
+  const int tok0 = cu[seg];
+  const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;  // keys [0, P) live in segment 0's rows [0, P)
+  const int T = P + cu[seg + 1] - tok0;                        // sequence length, prefix included
+  if (LASTQ) qb = (T - 1) / FA_QROWS;
+  if (qb * FA_QROWS >= T || (qb + 1) * FA_QROWS <= P) return;  // no query row of this segment in the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int quad = lane >> 4, li = lane & 15;
+  const int kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
   const int stride = LASTQ ? 2 * nkv * hd : (nh + 2 * nkv) * hd;
-  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
-
-  // ---- one (segment, head, query tile) of work. A workgroup of the one-tile launch derives its item from blockIdx:
-  // a (segment, head) PAIR is bound to one of 8 dispatch streams (blocks b and b + 8 are observed to share an XCD: speed
-  // only, never correctness), so the 3..12 query tiles that re-read one pair's K/V hit that XCD's L2; inside a stream the
-  // pairs' heavy tiles (qb >= 2, heaviest first) run pair after pair, and the two lightest tiles of every pair are kept for
-  // the end, where they fill the tail of the launch (a causal tile costs ~ its key-block count 2 qb + 2: launched last, a
-  // heavy tile would leave most CUs idle). A LISTED workgroup reads its items (4 ints each: seg << 16 | head << 8 | tile,
-  // first packed row, length with the prefix, 0) from its list -- no dependent segment-bounds fetch.
-  struct Item {
-    int seg, h, qb, tok0, P, T, kvh, vtok0, prompt, kb_last, wave_q_last;
-    const u16 *kbase, *vbase, *pkbase, *pvbase;
-    int qabs[2];
-  };
-  const int32_t* my_items = LISTED ? items + (size_t)blockIdx.x * list_stride : nullptr;
-  const int n_items = LISTED ? __builtin_amdgcn_readfirstlane(my_items[0]) : 1;
-  if (n_items <= 0) return;
-  // false: the tile holds no query row of its segment (never listed by the host)
-  auto make_item = [&](int it, Item& I) -> bool {
-    int seg, h, qb, tok0 = 0, T = 0;
-    if (LISTED) {
-      typedef int int4v __attribute__((ext_vector_type(4)));
-      const int4v w = *reinterpret_cast<const int4v*>(my_items + 4 * (it + 1));
-      seg = __builtin_amdgcn_readfirstlane(w[0] >> 16);
-      h = __builtin_amdgcn_readfirstlane((w[0] >> 8) & 255);
-      qb = __builtin_amdgcn_readfirstlane(w[0] & 255);
-      tok0 = __builtin_amdgcn_readfirstlane(w[1]);
-      T = __builtin_amdgcn_readfirstlane(w[2]);
-    } else if (LASTQ) {
-      const int id = blockIdx.x, stream = id & 7, pl = id >> 3;
-      const int pair = pl * 8 + stream;
-      if (pair >= n_pairs) return false;
-      seg = __builtin_amdgcn_readfirstlane(pair / nh);
-      h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
-      if (prefix_len > 0 && seg == 0) return false;   // segment 0 is the shared prefix, not a prompt
-      qb = 0;                                          // set below, once T is known
-    } else {
-      const int id = blockIdx.x, stream = id & 7, j = id >> 3;
-      const int ppx = (n_pairs + 7) >> 3;                  // pairs per stream
-      const int n_light = min(max_qblocks, 2), n_heavy = max_qblocks - n_light;
-      int pl;
-      if (j < ppx * n_heavy) {
-        pl = j / n_heavy;
-        qb = max_qblocks - 1 - j % n_heavy;
-      } else {
-        const int j2 = j - ppx * n_heavy;
-        pl = j2 / n_light;
-        qb = n_light - 1 - j2 % n_light;
-      }
-      const int pair = pl * 8 + stream;
-      if (pair >= n_pairs) return false;
-      // the integer divisions above run on the vector ALU (there is no scalar divide): hand the wave-uniform results
-      // back to scalar registers, or every buffer descriptor built from them is wrapped in a waterfall loop
-      seg = __builtin_amdgcn_readfirstlane(pair / nh);
-      h = __builtin_amdgcn_readfirstlane(pair - seg * nh);
-      qb = __builtin_amdgcn_readfirstlane(qb);
-    }
-    const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;  // keys [0, P) live in segment 0's rows [0, P)
-    if (!LISTED) {
-      tok0 = cu[seg];
-      T = P + cu[seg + 1] - tok0;                                // sequence length, prefix included
-    }
-    if (LASTQ) qb = (T - 1) / FA_QROWS;
-    if (qb * FA_QROWS >= T || (qb + 1) * FA_QROWS <= P) return false;  // no query row of this segment in the tile
-    I.seg = seg;
-    I.h = h;
-    I.qb = qb;
-    I.tok0 = tok0;
-    I.P = P;
-    I.T = T;
-    I.kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
-    const int koff0 = LASTQ ? I.kvh * hd : (nh + I.kvh) * hd, voff0 = koff0 + nkv * hd;
-    I.vtok0 = tok0 - P;  // the row of position p >= P is vtok0 + p (tok0 >= P: segment 0 precedes it)
-    I.kbase = qkv + (size_t)I.vtok0 * stride + koff0;
-    I.vbase = qkv + (size_t)I.vtok0 * stride + voff0;
-    I.pkbase = qkv + koff0;        // prefix rows start at packed row 0
-    I.pvbase = qkv + voff0;
-    I.prompt = prefix_len > 0 ? seg - 1 : seg;   // LASTQ: row of q_last / out
-    const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);   // (LASTQ: qb is the tile of row T - 1, so this is T - 1)
-    I.kb_last = q_last / FA_KB;
-    I.wave_q_last = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + 31;  // last query row this wave owns
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) I.qabs[qt] = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + qt * 16 + li;
-    return true;
-  };
+  const int koff0 = LASTQ ? kvh * hd : (nh + kvh) * hd, voff0 = koff0 + nkv * hd;
+  const int vtok0 = tok0 - P;  // the row of position p >= P is vtok0 + p (tok0 >= P: segment 0 precedes it)
+  const u16* kbase = qkv + (size_t)vtok0 * stride + koff0;
+  const u16* vbase = qkv + (size_t)vtok0 * stride + voff0;
+  const u16* pkbase = qkv + koff0;        // prefix rows start at packed row 0
+  const u16* pvbase = qkv + voff0;
+  const int prompt = prefix_len > 0 ? seg - 1 : seg;   // LASTQ: row of q_last / out
 
   // ---- Q fragments (B operand of S^T = K Q^T): row q, d = 32*ks + 8*quad + 0..7
   bf16x8 qf[2][4];
-  auto load_q = [&](const Item& I) {
+  int qabs[2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int qr = min(max(I.qabs[qt], I.P), I.T - 1);
-      const u16* qp = LASTQ ? q_rows_last + (size_t)I.prompt * nh * hd + I.h * hd + quad * 8
-                            : qkv + (size_t)(I.vtok0 + qr) * stride + I.h * hd + quad * 8;
+  for (int qt = 0; qt < 2; ++qt) {
+    qabs[qt] = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + qt * 16 + li;
+    const int qr = min(max(qabs[qt], P), T - 1);
+    const u16* qp = LASTQ ? q_rows_last + (size_t)prompt * nh * hd + h * hd + quad * 8
+                          : qkv + (size_t)(vtok0 + qr) * stride + h * hd + quad * 8;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
-    }
-  };
+    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+  }
+
+  floatx4 ot[2][8];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
+  float l_run[2] = {0.f, 0.f};
+
+  const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);   // (LASTQ: qb is the tile of row T - 1, so this is T - 1)
+  const int kb_last = q_last / FA_KB;
+  const int wave_q_last = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + 31;  // last query row this wave owns
+  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
 
   // ---- DMA staging: 16 pieces per tile (4 rows each); wave w moves pieces 4w..4w+3 of K and of V
   const int prow = lane >> 4, ppos = lane & 15;
@@ -367,13 +333,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   // end are range-checked to ZERO by the hardware (those keys are causally masked for every stored query row: P = 0
   // exactly, whatever finite bytes K and V hold -- same bits as fetching a clamped row). Descriptor, LDS base (M0) and
   // block offset are scalar work; the per-lane offsets koff / voff are block-invariant: no vector ALU in the staging.
-  auto stage = [&](const Item& I, int kb, int buf) {
+  auto stage = [&](int kb, int buf) {
     char* base = smem + buf * FA_STAGE_BYTES + wave * 4096;
-    if (kb * FA_KB >= I.P) {
+    if (kb * FA_KB >= P) {
       const size_t blk_off = (size_t)kb * FA_KB * stride * 2;
-      const int records = ((I.T - 1 - kb * FA_KB) * stride + hd) * 2;  // bytes from the block's first K (V) element
-      const fa_int4 rk = fa_make_rsrc(reinterpret_cast<const char*>(I.kbase) + blk_off, records);
-      const fa_int4 rv = fa_make_rsrc(reinterpret_cast<const char*>(I.vbase) + blk_off, records);
+      const int records = ((T - 1 - kb * FA_KB) * stride + hd) * 2;  // bytes from the block's first K (V) element
+      const fa_int4 rk = fa_make_rsrc(reinterpret_cast<const char*>(kbase) + blk_off, records);
+      const fa_int4 rv = fa_make_rsrc(reinterpret_cast<const char*>(vbase) + blk_off, records);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         fa_dma16(rk, base + i * 1024, koff[i]);
@@ -383,11 +349,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 4 + prow;
-        const int key = min(kb * FA_KB + row, I.T - 1);
+        const int key = min(kb * FA_KB + row, T - 1);
         const int kchunk = ppos ^ (row & 15);
         const int vchunk = ppos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        const u16* kr = key < I.P ? I.pkbase : I.kbase;
-        const u16* vr = key < I.P ? I.pvbase : I.vbase;
+        const u16* kr = key < P ? pkbase : kbase;
+        const u16* vr = key < P ? pvbase : vbase;
         fa_glds16(kr + (size_t)key * stride + kchunk * 8, base + i * 1024);
         fa_glds16(vr + (size_t)key * stride + vchunk * 8, base + FA_TILE_BYTES + i * 1024);
       }
@@ -408,21 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
     for (int dt = 0; dt < 8; ++dt) vb_off[dt] = lds + (v_off(quad * 4 + qp, dt * 2 + (p4 >> 1)) + 8 * (p4 & 1));   // + 8192 ks2 + 4096 half
   }
 
-  Item cur;
-  if (!make_item(0, cur)) return;
-  load_q(cur);
-  stage(cur, 0, 0);
-  for (int it = 0; it < n_items; ++it) {
-  const int P = cur.P, T = cur.T, qb = cur.qb, kb_last = cur.kb_last, wave_q_last = cur.wave_q_last;
-  const int qabs[2] = {cur.qabs[0], cur.qabs[1]};
-  floatx4 ot[2][8];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
-  float l_run[2] = {0.f, 0.f};
-
+  stage(0, 0);
   // Q must be resident before the loop: otherwise hipcc carries its pending-load state into the loop
   // and waits for the in-loop DMA prefetch (vmcnt is in-order) in front of the first MFMAs.
 #pragma unroll
@@ -433,10 +385,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   __syncthreads();
   FA_STAMP(0)  // prologue: Q fragments + first K/V tile landed
   FA_RT(rt_pro)
+
   auto block = [&](const int kb, auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int KS = BUF * FA_STAGE_BYTES, VS = KS + FA_TILE_BYTES;   // LDS byte offsets of this block's K and V tiles
-    if (kb < kb_last) stage(cur, kb + 1, BUF ^ 1);
+    if (kb < kb_last) stage(kb + 1, BUF ^ 1);
     FA_STAMP(1)  // DMA issue
 
     if (kb * FA_KB <= wave_q_last && wave_q_last >= P && (!LASTQ || wave == 0)) {  // otherwise every key of the block is masked for this wave
@@ -555,17 +508,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   }
 
   FA_RT(rt_loop)
-  // ---- LISTED: the next item's Q rows and first K/V block are requested BEFORE this item's output leaves (every wave is
-  // past the last block's barrier, so stage 0 is free and the Q registers are dead): the item's prologue is then one
-  // latency that runs beside the epilogue instead of three dependent ones in front of the next loop.
-  const int vtok0 = cur.vtok0, h = cur.h, prompt = cur.prompt;
-  Item nxt = cur;
-  const bool more = LISTED && it + 1 < n_items;
-  if (more) {
-    make_item(it + 1, nxt);
-    load_q(nxt);
-    stage(nxt, 0, 0);
-  }
   // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -614,8 +556,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       w[0] = rt_entry; w[1] = rt_pro; w[2] = rt_loop; w[3] = rt_exit; w[4] = hw; w[5] = xcc; w[6] = kb_last + 1; w[7] = wg;
     }
   }
-  cur = nxt;
-  }   // items of this workgroup
 }
 
 
@@ -645,174 +585,6 @@ int lr_launch_attention_rows(const u16* qkv, u16* out, const int32_t* cu, int B,
 }
 
 // =============================================================================================
-// Variant 4: item lists. The host knows every segment's length, hence every tile's key-block count; it deals the
-// (segment, head, tile) items to 2 workgroups per CU so that (i) a (segment, head) pair's tiles all run on one XCD
-// (workgroup b is observed on XCD b & 7; speed only) and close in time (its K/V rows are re-read from that L2), (ii) every
-// workgroup gets the same number of key blocks + FA_ITEM_FIXED per item to within one light tile: the pairs go to the
-// least-loaded XCD in order of decreasing length, inside an XCD the heavy tiles pair after pair to the least-loaded
-// workgroup, then the two lightest tiles of every pair, heaviest first, fill the ends (what the one-tile launch leaves to
-// the hardware dispatcher's first-free-slot order). The lists depend on the segment lengths only: they are built once per
-// batch (the 32 layers' calls find them cached) and uploaded from pinned memory on the caller's stream.
-#define FA_ITEM_FIXED 2    // a tile's prologue + epilogue in key blocks (3.2 + 1.4 us against 2.2 us per block)
-#define FA_LIST_SLOTS 4
-struct FaListCache {
-  std::mutex mu;
-  hipStream_t st = nullptr;
-  int B = -1, nh = 0, prefix = 0, n_wg = 0, stride = 0, cur = -1;
-  std::vector<int32_t> key;
-  int32_t* d_list[FA_LIST_SLOTS] = {};
-  int32_t* h_list[FA_LIST_SLOTS] = {};
-  size_t cap[FA_LIST_SLOTS] = {};
-  hipEvent_t ev[FA_LIST_SLOTS] = {};
-};
-static FaListCache g_fa_lists[LR_MAX_DEVICES];
-
-// lists[w] = items of workgroup w (global index: XCD x = w & 7, w >> 3 inside it), 4 ints each: seg << 16 | head << 8 | tile,
-// the segment's first packed row, its length with the prefix, 0. False: a field does not fit its bits.
-static bool fa_build_lists(const int32_t* cu_host, int B, int nh, int prefix_len, int n_wg,
-                           std::vector<std::vector<int32_t>>& lists) {
-  const int wpx = n_wg / 8;
-  lists.assign((size_t)n_wg, {});
-  if (B > 32767 || nh > 256) return false;
-  struct Seg { int seg, T, qb0, qb1, tok0; };
-  std::vector<Seg> segs;
-  for (int b = (prefix_len > 0 ? 1 : 0); b < B; ++b) {
-    const int P = prefix_len > 0 ? prefix_len : 0;
-    const int T = P + cu_host[b + 1] - cu_host[b];
-    if (T <= P) continue;
-    const int qb0 = P / FA_QROWS, qb1 = (T + FA_QROWS - 1) / FA_QROWS;   // tiles wholly inside the prefix hold no row of the segment
-    if (qb1 > 256) return false;
-    segs.push_back({b, T, qb0, qb1, cu_host[b]});
-  }
-  if (prefix_len > 0 && cu_host[1] - cu_host[0] > 0) {   // segment 0 = the prefix rows themselves
-    const int T = cu_host[1] - cu_host[0];
-    segs.push_back({0, T, 0, (T + FA_QROWS - 1) / FA_QROWS, cu_host[0]});
-  }
-  std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.T > b.T; });
-  auto cost = [](const Seg& s, int qb) { return min(qb * FA_QROWS + FA_QROWS - 1, s.T - 1) / FA_KB + 1 + FA_ITEM_FIXED; };
-  long long xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  struct Pair { int s, h; };
-  std::vector<Pair> xp[8];
-  for (size_t si = 0; si < segs.size(); ++si) {
-    long long c = 0;
-    for (int qb = segs[si].qb0; qb < segs[si].qb1; ++qb) c += cost(segs[si], qb);
-    for (int h = 0; h < nh; ++h) {
-      int x = 0;
-      for (int k = 1; k < 8; ++k)
-        if (xload[k] < xload[x]) x = k;
-      xload[x] += c;
-      xp[x].push_back({(int)si, h});
-    }
-  }
-  // a pair's tiles go out in causal couples (heaviest + lightest, ...: 2 n + 2 key blocks whichever couple), a couple to ONE
-  // workgroup: its second tile re-reads K/V rows the first has just pulled through the XCD's L2
-  struct Group { int c, n; int32_t item[2], tok0, T; };
-  const char* mode_env = getenv("LR_ATTN_LIST_MODE");
-  const int mode = mode_env ? atoi(mode_env) : 0;   // 0 couples (default), 1 single tiles: heavy ones pair after pair, then the light ones
-  for (int x = 0; x < 8; ++x) {
-    std::vector<long long> load((size_t)wpx, 0);
-    auto give = [&](const Group& g) {
-      int w = 0;
-      for (int k = 1; k < wpx; ++k)
-        if (load[k] < load[w]) w = k;
-      load[w] += g.c;
-      std::vector<int32_t>& l = lists[(size_t)w * 8 + x];
-      for (int i = 0; i < g.n; ++i) l.insert(l.end(), {g.item[i], g.tok0, g.T, 0});
-    };
-    std::vector<Group> later;
-    for (const Pair& pr : xp[x]) {
-      const Seg& sg = segs[pr.s];
-      auto item = [&](int qb) { return (int32_t)((sg.seg << 16) | (pr.h << 8) | qb); };
-      if (mode == 1) {
-        for (int qb = sg.qb1 - 1; qb >= sg.qb0; --qb) {
-          const Group g = {cost(sg, qb), 1, {item(qb), 0}, sg.tok0, sg.T};
-          if (qb >= sg.qb0 + 2) give(g);
-          else later.push_back(g);
-        }
-      } else {
-        for (int hi = sg.qb1 - 1, lo = sg.qb0; hi >= lo; --hi, ++lo) {
-          if (hi > lo) give({cost(sg, hi) + cost(sg, lo), 2, {item(hi), item(lo)}, sg.tok0, sg.T});
-          else later.push_back({cost(sg, hi), 1, {item(hi), 0}, sg.tok0, sg.T});   // the middle tile of an odd count
-        }
-      }
-    }
-    std::stable_sort(later.begin(), later.end(), [](const Group& a, const Group& b) { return a.c > b.c; });
-    for (const Group& g : later) give(g);
-  }
-  return true;
-}
-
-// device copy of the lists for (cu_host, B, nh, prefix_len) on this device and stream; *stride_out ints per workgroup
-static int fa_get_lists(const int32_t* cu_host, int B, int nh, int prefix_len, hipStream_t st, const int32_t** d_out,
-                        int* n_wg_out, int* stride_out, bool* ok) {
-  int dev = 0;
-  LR_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= LR_MAX_DEVICES) LR_FAIL(LR_EUNSUPPORTED, "attention: device %d", dev);
-  FaListCache& c = g_fa_lists[dev];
-  std::lock_guard<std::mutex> lock(c.mu);
-  *ok = true;
-  const bool hit = c.cur >= 0 && c.st == st && c.B == B && c.nh == nh && c.prefix == prefix_len &&
-                   std::equal(c.key.begin(), c.key.end(), cu_host);
-  if (!hit) {
-    if (c.n_wg == 0) {
-      int cus = 0;
-      LR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      c.n_wg = max(8, 2 * cus / 8 * 8);
-    }
-    std::vector<std::vector<int32_t>> lists;
-    if (!fa_build_lists(cu_host, B, nh, prefix_len, c.n_wg, lists)) {
-      *ok = false;
-      return LR_OK;
-    }
-    size_t longest = 0;
-    for (const auto& l : lists) longest = std::max(longest, l.size());
-    const int stride = (int)longest + 4;   // [count, 0, 0, 0] then 4 ints per item
-    const size_t ints = (size_t)c.n_wg * stride;
-    const int slot = (c.cur + 1) % FA_LIST_SLOTS;
-    if (c.ev[slot]) LR_CHECK_HIP(hipEventSynchronize(c.ev[slot]));   // the last launch that read this slot has finished
-    else LR_CHECK_HIP(hipEventCreateWithFlags(&c.ev[slot], hipEventDisableTiming));
-    if (c.cap[slot] < ints) {
-      if (c.d_list[slot]) LR_CHECK_HIP(hipFree(c.d_list[slot]));
-      if (c.h_list[slot]) LR_CHECK_HIP(hipHostFree(c.h_list[slot]));
-      c.d_list[slot] = nullptr;
-      c.h_list[slot] = nullptr;
-      c.cap[slot] = 0;
-      const size_t want = ints + ints / 2;
-      LR_CHECK_HIP(hipMalloc((void**)&c.d_list[slot], want * sizeof(int32_t)));
-      LR_CHECK_HIP(hipHostMalloc((void**)&c.h_list[slot], want * sizeof(int32_t), hipHostMallocDefault));
-      c.cap[slot] = want;
-    }
-    int32_t* hl = c.h_list[slot];
-    for (int w = 0; w < c.n_wg; ++w) {
-      int32_t* row = hl + (size_t)w * stride;
-      row[0] = (int32_t)(lists[w].size() / 4);
-      row[1] = row[2] = row[3] = 0;
-      std::copy(lists[w].begin(), lists[w].end(), row + 4);
-    }
-    LR_CHECK_HIP(hipMemcpyAsync(c.d_list[slot], hl, ints * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    c.cur = slot;
-    c.st = st;
-    c.B = B;
-    c.nh = nh;
-    c.prefix = prefix_len;
-    c.stride = stride;
-    c.key.assign(cu_host, cu_host + B + 1);
-  }
-  *d_out = c.d_list[c.cur];
-  *n_wg_out = c.n_wg;
-  *stride_out = c.stride;
-  return LR_OK;
-}
-static int fa_lists_used(hipStream_t st) {   // after a launch that reads the current slot
-  int dev = 0;
-  LR_CHECK_HIP(hipGetDevice(&dev));
-  FaListCache& c = g_fa_lists[dev];
-  std::lock_guard<std::mutex> lock(c.mu);
-  if (c.cur >= 0) LR_CHECK_HIP(hipEventRecord(c.ev[c.cur], st));
-  return LR_OK;
-}
-
-// =============================================================================================
 // cu / cu_host: segment starts [S + 1] in packed rows. prefix_len = P > 0: segment 0 is the shared prefix (P rows)
 // and segments 1.. continue it (see the kernel); only the MFMA kernel implements that.
 int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32_t* cu_host,
@@ -824,13 +596,6 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
   if (n_tok <= 0 || B <= 0) return LR_OK;
   if (nh % nkv != 0) LR_FAIL(LR_EINVAL, "attention: num_heads %d not a multiple of num_kv_heads %d", nh, nkv);
   if (variant == 0) variant = (hd == 128) ? 2 : 1;
-  bool listed = false;
-  if (variant == 4) {   // the MFMA kernel over host-made item lists; a stream under capture takes the one-tile launch
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    LR_CHECK_HIP(hipStreamIsCapturing(st, &cap));
-    listed = cap == hipStreamCaptureStatusNone;
-    variant = 2;
-  }
   if (prefix_len < 0 || (prefix_len > 0 && (variant != 2 || cu_host[1] - cu_host[0] != prefix_len)))
     LR_FAIL(LR_EINVAL, "attention: shared prefix of %d tokens needs the head_dim-128 MFMA kernel and segment 0 = the prefix",
             prefix_len);
@@ -856,22 +621,6 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
     static bool lds_set[LR_MAX_DEVICES] = {};
     if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<false>), 2 * FA_STAGE_BYTES, lds_set))
       return rc;
-    if (listed) {
-      const int32_t* d_items = nullptr;
-      int n_wg = 0, stride = 0;
-      bool ok = false;
-      if (int rc = fa_get_lists(cu_host, B, nh, prefix_len, st, &d_items, &n_wg, &stride, &ok)) return rc;
-      if (ok) {
-        static bool lds_set_l[LR_MAX_DEVICES] = {};
-        if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma128_kernel<false, false, true>),
-                                           2 * FA_STAGE_BYTES, lds_set_l))
-          return rc;
-        hipLaunchKernelGGL((attn_mfma128_kernel<false, false, true>), dim3((unsigned)n_wg), dim3(256), 2 * FA_STAGE_BYTES, st,
-                           qkv, out, cu, prefix_len, nh, nkv, mq, n_pairs, lse, (const u16*)nullptr, d_items, stride);
-        LR_CHECK_LAUNCH("attn_mfma128_kernel<listed>");
-        return fa_lists_used(st);
-      }
-    }
 #ifdef LR_EXPERIMENTS
     static bool lds_set_stamp[LR_MAX_DEVICES] = {};
     const char* stamp_env = getenv("LR_ATTN_STAMPS");
@@ -895,7 +644,7 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
                        n_tok, nh, nkv, hd, (const int32_t*)nullptr, lse);
     LR_CHECK_LAUNCH("attn_generic_kernel");
   } else {
-    LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA, 4 = the same over item lists)", variant);
+    LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA)", variant);
   }
   return LR_OK;
 }

@@ -161,48 +161,6 @@ def test_attention_vs_numpy(nh, nkv, hd, variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nh,nkv", [(4, 4), (8, 2)])
-def test_attention_item_lists_equal_the_one_tile_launch_bit_for_bit(nh, nkv):
-    """Attention variant 4 (llama_attn.hip, fa_build_lists): two workgroups per CU walk host-made lists of (segment, head,
-    tile) items instead of one tile per workgroup. Same tile arithmetic, so the output must equal variant 2's BIT FOR BIT:
-    on ragged batches with fewer items than workgroups and with many more, when the same lengths come again (the
-    cached lists) and when they change between calls (a new upload behind kernels that still read the old one)."""
-    hd = 128
-    batches = [[1, 63, 64, 65, 128, 129, 300, 2, 256, 257, 600],
-               [740] * 3 + [565, 1125, 901, 640, 128, 1, 1000] * 4,
-               [5, 700],
-               [740] * 3 + [565, 1125, 901, 640, 128, 1, 1000] * 4]
-    for i, lens in enumerate(batches):
-        cu = np.concatenate([[0], np.cumsum(lens)])
-        qkv = bf16_round(hash_uniform(nh * 100 + i, (cu[-1], (nh + 2 * nkv) * hd), 1.0))
-        one_tile = attention(qkv, cu, nh, nkv, hd, 2)
-        for _ in range(2):
-            assert np.array_equal(attention(qkv, cu, nh, nkv, hd, 4), one_tile), (i, lens)
-        assert np.isfinite(one_tile).all()
-
-
-@pytest.mark.gpu
-def test_attention_item_lists_in_the_prefill_with_a_shared_prefix():
-    """The same through lr_llama_prefill_verbalize(_prefix): set_variants(attention=4) must give the scores of the default
-    launch bit for bit, shared prefix on and off (the lists then hold the prefix segment's own tiles and skip the tiles
-    that lie wholly inside it)."""
-    from llamarec_amd.llm import LlamaRanker
-
-    cfg = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
-               num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-5, rope_theta=10000.0)
-    sd = synth_llama_state(cfg, 11)
-    model = LlamaRanker.from_state_dict(sd, cfg)
-    label_ids = list(range(40, 60))
-    for P in (1, 36, 128, 130, 300):
-        seqs = _prefixed_prompts(P, [1, 5, 100, 300, 64, 27, 500], 320, P)
-        for share in (True, False):
-            want = model.set_variants(0, 0).prefill_verbalize(seqs, label_ids, share_prefix=share)
-            got = model.set_variants(0, 4).prefill_verbalize(seqs, label_ids, share_prefix=share)
-            assert torch.isfinite(want).all() and torch.equal(got, want), (P, share)
-    model.set_variants(0, 0)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(460, 4096, 4096), (23, 4096, 11008), (700, 4096, 4096), (300, 512, 2048)])
 def test_split_k_reduce_with_fused_rmsnorm_is_bit_identical(M, N, K):
     """Latency mode: the reduce pass of a split-K o_proj / down_proj can also write the RMSNorm that reads its result
