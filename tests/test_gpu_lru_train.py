@@ -197,7 +197,9 @@ def test_row_panel_and_generic_block_kernels_agree(golden_dir, B, L):
         engines.append(e)
     for pass_no in range(2):
         losses = [float(e.loss_and_grads(tok, lab)) for e in engines]
-        assert abs(losses[0] - losses[1]) < 2e-5, (pass_no, losses)
+        # the mean of up to 68 000 row terms, summed in fp32 by atomics in an order that differs between the two forms AND between
+        # runs: 4e-6 relative has been observed at 68 000 rows (loss 4.81), so the bound is relative, not 2e-5 absolute
+        assert abs(losses[0] - losses[1]) < 2e-5 * max(1.0, abs(losses[1])), (pass_no, losses)
         ga, gb = engines[0].grad_dict(), engines[1].grad_dict()
         for n in names:
             assert rel_err(as_pairs(ga[n]), as_pairs(gb[n])) < 5e-5, (pass_no, n, rel_err(as_pairs(ga[n]), as_pairs(gb[n])))
