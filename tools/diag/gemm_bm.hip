@@ -23,7 +23,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define STAGE_BYTES 65536
 #ifndef GB_ABL
-#define GB_ABL 0   // ablations of the LDS-DMA kernel (wrong results, timings only): 1 = the B operand neither streamed nor re-read after the first K tile, 2 = the same for A
+#define GB_ABL 0   // ablations of the LDS-DMA kernel (wrong results, timings only): 1 = the B operand neither streamed nor re-read after the first K tile, 2 = the same for A, 5 = 1 + the B operand fetched by plain loads into registers (what a direct global -> register B path would cost)
 #endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -46,7 +46,11 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
   constexpr int AP = BM / 128;      // A pieces per wave and region (2 / 1)
   constexpr int MQ = BM / 64;       // 16-row blocks per quadrant (4 / 2)
   constexpr int HALF = BM / 2;      // rows of a wave group
-  constexpr int WA = 3 * AP + 4, WB = 6 + 2 * AP;   // "all but my newest n" at phases 0, 2 / 1, 3 (10, 10 for the product's tile)
+  // "all but my newest n" at phases 0, 2 / 1, 3: the vector-memory operations of the last five phases may be outstanding
+  // (A phases issue AP of them, B phases 2; 10, 10 for the product's tile). The ablations keep that set of PHASES:
+  // a dropped operand's phases issue nothing, GB_ABL & 4 issues 4 plain loads in each B phase.
+  constexpr int OPA = (GB_ABL & 2) ? 0 : AP, OPB = (GB_ABL & 4) ? 4 : ((GB_ABL & 1) ? 0 : 2);
+  constexpr int WA = 3 * OPA + 2 * OPB, WB = 3 * OPB + 2 * OPA;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +136,14 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                    \
     acc[(mh)*MQ + mt][(nh)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                         \
         bfrag[ks * 2 + nt], afr[ks * MQ + mt], acc[(mh)*MQ + mt][(nh)*2 + nt], 0, 0, 0);
+  // GB_ABL & 4 (with & 1): what a B operand taken straight from global memory would cost the loop -- per K tile and wave 8
+  // coalesced 1 KB loads (its 64 columns x 64 k, as if the weights were stored in fragment order; both row halves of the
+  // tile read the same bytes), issued where the B regions' DMAs were, into scratch registers that nothing reads.
+  const char* bdir = reinterpret_cast<const char*>(B) + (size_t)n0 * K * 2 + wn * 8192 + lane * 16;
+  floatx4 bscr[4] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};   // "+v" below and the use after the loop keep these registers reserved while loads are in flight
+#define RB_BDIRECT(tile, half)                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                    \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(bscr[i_]) : "v"(bdir + (size_t)(tile)*32768 + ((half)*4 + i_) * 1024) : "memory");
 #define RB_TILE(kt, b0cur, b0nxt)                                                                     \
   {                                                                                                   \
     const char* cur = smem + ((kt)&1) * STAGE_BYTES;                                                   \
@@ -146,6 +158,7 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
     BARRIER();                                                                                        \
     if (!(GB_ABL & 1) || (kt) == 0) { RB_LOAD_B(b1, cur, 1) }                                         \
     if (more2 && !(GB_ABL & 1)) RB_DMA(1, (kt) + 2);                                                  \
+    if (more2 && (GB_ABL & 4)) { RB_BDIRECT((kt) + 2, 0) }                                             \
     if (more2) { WAIT_VM(WB); } else { WAIT_VM(0); }                                                  \
     BARRIER();                                                                                        \
     RB_MFMA(b1, 0, 1)                                                                                 \
@@ -158,6 +171,7 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
     BARRIER();                                                                                        \
     if (more && !(GB_ABL & 1)) { RB_LOAD_B(b0nxt, nxt, 0) }                                           \
     if (more2 && !(GB_ABL & 1)) RB_DMA(2, (kt) + 2);                                                  \
+    if (more2 && (GB_ABL & 4)) { RB_BDIRECT((kt) + 2, 1) }                                             \
     if (more2) { WAIT_VM(WB); } else { WAIT_VM(0); }                                                  \
     BARRIER();                                                                                        \
     RB_MFMA(b0cur, 1, 0)                                                                              \
@@ -185,6 +199,11 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
   for (int kt = 0; kt < nkt; kt += 2) {
     RB_TILE(kt, b0x, b0y)
     if (kt + 1 < nkt) RB_TILE(kt + 1, b0y, b0x)
+  }
+  if (GB_ABL & 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i_ = 0; i_ < 4; ++i_) asm volatile("" ::"v"(bscr[i_]));
   }
   if (wm == 0) BARRIER();
   if (stamps) {
@@ -449,7 +468,14 @@ static void run(int M, int N, int K) {
   hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dS);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'q') {   // "quick": the product's tile on the two batch shapes only (the -DGB_ABL arms)
+    for (int rep = 0; rep < 2; ++rep) {
+      run<256, false>(32768, 4096, 4096);
+      run<256, false>(32768, 4096, 11008);
+    }
+    return 0;
+  }
   // the batch shape (many rounds of tiles): per-K-tile cost of the two tiles at full occupancy, LDS-DMA against register staging
   run<256, false>(32768, 4096, 4096);
   run<256, true>(32768, 4096, 4096);
