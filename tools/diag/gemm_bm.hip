@@ -22,6 +22,9 @@ typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define STAGE_BYTES 65536
+#ifndef GB_SADDR
+#define GB_SADDR 0   // 1: LDS-DMA sources as scalar base + 32-bit lane offset (first kernel only)
+#endif
 #ifndef GB_ABL
 #define GB_ABL 0   // ablations of the LDS-DMA kernel (wrong results, timings only): 1 = the B operand neither streamed nor re-read after the first K tile, 2 = the same for A, 5 = 1 + the B operand fetched by plain loads into registers (what a direct global -> register B path would cost)
 #endif
@@ -29,6 +32,16 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// the same DMA with the source as scalar base + 32-bit lane offset (hipcc does not select this form for the builtin: it adds the
+// uniform part to a per-lane 64-bit pointer on the vector ALU in front of every issue); as inline asm it is invisible to hipcc's
+// vmcnt bookkeeping, which this loop does by hand anyway
+__device__ __forceinline__ void glds16_s(const void* base, unsigned voff, void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const char*)lds_wave_base));
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bs = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(bs) : "memory");
 }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -76,6 +89,7 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
   // row-half 1. A: AP pieces per wave (q = AP wave + j: group q / (8 AP / 2) ..), B: 2 per wave
   const int srow = lane >> 3, spos = lane & 7;
   const char* src[4][2];
+  unsigned soff[4][2];   // GB_SADDR: the same source as a 32-bit lane offset from the tile's (wave-uniform) A / B base
   int ldsoff[4][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -91,19 +105,35 @@ __global__ __launch_bounds__(512) void gemm_bm_kernel(const u16* __restrict__ A,
       const int chunk = spos ^ ((row >> 1) & 7);
       if (isA[t]) {
         src[t][j] = reinterpret_cast<const char*>(A) + ((size_t)(m0 + row) * K) * 2 + chunk * 16;
+        soff[t][j] = (unsigned)(row * K * 2 + chunk * 16);
         ldsoff[t][j] = rows[t] * 128;
       } else {
         src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16;
+        soff[t][j] = (unsigned)(row * K * 2 + chunk * 16);
         ldsoff[t][j] = 32768 + rows[t] * 128;
       }
     }
   }
+  const char* const a_tile = reinterpret_cast<const char*>(A) + (size_t)m0 * K * 2;   // wave-uniform bases (SGPR pairs)
+  const char* const b_tile = reinterpret_cast<const char*>(B) + (size_t)n0 * K * 2;
+#if GB_SADDR
+  // source = uniform base (+ the K tile's 128 bytes, scalar arithmetic) + a 32-bit lane offset: the saddr form of the DMA, no
+  // 64-bit vector adds per issue (the per-lane pointer form costs two v_lshl_add_u64 in front of every global_load_lds)
+#define RB_DMA(reg, tile)                                                                         \
+  do {                                                                                            \
+    char* dst_ = smem + ((tile)&1) * STAGE_BYTES;                                                 \
+    const char* base_ = (((reg) == 1 || (reg) == 2) ? b_tile : a_tile) + (size_t)(tile)*128;      \
+    glds16_s(base_, soff[(reg)][0], dst_ + ldsoff[(reg)][0]);                                     \
+    if (((reg) == 1 || (reg) == 2) || AP == 2) glds16_s(base_, soff[(reg)][1], dst_ + ldsoff[(reg)][1]); \
+  } while (0)
+#else
 #define RB_DMA(reg, tile)                                                                         \
   do {                                                                                            \
     char* dst_ = smem + ((tile)&1) * STAGE_BYTES;                                                 \
     glds16(src[(reg)][0] + (size_t)(tile)*128, dst_ + ldsoff[(reg)][0]);                          \
     if (((reg) == 1 || (reg) == 2) || AP == 2) glds16(src[(reg)][1] + (size_t)(tile)*128, dst_ + ldsoff[(reg)][1]); \
   } while (0)
+#endif
 
   const int frow = lane & 15, fsw = frow >> 1;
   const int fo0 = frow * 128 + (((lane >> 4) ^ fsw) << 4);
