@@ -110,7 +110,7 @@ def test_out_of_range_labels_are_ignored_and_counted(golden_dir):
     loss = float(eng.loss_and_grads(tok2, lab2))
     assert eng.bad_labels == 3 * lab.shape[1]
     # the loss sum is accumulated with fp32 atomics: the extra rows change their order, not the terms
-    assert abs(loss - ref) < 1e-5 and torch.allclose(eng.grads, g_ref, rtol=1e-4, atol=1e-7)
+    assert abs(loss - ref) < 1e-5 and torch.allclose(eng.grads, g_ref, rtol=2e-4, atol=1e-6)   # a row that leaked would add ~1e-3
 
 
 def test_graph_replay_equals_direct_launches(golden_dir):
