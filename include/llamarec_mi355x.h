@@ -215,6 +215,8 @@ void lr_llama_destroy(lr_llama_t* h);
 
 /* Kernel selection: 0 = auto (default), 1 = generic kernels (any shape; the in-library cross-check of the fast
  * ones), attention 2 = head_dim-128 MFMA flash attention (K/V by LDS-DMA, 128 query rows per workgroup),
+ * attention 3 = head_dim-128 flash attention on 256-row tiles, one wave per SIMD, persistent workgroups (what auto picks for
+ * head_dim 128 when the shared prefix is a multiple of 4 and <= 64 tokens; falls back to 2 otherwise),
  * gemm 4 = the ping-pong pipelined 256x256x64 MFMA GEMM (an error if a shape does not fit).
  * gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
  * variant 4 plus split-K wherever the output tiles alone would leave most CUs idle (a 460-token prompt
@@ -346,6 +348,13 @@ int lr_rope_table(float* cs, int32_t max_positions, int32_t head_dim, float thet
 int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int32_t* cu_seqlens,
                         const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads,
                         int32_t num_kv_heads, int32_t head_dim, int32_t variant, void* hip_stream);
+/* The same with a DEVICE workspace of lr_attention_workspace_bytes(total, B, num_heads) bytes, which variant 3 (and
+ * auto, for head_dim 128) needs for its work-item list; lse: optional DEVICE fp32 [total][num_heads] log-sum-exp of
+ * the scaled scores (NULL: not written). */
+size_t lr_attention_workspace_bytes(int32_t total_tokens, int32_t B, int32_t num_heads);
+int lr_attention_varlen_ws(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu_seqlens,
+                           const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads, int32_t num_kv_heads,
+                           int32_t head_dim, int32_t variant, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optional in-library kernel timing (HIP events on the caller's stream). Not part of the

@@ -91,6 +91,9 @@ PROTOTYPES = {
                                      C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_attention_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "lr_attention_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "lr_attention_varlen_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lr_nf4_scratch_bytes": (C.c_size_t, [C.c_size_t]),
     "lr_nf4_roundtrip_bf16": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),

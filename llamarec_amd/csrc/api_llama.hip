@@ -42,8 +42,8 @@ extern "C" int lr_llama_create(const LrLlamaConfig* cfg, const LrLlamaWeightsDes
 
 extern "C" int lr_llama_set_variants(lr_llama_t* h, int32_t gemm_variant, int32_t attention_variant) {
   if (!h || (gemm_variant != 0 && gemm_variant != 1 && gemm_variant != 4 && gemm_variant != 5) || attention_variant < 0 ||
-      attention_variant > 2)
-    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: gemm in {0, 1, 4, 5}, attention in {0, 1, 2}");
+      attention_variant > 3)
+    LR_FAIL(LR_EINVAL, "lr_llama_set_variants: gemm in {0, 1, 4, 5}, attention in {0, 1, 2, 3}");
   h->gemm_variant = gemm_variant;
   h->attn_variant = attention_variant;
   return LR_OK;
@@ -95,6 +95,8 @@ struct LlamaWs {
   float* splitk;                              // fp32 partial planes of the split-K GEMMs (gemm variant 5)
   unsigned* rope16;                           // the rope table as packed bf16 (cos | sin << 16) pairs
   int32_t* prefix_bad;                        // device word: a prompt broke the shared-prefix promise (token_meta_kernel)
+  void* attn_items;                           // work-item list of the 256-row attention kernel (llama_attn256.hip)
+  size_t attn_items_bytes;
   bool compact;                               // ws.x_last (not ws.x) holds the final residual rows
   size_t total;
 };
@@ -131,6 +133,8 @@ static LlamaWs carve(const LrLlamaConfig& c, int max_tokens, int max_seqs, char*
   w.q_last = (u16*)take(nb * (size_t)c.num_heads * c.head_dim * 2);
   w.splitk = (float*)take(LR_SPLITK_WS_BYTES);
   w.prefix_bad = (int32_t*)take(sizeof(int32_t));
+  w.attn_items_bytes = lr_attn256_ws_bytes(max_tokens, (int)nb + 1, c.num_heads);
+  w.attn_items = take(w.attn_items_bytes);
   w.total = o;
   return w;
 }
@@ -165,7 +169,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   if (P < 0 || (P > 0 && P >= minT))
     LR_FAIL(LR_EINVAL, "llama prefill: shared prefix of %d tokens, shortest prompt has %d (every prompt keeps >= 1 own token)",
             P, minT);
-  if (P > 0 && (c.head_dim != 128 || h->attn_variant == 1)) P = 0;  // only the MFMA attention kernel reads a shared prefix
+  if (P > 0 && (c.head_dim != 128 || h->attn_variant == 1)) P = 0;  // only the MFMA attention kernels read a shared prefix
   if (B == 1) P = 0;
   const int n_in = cu_host[B];
   const int n = P > 0 ? n_in - (B - 1) * P : n_in;  // internal rows
@@ -195,6 +199,12 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st, ws.last_pos, ids,
                            ws.prefix_bad));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st, ws.rope16));
+  // attention: 3 = 256-row tiles (auto for head_dim 128 when the prefix allows), its item list built once per call
+  const bool attn256 = (h->attn_variant == 3 || h->attn_variant == 0) && lr_attention256_takes(hd, P);
+  if (h->attn_variant == 3 && !attn256 && hd != 128)
+    LR_FAIL(LR_EUNSUPPORTED, "llama prefill: attention variant 3 needs head_dim 128 (got %d)", hd);
+  const int attn_var = attn256 ? 3 : (h->attn_variant == 3 ? 2 : h->attn_variant);
+  if (attn256) RUN(lr_launch_attn256_items(ws.seg_start, S, n, nh, P, ws.attn_items, ws.attn_items_bytes, st));
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   bool input_normed = false;   // ws.xn already holds RMSNorm(ws.x) with this layer's input_norm
   for (int l = 0; l < c.num_layers; ++l) {
@@ -235,8 +245,11 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       } else if (hd == 128 && h->attn_variant != 1) {
         // the MFMA kernel over ALL rows (188 us for 14.8 k tokens, 16 us for one prompt) beats the scalar kernel over the
         // B last rows (459 / 295 us): attend everything, keep the last rows
-        RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,
-                                h->attn_variant, nullptr, st, P));
+        if (attn256)
+          RUN(lr_launch_attention256(ws.qkv, ws.att, ws.seg_start, seg_host, S, n, nh, nkv, hd, nullptr, ws.attn_items, st, P));
+        else
+          RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,
+                                  attn_var, nullptr, st, P));
         RUN(lr_launch_gather_rows(ws.att, ws.last_rows, B, nh * hd, ws.att_last, st));
       } else {
         RUN(lr_launch_attention_rows(ws.qkv, ws.att_last, cu, B, ws.last_rows, B, nh, nkv, hd, st));
@@ -259,8 +272,11 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
       ws.compact = true;
       break;
     }
-    RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd,
-                            h->attn_variant, nullptr, st, P));
+    if (attn256)
+      RUN(lr_launch_attention256(ws.qkv, ws.att, ws.seg_start, seg_host, S, n, nh, nkv, hd, nullptr, ws.attn_items, st, P));
+    else
+      RUN(lr_launch_attention(ws.qkv, ws.att, ws.seg_start, seg_host, ws.tok_pos, nullptr, S, n, nh, nkv, hd, attn_var,
+                              nullptr, st, P));
     bool post_normed = false;
     RUN(lr_launch_gemm(ws.att, w.wo, ws.x, ws.x, n, d, nh * hd, LR_EPI_RESIDUAL, h->gemm_variant, st, nullptr, nullptr, 0,
                        0, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, nullptr, folded ? nullptr : w.post_norm, ws.xn, c.rms_eps,
@@ -430,4 +446,26 @@ extern "C" int lr_attention_varlen(const uint16_t* qkv, uint16_t* out, const int
   if (!qkv || !out || !cu_seqlens || !cu_seqlens_host || B < 1) LR_FAIL(LR_EINVAL, "lr_attention_varlen: bad argument");
   return lr_launch_attention(qkv, out, cu_seqlens, cu_seqlens_host, nullptr, nullptr, B, cu_seqlens_host[B],
                              num_heads, num_kv_heads, head_dim, variant, nullptr, (hipStream_t)hip_stream);
+}
+
+extern "C" size_t lr_attention_workspace_bytes(int32_t total_tokens, int32_t B, int32_t num_heads) {
+  if (total_tokens < 1 || B < 1 || num_heads < 1) return 0;
+  return lr_attn256_ws_bytes(total_tokens, B, num_heads);
+}
+
+extern "C" int lr_attention_varlen_ws(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu_seqlens,
+                                      const int32_t* cu_seqlens_host, int32_t B, int32_t num_heads, int32_t num_kv_heads,
+                                      int32_t head_dim, int32_t variant, void* workspace, size_t workspace_bytes,
+                                      void* hip_stream) {
+  if (!qkv || !out || !cu_seqlens || !cu_seqlens_host || B < 1) LR_FAIL(LR_EINVAL, "lr_attention_varlen_ws: bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int n = cu_seqlens_host[B];
+  if (variant == 3 || (variant == 0 && head_dim == 128 && workspace)) {
+    if (head_dim != 128) LR_FAIL(LR_EUNSUPPORTED, "lr_attention_varlen_ws: variant 3 needs head_dim 128 (got %d)", head_dim);
+    if (int rc = lr_launch_attn256_items(cu_seqlens, B, n, num_heads, 0, workspace, workspace_bytes, st)) return rc;
+    return lr_launch_attention256(qkv, out, cu_seqlens, cu_seqlens_host, B, n, num_heads, num_kv_heads, head_dim, lse,
+                                  workspace, st, 0);
+  }
+  return lr_launch_attention(qkv, out, cu_seqlens, cu_seqlens_host, nullptr, nullptr, B, n, num_heads, num_kv_heads, head_dim,
+                             variant, lse, st);
 }

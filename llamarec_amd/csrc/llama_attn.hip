@@ -644,7 +644,8 @@ int lr_launch_attention(const u16* qkv, u16* out, const int32_t* cu, const int32
                        n_tok, nh, nkv, hd, (const int32_t*)nullptr, lse);
     LR_CHECK_LAUNCH("attn_generic_kernel");
   } else {
-    LR_FAIL(LR_EINVAL, "attention: unknown variant %d (0 auto, 1 generic, 2 = head_dim-128 MFMA)", variant);
+    LR_FAIL(LR_EINVAL, "attention: unknown variant %d here (0 auto, 1 generic, 2 = head_dim-128 MFMA; 3 needs a workspace: "
+            "lr_attention_varlen_ws)", variant);
   }
   return LR_OK;
 }

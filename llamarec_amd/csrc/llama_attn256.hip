@@ -1,0 +1,529 @@
+// llama_attn256.hip -- varlen causal self-attention, head_dim 128, on the one-wave-per-SIMD structure
+// (cdna_hip_programming.md, "Fused attention prefill", 4-wave persistent form): attention variant 3.
+//
+// Replaces flash-attn 2.5.8's varlen forward (train_ranker.py:61) inside the patched LlamaForCausalLM.forward
+// (model/llm.py:89-100) like attn_mfma128_kernel (llama_attn.hip) does; this kernel is the one the prefill runs.
+//
+//  * A workgroup = 4 wave64 = ONE wave per SIMD with the whole 512-register file: a 256-row query tile of one
+//    (segment, head), 64 rows per wave as two 32-row halves. 256 persistent workgroups take tiles from per-XCD ticket
+//    counters over a device-built item list (attn256_items_kernel): the tiles of one (segment, head) follow each other on
+//    ONE XCD, so that their K/V blocks meet in that XCD's L2; heavy tiles first, every pair's lightest tile last.
+//  * Query tiles are anchored at the END of a sequence (tile k = rows [T - 256 (k+1), T - 256 k)): the one partial tile
+//    is the cheapest (first rows, fewest keys). Key blocks stay at absolute multiples of 64, and every per-row operation
+//    (S^T column, row maximum, P column, O^T column) is independent of the other rows of a tile, so a row's bits depend
+//    on its own keys only -- not on the tiling, the batch, or whether the shared prefix is stored once (segment 0).
+//  * v_mfma_f32_32x32x16_bf16 for both products, everything transposed: S^T = K Q^T puts a query row on a lane
+//    (l & 31) with 16 of a tile's 32 keys in its registers; those accumulators, packed pairwise to bf16, ARE the B operand
+//    of O^T += V^T P^T in the k order "16 s + 8 (j >> 2) + 4 (l >> 5) + (j & 3)" (guide section 3, "An accumulator tile as the
+//    next MFMA's operand"), and the V^T fragments are read with ds_read_b64_tr_b16 in that same order: no cross-lane
+//    movement except one v_permlane32_swap per row maximum.
+//  * O (128 registers), the Q fragments (64) and the K fragments of the current block (64) live in a[0:255], named
+//    literally in the asm statements -- hipcc, given "a" operands, shuttles them through VGPRs around every block. The
+//    softmax state, the V^T fragments and P are ordinary C++ values in the 256 arch VGPRs.
+//  * The instruction stream of a key block is GENERATED (tools/gen_attn256.py -> llama_attn256_body.inc): 64 MFMAs, every
+//    other instruction assigned to one of the 64 gaps. The two halves run half a block apart -- QK(A) | PV(B, previous
+//    block) | QK(B) | PV(A) -- so one half's softmax always has the other half's MFMAs to hide behind.
+//  * Deferred maximum (guide T13): a row's reference maximum m moves only when the block's maximum exceeds it by more than
+//    2^8; P <= 2^8 otherwise. The decision is per ROW (alpha = 1 exactly for the rows that keep m), so it does not couple rows.
+//  * K/V blocks arrive by LDS-DMA, K two blocks ahead, V one, into a ring of two slots each; one barrier per block.
+//    Q arrives by LDS-DMA into the wave's own 16 KiB, which the epilogue reuses to turn O^T into whole 256-byte rows.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "llama_kernels.h"
+#include "lr_profile.h"
+
+typedef unsigned short u16;
+typedef float a2_f16v __attribute__((ext_vector_type(16)));
+typedef int a2_int4 __attribute__((ext_vector_type(4)));
+typedef long long a2_i64x2 __attribute__((ext_vector_type(2)));
+typedef short a2_short4 __attribute__((ext_vector_type(4)));
+typedef unsigned a2_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned a2_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char a2_lds;
+
+#define A2_ROWS 256
+#define A2_KB 64
+#define A2_RING_BYTES 65536               // 2 slots x (K 16 KiB | V 16 KiB)
+#define A2_QBUF 65536                     // 4 waves x 16 KiB
+#define A2_CTRL (A2_QBUF + 65536)         // ticket word
+#define A2_LDS_BYTES (A2_CTRL + 64)
+#define A2_THR 8.0f                       // deferred maximum: log2 units
+
+// ---- item list: header int32[16] = {len[8], cap, ...}, counters int32[16] = {ticket[8], done}, items int2[8][cap]
+#define A2_HDR_INTS 16
+#define A2_CTR_INTS 16
+
+size_t lr_attn256_ws_bytes(int n_tok, int S, int nh) {
+  const size_t tiles = (size_t)n_tok / A2_ROWS + (size_t)S + 1;
+  const size_t cap = (size_t)((nh + 7) / 8) * tiles;
+  return (A2_HDR_INTS + A2_CTR_INTS) * 4 + 8 * cap * 8;
+}
+
+// One workgroup. Segment s (T rows incl. the shared prefix, live rows >= P) has nt = ceil((T - P) / 256) tiles counted from
+// the END; tiles 0 .. nt-2 are "heavy", tile nt-1 (the first rows) is "light". Stream x (one per XCD) = heads h % 8 == x:
+// heavy section: segments ascending, per segment head after head, per head tile 0, 1, ..; then every pair's light tile.
+__global__ __launch_bounds__(256) void attn256_items_kernel(const int32_t* cu, int S, int prefix_len, int nh, int32_t* ws,
+                                                            int cap) {
+  __shared__ int part[256];
+  __shared__ int total;
+  int32_t* hdr = ws;
+  int32_t* ctr = ws + A2_HDR_INTS;
+  int2* items = reinterpret_cast<int2*>(ws + A2_HDR_INTS + A2_CTR_INTS);
+  const int t = threadIdx.x;
+  const int chunk = (S + 255) / 256;
+  const int s0 = min(S, t * chunk), s1 = min(S, s0 + chunk);
+  auto ntiles = [&](int s) {
+    const int P = (prefix_len > 0 && s > 0) ? prefix_len : 0;
+    const int T = P + cu[s + 1] - cu[s];
+    return (T - P + A2_ROWS - 1) / A2_ROWS;
+  };
+  int mine = 0;
+  for (int s = s0; s < s1; ++s) mine += ntiles(s) - 1;
+  part[t] = mine;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    total = run;
+  }
+  __syncthreads();
+  const int htot = total;
+  int hpre = part[t];
+  for (int s = s0; s < s1; ++s) {
+    const int nt = ntiles(s), heavy = nt - 1;
+    for (int h = 0; h < nh; ++h) {
+      const int x = h & 7, hl = h >> 3, nhx = (nh - x + 7) >> 3;
+      int2* st = items + (size_t)x * cap;
+      for (int k = 0; k < heavy; ++k) st[hpre * nhx + hl * heavy + k] = make_int2(s, (h << 16) | k);
+      st[htot * nhx + s * nhx + hl] = make_int2(s, (h << 16) | (nt - 1));
+    }
+    hpre += heavy;
+  }
+  if (t < 8) {
+    const int nhx = (nh - t + 7) >> 3;
+    hdr[t] = nhx > 0 ? nhx * (htot + S) : 0;
+    ctr[t] = 0;
+  }
+  if (t == 8) {
+    hdr[8] = cap;
+    ctr[8] = 0;
+  }
+}
+
+int lr_launch_attn256_items(const int32_t* cu, int S, int n_tok, int nh, int prefix_len, void* ws, size_t ws_bytes,
+                            hipStream_t st) {
+  const size_t need = lr_attn256_ws_bytes(n_tok, S, nh);
+  if (!ws || ws_bytes < need)
+    LR_FAIL(LR_EWORKSPACE, "attention (256-row tiles): item list needs %zu bytes, have %zu", need, ws_bytes);
+  const int cap = (int)(((size_t)n_tok / A2_ROWS + (size_t)S + 1) * ((nh + 7) / 8));
+  hipLaunchKernelGGL(attn256_items_kernel, dim3(1), dim3(256), 0, st, cu, S, prefix_len, nh, (int32_t*)ws, cap);
+  LR_CHECK_LAUNCH("attn256_items_kernel");
+  return LR_OK;
+}
+
+// Every asm statement of the kernel names the WHOLE accumulator file as clobbered. a[0:255] hold O, Q and K across
+// statements without hipcc knowing; given the chance it parks values of its own there (v_accvgpr_write / _read around a
+// region of high pressure -- seen in the first build of this file: Q fragments overwritten). With the clobber on every
+// statement no value of the compiler's can sit in an accumulator register across any of them; tests/test_isa_checks.py
+// asserts that the built kernel holds no v_accvgpr_* outside the asm statements and no scratch access.
+#define A2_ALLA \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+  "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+  "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+  "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+  "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+  "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+  "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+  "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+  "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+  "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+  "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+  "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+  "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+  "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+  "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+  "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
+// ---- helpers ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float a2_max3(float a, float b, float c) {   // raw MFMA outputs: no canonicalising v_max x, x
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float a2_max2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void a2_swap32(float v, float& a, float& b) {   // both lane halves' values to every lane
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ a2_int4 a2_make_rsrc(const void* base, int num_records) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  a2_int4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));   // stride 0
+  r[2] = __builtin_amdgcn_readfirstlane(num_records);
+  r[3] = 0x00020000;
+  return r;
+}
+// LDS-DMA as inline asm (hipcc must not count it: see llama_attn.hip); M0 is written in the statement that reads it
+__device__ __forceinline__ void a2_dma16(a2_int4 rsrc, unsigned lds_dst, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rsrc)
+               : "memory", A2_ALLA);
+}
+__device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {   // scalar base + per-lane offset
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", A2_ALLA);
+}
+__device__ __forceinline__ int a2_vswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+#define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
+
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict__ qkv, u16* out, const int32_t* cu,
+                                                           int prefix_len, int nh, int nkv, const int32_t* ws_ro,
+                                                           int32_t* ctr, float* lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int hd = 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int stride = (nh + 2 * nkv) * hd;
+  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+  const unsigned lds0 = (unsigned)(size_t)(a2_lds*)smem;
+  const int2* items = reinterpret_cast<const int2*>(ws_ro + A2_HDR_INTS + A2_CTR_INTS);
+
+  // ---- lane constants of the fragment reads
+  unsigned kaddr[8];                // K / Q row reads: row (l & 31) of a 32-row tile, 16-byte chunk (2 ks + hi) ^ (row & 15)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = lds0 + r * 256 + (((2 * ks + hi) ^ (r & 15)) << 4);
+  const unsigned qoff = A2_QBUF + wave * 16384;   // the wave's own Q / O rows
+  unsigned vb[4][2];                // V^T reads (ds_read_b64_tr_b16): fragment (dt, s), half jj: + 4096 s + slot base
+  {
+    const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        vb[dt][jj] = lds0 + 256 * (8 * jj + 4 * hi + q) +
+                     16 * ((4 * dt + 2 * g1 + (p >> 1)) ^ ((q << 2) | (2 * jj + hi))) + 8 * (p & 1);
+  }
+  // ---- lane constants of the K/V staging: wave w moves pieces 4w .. 4w+3 (4 rows of 256 B each) of a block's K and V
+  const int prow = lane >> 4, ppos = lane & 15;
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 4 + prow;
+    koff[i] = (unsigned)(row * stride + (ppos ^ (row & 15)) * 8) * 2u;
+    voff[i] = (unsigned)(row * stride + nkv * hd + (ppos ^ a2_vswz(row)) * 8) * 2u;   // V sits nkv * hd columns behind K
+  }
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7;
+
+  // ---- softmax state (kernel scope: the stream of a block reaches into the next one)
+  a2_f16v S[2][2];
+  a2_int4 Pf[2][4];
+  a2_i64x2 Vf[4][4];
+  float t_[2][32], p_[2][32];
+  float m_run[2], l_run[2], lsum[2], negm[2], alpha[2], mx0[2], mx1[2], rowmx[2];
+  unsigned long long need[2];      // lanes whose row's reference maximum moves in this block
+  int thr[2];
+  const float ninf = -__builtin_inff();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    lsum[h] = negm[h] = alpha[h] = mx0[h] = mx1[h] = rowmx[h] = 0.f;
+    need[h] = 0;
+    thr[h] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Pf[h][i] = a2_int4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t_[h][i] = p_[h][i] = 0.f;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Vf[dt][s] = a2_i64x2{0, 0};
+
+  for (;;) {
+    // ================================================================ ticket -> tile
+    if (tid == 0) {
+      int item = -1;
+      const int cap = ws_ro[8];
+      for (int a = 0, s = (int)xcc; a < 8; ++a, s = (s + 1) & 7) {   // own stream first, then the neighbours' leftovers
+        const int len = ws_ro[s];
+        if (len <= 0) continue;
+        const int j = atomicAdd(&ctr[s], 1);
+        if (j < len) {
+          item = s * cap + j;
+          break;
+        }
+      }
+      *reinterpret_cast<volatile int*>(smem + A2_CTRL) = item;
+    }
+    __syncthreads();   // also: every wave is done with the previous tile's ring slots
+    const int item = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + A2_CTRL));
+    if (item < 0) break;
+    // an opaque zero, new for every tile: lane arithmetic of the prologue and the epilogue that hipcc would otherwise hoist
+    // out of the tile loop (it is loop-invariant) and keep in ~100 registers across the key-block loop -- or spill
+    int z_;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z_));
+    const int2 it = items[item];
+    const int seg = __builtin_amdgcn_readfirstlane(it.x);
+    const int h = __builtin_amdgcn_readfirstlane(it.y >> 16), tk = __builtin_amdgcn_readfirstlane(it.y & 0xffff);
+    const int tok0 = cu[seg];
+    const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;   // keys [0, P) live in segment 0's rows [0, P)
+    const int T = P + cu[seg + 1] - tok0;
+    const int row0 = T - A2_ROWS * (tk + 1);                      // may be negative for a sequence's first tile
+    const int q0 = row0 + 64 * wave;
+    const int kb_wg = (row0 + A2_ROWS - 1) >> 6;                  // the tile's last key block
+    const bool dead = q0 + 63 < P;                                // no live row in this wave
+    const int n_full = q0 >= 0 ? (q0 + 1) >> 6 : 0;               // blocks every row of the wave sees unmasked
+    const int kl = dead ? -1 : (q0 + 63) >> 6;                    // the wave's last block
+    const int kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
+    const int vtok0 = tok0 - P;                                   // the row of position p >= P is vtok0 + p
+    const char* kbase = reinterpret_cast<const char*>(qkv + (size_t)vtok0 * stride + (nh + kvh) * hd);
+    const char* pkbase = reinterpret_cast<const char*>(qkv + (nh + kvh) * hd);   // prefix rows start at packed row 0
+    const unsigned blk_bytes = (unsigned)A2_KB * stride * 2;      // < 2^31 / blocks: lr_launch_attention256 checks n_tok
+    const int kv_tail = (nkv * hd + hd) * 2;                      // bytes from a row's K element 0 to the end of its V row
+    const int rec0 = (T - 1) * stride * 2 + kv_tail;              // bytes from the sequence's K element 0 to its end
+    int qm[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) qm[hf] = max(q0 + 32 * hf + r, 0);
+
+    // descriptor of key block kbx of this tile's own rows: rows past T - 1 are range-checked to zero; kbx > kb_wg: nothing
+    auto own_rsrc = [&](int kbx) {
+      const unsigned off = (unsigned)kbx * blk_bytes;
+      int rec = rec0 - (int)off;
+      if (kbx > kb_wg) rec = 0;
+      return a2_make_rsrc(kbase + off, rec);
+    };
+    // prologue staging of one block (prefix rows come from segment 0; P % 4 == 0, so a 4-row piece never straddles)
+    auto stage_generic = [&](int kbx, bool do_k, bool do_v) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key0 = kbx * A2_KB + (wave * 4 + i) * 4;
+        a2_int4 rs;
+        if (key0 < P) {
+          int rec = (P - 1 - kbx * A2_KB) * stride * 2 + kv_tail;
+          if (kbx > kb_wg) rec = 0;
+          rs = a2_make_rsrc(pkbase + (unsigned)kbx * blk_bytes, rec);
+        } else {
+          rs = own_rsrc(kbx);
+        }
+        const unsigned dst = lds0 + (kbx & 1) * 32768 + (wave * 4 + i) * 1024;
+        if (do_k) a2_dma16(rs, dst, koff[i]);
+        if (do_v) a2_dma16(rs, dst + 16384, voff[i]);
+      }
+    };
+
+    // ================================================================ prologue: Q, K(0), K(1), V(0)
+    if (!dead) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int row = 4 * p + (prow | z_);
+        const int qr = min(max(q0 + row, P), T - 1);
+        a2_glds16(qkv + h * hd, (unsigned)((vtok0 + qr) * stride + (ppos ^ (row & 15)) * 8) * 2u, lds0 + qoff + p * 1024);
+      }
+    }
+    stage_generic(0, true, true);
+    stage_generic(1, true, false);
+    A2_BARRIER();
+    if (!dead) {
+#define A2_EMIT_QLOAD
+#define A2_EMIT_KLOAD
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_QLOAD
+#undef A2_EMIT_KLOAD
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);
+    }
+    m_run[0] = m_run[1] = -__builtin_inff();
+    l_run[0] = l_run[1] = 0.f;
+
+    // O[half] *= alpha: taken when some row's reference maximum moved (rare after a sequence's first blocks)
+    auto rescale_a = [&]() {
+      float rt_[8];
+#define A2_EMIT_RESCALE_0
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_RESCALE_0
+    };
+    auto rescale_b = [&]() {
+      float rt_[8];
+#define A2_EMIT_RESCALE_1
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_RESCALE_1
+    };
+    // ================================================================ one key block
+    auto body = [&](auto first_c, auto diag_c, auto par_c, const int kb) {
+      constexpr bool FIRST = decltype(first_c)::value, DIAG = decltype(diag_c)::value;
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr int KNEXT = (PAR ^ 1) * 32768;            // slot of K(kb + 1)
+      constexpr int VCUR = PAR * 32768 + 16384;           // slot of V(kb)
+      const a2_int4 rs_k = own_rsrc(kb + 2), rs_v = own_rsrc(kb + 1);
+      const unsigned dst_k = lds0 + PAR * 32768 + wave * 4096, dst_v = lds0 + (PAR ^ 1) * 32768 + 16384 + wave * 4096;
+      if constexpr (DIAG) {
+        thr[0] = qm[0] - kb * A2_KB - 4 * hi;
+        thr[1] = qm[1] - kb * A2_KB - 4 * hi;
+      }
+#define A2_DMA_K(i) a2_dma16(rs_k, dst_k + (i) * 1024, koff[i]);
+#define A2_DMA_V(i) a2_dma16(rs_v, dst_v + (i) * 1024, voff[i]);
+// row maximum of the block: the two key tiles, then the two lane halves of a row (v_permlane32_swap of two copies)
+#define A2_BK0(hf)                                                                                                     \
+  {                                                                                                                    \
+    float a_, b_;                                                                                                      \
+    asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\t" \
+                 "v_max_f32 %0, %0, %1"                                                                                \
+                 : "=&v"(a_), "=&v"(b_) : "v"(mx0[hf]), "v"(mx1[hf]) : A2_ALLA);                                                 \
+    rowmx[hf] = a_;                                                                                                    \
+  }
+// mxs = rowmax * scale; need = mxs > m + 2^THR; m' = need ? mxs : m; alpha = 2^(m - m'); -m'; row sum restarts at l * alpha
+#define A2_BK1(hf)                                                                                                     \
+  {                                                                                                                    \
+    float mxs_, tmp_;                                                                                                  \
+    asm volatile("v_mul_f32 %4, 0x3e0293ee, %7\n\t"                                                                   \
+                 "v_add_f32 %5, 0x41000000, %0\n\t"                                                                   \
+                 "v_cmp_gt_f32 vcc, %4, %5\n\t"                                                                       \
+                 "v_cndmask_b32 %4, %0, %4, vcc\n\t"                                                                  \
+                 "v_sub_f32 %5, %0, %4\n\t"                                                                           \
+                 "v_exp_f32 %2, %5\n\t"                                                                               \
+                 "v_mov_b32 %0, %4\n\t"                                                                               \
+                 "v_xor_b32 %1, 0x80000000, %4\n\t"                                                                   \
+                 "s_mov_b64 %6, vcc\n\t"                                                                              \
+                 "v_mul_f32 %3, %8, %2"                                                                                \
+                 : "+v"(m_run[hf]), "=&v"(negm[hf]), "=&v"(alpha[hf]), "=&v"(lsum[hf]), "=&v"(mxs_), "=&v"(tmp_),      \
+                   "=&s"(need[hf])                                                                                     \
+                 : "v"(rowmx[hf]), "v"(l_run[hf])                                                                      \
+                 : "vcc", A2_ALLA);                                                                                    \
+  }
+#define A2_RESCALE(hf)                                  \
+  if (need[hf] != 0) {                                  \
+    if (hf == 0) rescale_a(); else rescale_b();         \
+  }
+#define A2_EMIT_BODY
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_BODY
+      A2_BARRIER();
+    };
+    auto idle = [&](const int kb) {   // a wave with no work in this block still moves its share of K(kb + 2) and V(kb + 1)
+      const a2_int4 rs_k = own_rsrc(kb + 2), rs_v = own_rsrc(kb + 1);
+      const unsigned dst_k = lds0 + (kb & 1) * 32768 + wave * 4096, dst_v = lds0 + ((kb + 1) & 1) * 32768 + 16384 + wave * 4096;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a2_dma16(rs_k, dst_k + i * 1024, koff[i]);
+        a2_dma16(rs_v, dst_v + i * 1024, voff[i]);
+      }
+      A2_BARRIER();
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using BF = std::false_type;
+    using BT = std::true_type;
+    if (dead) {
+      for (int kb = 0; kb <= kb_wg; ++kb) idle(kb);
+    } else {
+      if (n_full == 0) body(BT{}, BT{}, C0{}, 0); else body(BT{}, BF{}, C0{}, 0);
+      for (int kb = 1; kb <= kl; ++kb) {
+        if (kb < n_full) {
+          if (kb & 1) body(BF{}, BF{}, C1{}, kb); else body(BF{}, BF{}, C0{}, kb);
+        } else {
+          if (kb & 1) body(BF{}, BT{}, C1{}, kb); else body(BF{}, BT{}, C0{}, kb);
+        }
+      }
+      {   // what the wave still owes after its last block: the rest of B's softmax and PV(B, kl)
+#define A2_EMIT_DRAIN
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_DRAIN
+      }
+      for (int kb = kl + 1; kb <= kb_wg; ++kb) idle(kb);
+
+      // ============================================================== epilogue: O^T / l -> bf16 rows via the wave's own LDS region -> global
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory", A2_ALLA);   // the last asm MFMAs' results (the compiler pads nothing)
+      float inv[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float a_, b_;
+        a2_swap32(l_run[hf], a_, b_);
+        const float l = a_ + b_;
+        inv[hf] = 1.0f / l;
+        const int q = q0 + 32 * hf + r;
+        if (lse && hi == 0 && q >= P) lse[(size_t)(vtok0 + q) * nh + h] = (m_run[hf] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+      }
+      a2_lds* const obase = (a2_lds*)smem + qoff;
+      float ov[16];
+      // lane: query row 32 hf + r, d = 32 dt + 8 g + 4 hi + 0..3 in registers 4g .. 4g+3: 8 bytes of 16-byte chunk 4 dt + g
+#define A2_OSTORE(hf, dt)                                                                                          \
+  {                                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+      a2_u32x2 w_;                                                                                                 \
+      w_[0] = (unsigned)f2bf(ov[4 * g] * inv[hf]) | ((unsigned)f2bf(ov[4 * g + 1] * inv[hf]) << 16);               \
+      w_[1] = (unsigned)f2bf(ov[4 * g + 2] * inv[hf]) | ((unsigned)f2bf(ov[4 * g + 3] * inv[hf]) << 16);           \
+      *reinterpret_cast<__attribute__((address_space(3))) a2_u32x2*>(                                              \
+          obase + (32 * hf + (r | z_)) * 256 + (((4 * dt + g) ^ (r & 15)) << 4) + 8 * hi) = w_;                    \
+    }                                                                                                              \
+  }
+#define A2_EMIT_OREAD
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_OREAD
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int row = 4 * k + (prow | z_), q = q0 + row;
+        const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ppos * 16);
+        if (q >= P) *reinterpret_cast<a2_u32x4*>(out + (size_t)(vtok0 + q) * nh * hd + h * hd + (ppos ^ (row & 15)) * 8) = v;
+      }
+    }
+  }
+  // ---- the last workgroup to leave re-arms the counters for the next launch over the same item list
+  if (tid == 0) {
+    const int d = atomicAdd(&ctr[8], 1);
+    if (d == (int)gridDim.x - 1)
+      for (int i = 0; i < 9; ++i) atomicExch(&ctr[i], 0);
+  }
+}
+
+// =====================================================================================================================
+// cu / cu_host / prefix_len as lr_launch_attention; items_ws = lr_launch_attn256_items' output for the same cu.
+int lr_launch_attention256(const u16* qkv, u16* out, const int32_t* cu, const int32_t* cu_host, int S, int n_tok, int nh,
+                           int nkv, int hd, float* lse, void* items_ws, hipStream_t st, int prefix_len) {
+  if (n_tok <= 0 || S <= 0) return LR_OK;
+  if (hd != 128 || nh % nkv != 0 || nh > 0xffff) LR_FAIL(LR_EUNSUPPORTED, "attention (256-row tiles): head_dim 128, nh %% nkv == 0 only");
+  if (prefix_len < 0 || prefix_len % 4 != 0 || prefix_len > A2_KB || (prefix_len > 0 && cu_host[1] - cu_host[0] != prefix_len))
+    LR_FAIL(LR_EINVAL, "attention (256-row tiles): shared prefix of %d tokens (multiple of 4, <= 64, = segment 0)", prefix_len);
+  if ((long long)n_tok * (nh + 2 * nkv) * hd * 2 > 0x7fffffffLL * 2)
+    LR_FAIL(LR_EUNSUPPORTED, "attention: packed qkv of %d tokens exceeds the 4 GiB a buffer descriptor addresses", n_tok);
+  if (!items_ws) LR_FAIL(LR_EINVAL, "attention (256-row tiles): no item list");
+  double work = 0;
+  for (int b = 0; b < S; ++b) {
+    const double P = (prefix_len > 0 && b > 0) ? prefix_len : 0;
+    const double T = P + cu_host[b + 1] - cu_host[b];
+    work += 4.0 * nh * hd * (T * (T + 1) / 2 - P * (P + 1) / 2);
+  }
+  LrProfScope prof(LR_PROF_ATTN_MFMA, work, st);
+  int dev = 0, cus = 0;
+  LR_CHECK_HIP(hipGetDevice(&dev));
+  static int cu_count[LR_MAX_DEVICES] = {};
+  if (dev >= 0 && dev < LR_MAX_DEVICES && cu_count[dev] > 0) {
+    cus = cu_count[dev];
+  } else {
+    LR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < LR_MAX_DEVICES) cu_count[dev] = cus;
+  }
+  int32_t* ws = (int32_t*)items_ws;
+  static bool lds_set[LR_MAX_DEVICES] = {};
+  if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma256_kernel), A2_LDS_BYTES, lds_set)) return rc;
+  hipLaunchKernelGGL(attn_mfma256_kernel, dim3(cus), dim3(256), A2_LDS_BYTES, st, qkv, out, cu, prefix_len, nh, nkv,
+                     (const int32_t*)ws, ws + A2_HDR_INTS, lse);
+  LR_CHECK_LAUNCH("attn_mfma256_kernel");
+  return LR_OK;
+}

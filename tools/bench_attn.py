@@ -18,7 +18,10 @@ def run(lens, var=0, name=""):
     out = torch.empty(n, nh * hd, dtype=torch.bfloat16, device="cuda")
     cu_h = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     cu = torch.from_numpy(cu_h).cuda(); l = lib()
-    call = lambda: check(l.lr_attention_varlen(qkv.data_ptr(), out.data_ptr(), cu.data_ptr(), cu_h.ctypes.data, B, nh, nh, hd, var, stream_ptr()), "attn")
+    wsb = l.lr_attention_workspace_bytes(n, B, nh)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda")
+    call = lambda: check(l.lr_attention_varlen_ws(qkv.data_ptr(), out.data_ptr(), None, cu.data_ptr(), cu_h.ctypes.data, B, nh, nh, hd, var,
+                                                  ws.data_ptr(), wsb, stream_ptr()), "attn")
     for _ in range(3): call()
     torch.cuda.synchronize()
     ts = []
@@ -46,3 +49,4 @@ if __name__ == "__main__":
             run([740] * 16, v, name="beauty reference batch (16 x 740)")
             run(T[token_budget_steps(T)[0]], v, name="beauty token-budget step")
             run([1000] * 16, v, name="16 x 1000")
+            run([8192] * 4, v, name="4 x 8192")
