@@ -178,14 +178,14 @@ __device__ __forceinline__ a2_int4 a2_make_rsrc(const void* base, int num_record
   return r;
 }
 // LDS-DMA as inline asm (hipcc must not count it: see llama_attn.hip); M0 is written in the statement that reads it
-__device__ __forceinline__ void a2_dma16(a2_int4 rsrc, unsigned lds_dst, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rsrc)
+// soff: 0 / 64 / 128 / 192, the 64-byte column group of the piece (memory side only; the range check of a raw buffer is on voff)
+__device__ __forceinline__ void a2_dma16(a2_int4 rsrc, unsigned lds_dst, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory", A2_ALLA);
 }
 __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {   // scalar base + per-lane offset
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", A2_ALLA);
 }
-__device__ __forceinline__ int a2_vswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 #define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
 
@@ -203,30 +203,25 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   const unsigned lds0 = (unsigned)(size_t)(a2_lds*)smem;
   const int2* items = reinterpret_cast<const int2*>(ws_ro + A2_HDR_INTS + A2_CTR_INTS);
 
-  // ---- lane constants of the fragment reads
-  unsigned kaddr[8];                // K / Q row reads: row (l & 31) of a 32-row tile, 16-byte chunk (2 ks + hi) ^ (row & 15)
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = lds0 + r * 256 + (((2 * ks + hi) ^ (r & 15)) << 4);
-  const unsigned qoff = A2_QBUF + wave * 16384;   // the wave's own Q / O rows
-  unsigned vb[4][2];                // V^T reads (ds_read_b64_tr_b16): fragment (dt, s), half jj: + 4096 s + slot base
+  // ---- LDS images (no XOR swizzle: every read address is ONE lane constant + an immediate)
+  //  K tile (and the wave's Q rows): 16-row groups; inside a group chunk-major: (row, 16-byte chunk c) at
+  //    (row >> 4) * 4096 + c * 256 + (row & 15) * 16 -- a ds_read_b128 of 16 consecutive rows' chunk c is 256 contiguous bytes
+  //  V tile: 64-byte column groups G (= the 32 dims of O^T tile dt): (key, byte b of the row) at
+  //    (b >> 6) * 4096 + key * 64 + (b & 63) -- a ds_read_b64_tr_b16 half-wave (4 keys x 64 bytes) is 256 contiguous bytes
+  //  LDS-DMA pieces (1 KiB, lane-linear): K piece (row group g, chunk quad p): lane L <- row 16 g + (L & 15), chunk 4 p + (L >> 4);
+  //  V piece (column group G, key group g): lane L <- key 16 g + (L >> 2), bytes 64 G + 16 (L & 3). Wave w moves group w of both,
+  //  so the per-lane source offset is one constant per operand and the piece index is the load's scalar offset (64 p).
+  const unsigned kaddr = lds0 + (r >> 4) * 4096 + (r & 15) * 16 + hi * 256;           // + 512 ks + 8192 kt + slot
+  const unsigned qaddr = kaddr + A2_QBUF + wave * 16384;                             // + 512 ks + 8192 half
+  const unsigned qoff = A2_QBUF + wave * 16384;                                      // the wave's own Q / O rows
+  unsigned vaddr;                                                                    // + 4096 dt + 1024 s + 512 jj + slot
   {
     const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-        vb[dt][jj] = lds0 + 256 * (8 * jj + 4 * hi + q) +
-                     16 * ((4 * dt + 2 * g1 + (p >> 1)) ^ ((q << 2) | (2 * jj + hi))) + 8 * (p & 1);
+    vaddr = lds0 + (4 * hi + q) * 64 + 32 * g1 + 8 * p;
   }
-  // ---- lane constants of the K/V staging: wave w moves pieces 4w .. 4w+3 (4 rows of 256 B each) of a block's K and V
-  const int prow = lane >> 4, ppos = lane & 15;
-  unsigned koff[4], voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 4 + prow;
-    koff[i] = (unsigned)(row * stride + (ppos ^ (row & 15)) * 8) * 2u;
-    voff[i] = (unsigned)(row * stride + nkv * hd + (ppos ^ a2_vswz(row)) * 8) * 2u;   // V sits nkv * hd columns behind K
-  }
+  const unsigned koff = (unsigned)((16 * wave + (lane & 15)) * stride) * 2u + (lane >> 4) * 16;
+  const unsigned voff = (unsigned)((16 * wave + (lane >> 2)) * stride + nkv * hd) * 2u + (lane & 3) * 16;   // V sits nkv * hd columns behind K
+  const int prow = lane >> 4, ppos = lane & 15;   // epilogue: row-major rows
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7;
@@ -235,21 +230,25 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   a2_f16v S[2][2];
   a2_int4 Pf[2][4];
   a2_i64x2 Vf[4][4];
-  float t_[2][32], p_[2][32];
-  float m_run[2], l_run[2], lsum[2], negm[2], alpha[2], mx0[2], mx1[2], rowmx[2];
-  unsigned long long need[2];      // lanes whose row's reference maximum moves in this block
+  float t_[2][2], p_[2][4], bt_[2], rt_[8];          // rotating temporaries of the generated stream
+  float m_run[2], lsum[2], negm[2], alpha[2], mx0[2], mx1[2], rowmx[2];   // lsum: the running row sum l
   int thr[2];
   const float ninf = -__builtin_inff();
+  const int soff[4] = {0, 64, 128, 192};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    lsum[h] = negm[h] = alpha[h] = mx0[h] = mx1[h] = rowmx[h] = 0.f;
-    need[h] = 0;
+    m_run[h] = lsum[h] = negm[h] = alpha[h] = mx0[h] = mx1[h] = rowmx[h] = 0.f;
     thr[h] = 0;
+    t_[h][0] = t_[h][1] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Pf[h][i] = a2_int4{0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 32; ++i) t_[h][i] = p_[h][i] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      Pf[h][i] = a2_int4{0, 0, 0, 0};
+      p_[h][i] = 0.f;
+    }
   }
+  bt_[0] = bt_[1] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rt_[i] = 0.f;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -308,32 +307,29 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       if (kbx > kb_wg) rec = 0;
       return a2_make_rsrc(kbase + off, rec);
     };
-    // prologue staging of one block (prefix rows come from segment 0; P % 4 == 0, so a 4-row piece never straddles)
+    // prologue staging of one block with per-lane source addresses: keys < P come from segment 0's rows, keys >= T are
+    // clamped to T - 1 (they are causally masked for every live row; the descriptor path zero-fills them instead)
     auto stage_generic = [&](int kbx, bool do_k, bool do_v) {
+      const unsigned dst = lds0 + (kbx & 1) * 32768 + wave * 4096;
+      const int kk = min(kbx * A2_KB + 16 * wave + (lane & 15), T - 1), kv = min(kbx * A2_KB + 16 * wave + (lane >> 2), T - 1);
+      const unsigned ok = (unsigned)(((kk < P ? kk : vtok0 + kk) * stride + (nh + kvh) * hd) * 2 + (lane >> 4) * 16);
+      const unsigned ov = (unsigned)(((kv < P ? kv : vtok0 + kv) * stride + (nh + nkv + kvh) * hd) * 2 + (lane & 3) * 16);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int key0 = kbx * A2_KB + (wave * 4 + i) * 4;
-        a2_int4 rs;
-        if (key0 < P) {
-          int rec = (P - 1 - kbx * A2_KB) * stride * 2 + kv_tail;
-          if (kbx > kb_wg) rec = 0;
-          rs = a2_make_rsrc(pkbase + (unsigned)kbx * blk_bytes, rec);
-        } else {
-          rs = own_rsrc(kbx);
-        }
-        const unsigned dst = lds0 + (kbx & 1) * 32768 + (wave * 4 + i) * 1024;
-        if (do_k) a2_dma16(rs, dst, koff[i]);
-        if (do_v) a2_dma16(rs, dst + 16384, voff[i]);
+        if (do_k) a2_glds16(qkv, ok + i * 64, dst + i * 1024);
+        if (do_v) a2_glds16(qkv, ov + i * 64, dst + 16384 + i * 4096 - wave * 3072);
       }
     };
 
     // ================================================================ prologue: Q, K(0), K(1), V(0)
     if (!dead) {
 #pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int row = 4 * p + (prow | z_);
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * g + ((lane & 15) | z_);
         const int qr = min(max(q0 + row, P), T - 1);
-        a2_glds16(qkv + h * hd, (unsigned)((vtok0 + qr) * stride + (ppos ^ (row & 15)) * 8) * 2u, lds0 + qoff + p * 1024);
+        const unsigned qo = (unsigned)((vtok0 + qr) * stride + h * hd) * 2u + (lane >> 4) * 16;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a2_glds16(qkv, qo + p * 64, lds0 + qoff + g * 4096 + p * 1024);
       }
     }
     stage_generic(0, true, true);
@@ -348,97 +344,58 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);
     }
     m_run[0] = m_run[1] = -__builtin_inff();
-    l_run[0] = l_run[1] = 0.f;
+    lsum[0] = lsum[1] = 0.f;
 
-    // O[half] *= alpha: taken when some row's reference maximum moved (rare after a sequence's first blocks)
-    auto rescale_a = [&]() {
-      float rt_[8];
-#define A2_EMIT_RESCALE_0
-#include "llama_attn256_body.inc"
-#undef A2_EMIT_RESCALE_0
-    };
-    auto rescale_b = [&]() {
-      float rt_[8];
-#define A2_EMIT_RESCALE_1
-#include "llama_attn256_body.inc"
-#undef A2_EMIT_RESCALE_1
-    };
     // ================================================================ one key block
-    auto body = [&](auto first_c, auto diag_c, auto par_c, const int kb) {
+    auto body = [&](auto first_c, auto diag_c, const int kb) {
       constexpr bool FIRST = decltype(first_c)::value, DIAG = decltype(diag_c)::value;
-      constexpr int PAR = decltype(par_c)::value;
-      constexpr int KNEXT = (PAR ^ 1) * 32768;            // slot of K(kb + 1)
-      constexpr int VCUR = PAR * 32768 + 16384;           // slot of V(kb)
+      const int par = (kb & 1) * 32768;                   // K(kb), V(kb) and K(kb + 2) live in slot kb & 1; K(kb + 1), V(kb + 1) in the other
       const a2_int4 rs_k = own_rsrc(kb + 2), rs_v = own_rsrc(kb + 1);
-      const unsigned dst_k = lds0 + PAR * 32768 + wave * 4096, dst_v = lds0 + (PAR ^ 1) * 32768 + 16384 + wave * 4096;
+      const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
+      const unsigned kaddr_n = kaddr + (par ^ 32768), vaddr_c = vaddr + par + 16384;
+      (void)rt_; (void)bt_; (void)t_; (void)p_; (void)soff; (void)ninf; (void)kaddr_n; (void)vaddr_c;   // named here so that the generic lambda captures them (the
+                                                                          // asm operands inside the if-constexpr arms alone do not)
       if constexpr (DIAG) {
         thr[0] = qm[0] - kb * A2_KB - 4 * hi;
         thr[1] = qm[1] - kb * A2_KB - 4 * hi;
       }
-#define A2_DMA_K(i) a2_dma16(rs_k, dst_k + (i) * 1024, koff[i]);
-#define A2_DMA_V(i) a2_dma16(rs_v, dst_v + (i) * 1024, voff[i]);
-// row maximum of the block: the two key tiles, then the two lane halves of a row (v_permlane32_swap of two copies)
-#define A2_BK0(hf)                                                                                                     \
-  {                                                                                                                    \
-    float a_, b_;                                                                                                      \
-    asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\t" \
-                 "v_max_f32 %0, %0, %1"                                                                                \
-                 : "=&v"(a_), "=&v"(b_) : "v"(mx0[hf]), "v"(mx1[hf]) : A2_ALLA);                                                 \
-    rowmx[hf] = a_;                                                                                                    \
-  }
-// mxs = rowmax * scale; need = mxs > m + 2^THR; m' = need ? mxs : m; alpha = 2^(m - m'); -m'; row sum restarts at l * alpha
-#define A2_BK1(hf)                                                                                                     \
-  {                                                                                                                    \
-    float mxs_, tmp_;                                                                                                  \
-    asm volatile("v_mul_f32 %4, 0x3e0293ee, %7\n\t"                                                                   \
-                 "v_add_f32 %5, 0x41000000, %0\n\t"                                                                   \
-                 "v_cmp_gt_f32 vcc, %4, %5\n\t"                                                                       \
-                 "v_cndmask_b32 %4, %0, %4, vcc\n\t"                                                                  \
-                 "v_sub_f32 %5, %0, %4\n\t"                                                                           \
-                 "v_exp_f32 %2, %5\n\t"                                                                               \
-                 "v_mov_b32 %0, %4\n\t"                                                                               \
-                 "v_xor_b32 %1, 0x80000000, %4\n\t"                                                                   \
-                 "s_mov_b64 %6, vcc\n\t"                                                                              \
-                 "v_mul_f32 %3, %8, %2"                                                                                \
-                 : "+v"(m_run[hf]), "=&v"(negm[hf]), "=&v"(alpha[hf]), "=&v"(lsum[hf]), "=&v"(mxs_), "=&v"(tmp_),      \
-                   "=&s"(need[hf])                                                                                     \
-                 : "v"(rowmx[hf]), "v"(l_run[hf])                                                                      \
-                 : "vcc", A2_ALLA);                                                                                    \
-  }
-#define A2_RESCALE(hf)                                  \
-  if (need[hf] != 0) {                                  \
-    if (hf == 0) rescale_a(); else rescale_b();         \
-  }
-#define A2_EMIT_BODY
+      if constexpr (FIRST && DIAG) {
+#define A2_EMIT_BODY_11
 #include "llama_attn256_body.inc"
-#undef A2_EMIT_BODY
+#undef A2_EMIT_BODY_11
+      } else if constexpr (FIRST) {
+#define A2_EMIT_BODY_10
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_BODY_10
+      } else if constexpr (DIAG) {
+#define A2_EMIT_BODY_01
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_BODY_01
+      } else {
+#define A2_EMIT_BODY_00
+#include "llama_attn256_body.inc"
+#undef A2_EMIT_BODY_00
+      }
       A2_BARRIER();
     };
     auto idle = [&](const int kb) {   // a wave with no work in this block still moves its share of K(kb + 2) and V(kb + 1)
       const a2_int4 rs_k = own_rsrc(kb + 2), rs_v = own_rsrc(kb + 1);
-      const unsigned dst_k = lds0 + (kb & 1) * 32768 + wave * 4096, dst_v = lds0 + ((kb + 1) & 1) * 32768 + 16384 + wave * 4096;
+      const unsigned dst_k = lds0 + (kb & 1) * 32768 + wave * 4096, dst_v = lds0 + ((kb + 1) & 1) * 32768 + 16384 + wave * 1024;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        a2_dma16(rs_k, dst_k + i * 1024, koff[i]);
-        a2_dma16(rs_v, dst_v + i * 1024, voff[i]);
+        a2_dma16(rs_k, dst_k + i * 1024, koff, i * 64);
+        a2_dma16(rs_v, dst_v + i * 4096, voff, i * 64);
       }
       A2_BARRIER();
     };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
     using BF = std::false_type;
     using BT = std::true_type;
     if (dead) {
       for (int kb = 0; kb <= kb_wg; ++kb) idle(kb);
     } else {
-      if (n_full == 0) body(BT{}, BT{}, C0{}, 0); else body(BT{}, BF{}, C0{}, 0);
-      for (int kb = 1; kb <= kl; ++kb) {
-        if (kb < n_full) {
-          if (kb & 1) body(BF{}, BF{}, C1{}, kb); else body(BF{}, BF{}, C0{}, kb);
-        } else {
-          if (kb & 1) body(BF{}, BT{}, C1{}, kb); else body(BF{}, BT{}, C0{}, kb);
-        }
-      }
+      if (n_full == 0) body(BT{}, BT{}, 0); else body(BT{}, BF{}, 0);
+      for (int kb = 1; kb < n_full; ++kb) body(BF{}, BF{}, kb);               // the steady state: ONE instance, a self-loop
+      for (int kb = max(n_full, 1); kb <= kl; ++kb) body(BF{}, BT{}, kb);     // the one or two blocks the diagonal crosses
       {   // what the wave still owes after its last block: the rest of B's softmax and PV(B, kl)
 #define A2_EMIT_DRAIN
 #include "llama_attn256_body.inc"
@@ -452,7 +409,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         float a_, b_;
-        a2_swap32(l_run[hf], a_, b_);
+        a2_swap32(lsum[hf], a_, b_);
         const float l = a_ + b_;
         inv[hf] = 1.0f / l;
         const int q = q0 + 32 * hf + r;

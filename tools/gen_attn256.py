@@ -49,82 +49,97 @@ def K_(kt, ks):
     return 192 + (8 * kt + ks) * 4
 
 
-class Op:
-    def __init__(self, gap, code, cond="", kind="valu", prio=5):
-        self.gap, self.code, self.cond, self.kind, self.prio = gap, code, cond, kind, prio
+class Ins:
+    """One instruction of a gap: text with {0} {1} .. placeholders and its operands (mode, C expression).
+    mode: 'o' written, 'i' read, 'io' both (VGPR); 's' SGPR read; 'n' integer constant."""
+    def __init__(self, gap, text, operands=(), cond="", kind="valu", prio=5, raw=None):
+        self.gap, self.text, self.operands, self.cond, self.kind, self.prio, self.raw = gap, text, list(operands), cond, kind, prio, raw
 
 
 def build():
-    mf = {}      # gap -> (code, cond)
+    mf = {}      # gap -> Ins (the MFMA)
     ops = []     # fillers
 
-    def add(gap, code, cond="", kind="valu", prio=5):
-        ops.append(Op(gap, code, cond, kind, prio))
+    def add(gap, text, operands=(), cond="", kind="valu", prio=5, raw=None):
+        ops.append(Ins(gap, text, operands, cond, kind, prio, raw))
 
     # ---------------- MFMAs
     for h, g0 in ((0, 0), (1, 32)):
         for kt in range(2):
             for ks in range(8):
                 g = g0 + 8 * kt + ks
-                c = "0" if ks == 0 else "%0"
-                con = '"=v"' if ks == 0 else '"+v"'
-                mf[g] = ('asm volatile("v_mfma_f32_32x32x16_bf16 %%0, %s, %s, %s" : %s(S[%d][%d]));'
-                         % (areg(K_(kt, ks), 4), areg(Q_(h, ks), 4), c, con, h, kt), "")
-                mf[g] = (mf[g][0].replace("));", ") :: A2_ALLA);"), "")
+                S = "S[%d][%d]" % (h, kt)
+                if ks == 0:
+                    mf[g] = Ins(g, "v_mfma_f32_32x32x16_bf16 {0}, %s, %s, 0" % (areg(K_(kt, ks), 4), areg(Q_(h, ks), 4)), [("o", S)])
+                    mf[g].diag_text = "v_mfma_f32_32x32x16_bf16 {0}, %s, %s, {0}" % (areg(K_(kt, ks), 4), areg(Q_(h, ks), 4))
+                else:
+                    mf[g] = Ins(g, "v_mfma_f32_32x32x16_bf16 {0}, %s, %s, {0}" % (areg(K_(kt, ks), 4), areg(Q_(h, ks), 4)), [("io", S)])
     for h, g0 in ((1, 16), (0, 48)):
         for s in range(4):
             for dt in range(4):
                 g = g0 + 4 * s + dt
-                o = O_(h, dt)
-                acc = ('asm volatile("v_mfma_f32_32x32x16_bf16 %s, %%0, %%1, %s" :: "v"(Vf[%d][%d]), "v"(Pf[%d][%d]) : %s);'
-                       % (areg(o, 16), areg(o, 16), dt, s, h, s, clob(o, 16)))
-                ini = ('asm volatile("v_mfma_f32_32x32x16_bf16 %s, %%0, %%1, 0" :: "v"(Vf[%d][%d]), "v"(Pf[%d][%d]) : %s);'
-                       % (areg(o, 16), dt, s, h, s, clob(o, 16)))
-                if h == 1:
-                    mf[g] = (acc, "!FIRST")            # PV(B, kb-1): nothing to do in a tile's first block
-                elif s == 0:
-                    mf[g] = ("if constexpr (FIRST) { %s } else { %s }" % (ini, acc), "")   # O[A] starts at 0
-                else:
-                    mf[g] = (acc, "")
+                o = areg(O_(h, dt), 16)
+                opr = [("i", "Vf[%d][%d]" % (dt, s)), ("i", "Pf[%d][%d]" % (h, s))]
+                m = Ins(g, "v_mfma_f32_32x32x16_bf16 %s, {0}, {1}, %s" % (o, o), opr, cond="!FIRST" if h == 1 else "")
+                if h == 0 and s == 0:   # O[A] of a tile starts at 0: its first PV takes C = 0
+                    m.first_text = "v_mfma_f32_32x32x16_bf16 %s, {0}, {1}, 0" % o
+                mf[g] = m
 
-    # ---------------- softmax of half h; gb = gap of the first QK MFMA of that half (0 / 32). Every instruction is an
-    # asm volatile statement: the order below IS the order in the kernel (hipcc allocates registers, nothing else)
+    # ---------------- softmax of half h; gb = gap of the first QK MFMA of that half (0 / 32)
     for h, gb in ((0, 0), (1, 32)):
-        H = str(h)
-        # causal mask (DIAG blocks only), right in front of the maxima that read the tile: key c of the block > thr[h]
+        # causal mask (DIAG blocks only): the accumulator tile STARTS at 0 / -inf (key c of the block > thr[h]: masked) and the
+        # first QK MFMA accumulates onto it. (Masking the finished scores in place made hipcc copy accumulator elements
+        # around the statement -- compiler code that reads an asm MFMA's result with no wait states.) The tile's registers are
+        # free by then: S[h][kt] was last read by the previous block's E-phase.
         for kt in range(2):
-            gm = gb + 9 + 8 * kt
+            g0 = (-1, 0, 24, 32)[2 * h + kt]      # -1: in front of the block's first MFMA
             for rr in range(16):
                 c = 32 * kt + (rr & 3) + 8 * (rr >> 2)
-                add(gm + (rr >> 3), 'asm volatile("v_cmp_gt_i32 vcc, %d, %%1\\n\\tv_cndmask_b32 %%0, %%0, %%2, vcc" '
-                    ': "+v"(S[%s][%d][%d]) : "v"(thr[%s]), "v"(ninf) : "vcc", A2_ALLA);' % (c, H, kt, rr, H), "DIAG", prio=1)
+                add(g0 + (rr >> 1) if g0 >= 0 else -1, "v_cmp_gt_i32 vcc, %d, {1}\n\tv_cndmask_b32 {0}, 0, {2}, vcc" % c,
+                    [("o", "S[%d][%d][%d]" % (h, kt, rr)), ("i", "thr[%d]" % h), ("i", "ninf")], "DIAG", kind="mask", prio=1)
         # row maximum: 8 v_max3 / v_max per 16-value tile; S[h][0] is complete after gap gb+7, S[h][1] after gb+15 and an
-        # asm MFMA's result may be read two gaps later at the earliest (the compiler pads nothing for an asm statement)
+        # asm MFMA's result may be read two gaps later at the earliest (nothing pads an asm statement's hazards)
         for kt, g_first, per_gap in ((0, gb + 9, 1), (1, gb + 17, 2)):
-            v = "S[%s][%d]" % (H, kt)
-            mx = "mx%d[%s]" % (kt, H)
-            seq = ['asm volatile("v_max3_f32 %%0, %%1, %%2, %%3" : "=v"(%s) : "v"(%s[0]), "v"(%s[1]), "v"(%s[2]) : A2_ALLA);' % (mx, v, v, v)]
+            v = "S[%d][%d]" % (h, kt)
+            mx = "mx%d[%d]" % (kt, h)
+            seq = [("v_max3_f32 {0}, {1}, {2}, {3}", [("o", mx), ("i", v + "[0]"), ("i", v + "[1]"), ("i", v + "[2]")])]
             for j in range(1, 7):
-                seq.append('asm volatile("v_max3_f32 %%0, %%0, %%1, %%2" : "+v"(%s) : "v"(%s[%d]), "v"(%s[%d]) : A2_ALLA);' % (mx, v, 2 * j + 1, v, 2 * j + 2))
-            seq.append('asm volatile("v_max_f32 %%0, %%0, %%1" : "+v"(%s) : "v"(%s[15]) : A2_ALLA);' % (mx, v))
-            for n, code in enumerate(seq):
-                add(g_first + n // per_gap, code, prio=2)
+                seq.append(("v_max3_f32 {0}, {0}, {1}, {2}", [("io", mx), ("i", "%s[%d]" % (v, 2 * j + 1)), ("i", "%s[%d]" % (v, 2 * j + 2))]))
+            seq.append(("v_max_f32 {0}, {0}, {1}", [("io", mx), ("i", v + "[15]")]))
+            for n, (t, o) in enumerate(seq):
+                add(g_first + n // per_gap, t, o, prio=2)
         g = gb + 21
-        add(g, "A2_BK0(%s)" % H, prio=2)        # max of the two tiles, across the lane halves (permlane32 swap)
-        add(g + 1, "A2_BK1(%s)" % H, prio=2)    # scaled maximum, deferred-maximum decision, alpha, -m, row-sum start
-        add(g + 1, "if constexpr (!FIRST) { A2_RESCALE(%s) }" % H, prio=3)
-        # E-phase
+        H = h
+        # row maximum of the block: the two key tiles, then the two lane halves of a row (v_permlane32_swap of two copies)
+        add(g, "v_max_f32 {0}, {2}, {3}\n\tv_max_f32 {1}, {2}, {3}\n\ts_nop 1\n\tv_permlane32_swap_b32 {0}, {1}\n\ts_nop 1\n\tv_max_f32 {4}, {0}, {1}",
+            [("o", "bt_[0]"), ("o", "bt_[1]"), ("i", "mx0[%d]" % H), ("i", "mx1[%d]" % H), ("o", "rowmx[%d]" % H)], kind="bk", prio=2)
+        # mxs = rowmax * scale; need (vcc) = mxs > m + 2^THR; m' = need ? mxs : m; alpha = 2^(m - m'); -m'; the row sum carries on
+        # from l * alpha; O[half] *= alpha if some row's reference maximum moved (not in a tile's first block: O starts there)
+        bk1 = ("v_mul_f32 {4}, 0x3e0293ee, {6}\n\tv_add_f32 {5}, 0x41000000, {0}\n\tv_cmp_gt_f32 vcc, {4}, {5}\n\t"
+               "v_cndmask_b32 {4}, {0}, {4}, vcc\n\tv_sub_f32 {5}, {0}, {4}\n\tv_exp_f32 {2}, {5}\n\tv_mov_b32 {0}, {4}\n\t"
+               "v_xor_b32 {1}, 0x80000000, {4}\n\ts_nop 0\n\tv_mul_f32 {3}, {3}, {2}")
+        opr = [("io", "m_run[%d]" % H), ("o", "negm[%d]" % H), ("o", "alpha[%d]" % H), ("io", "lsum[%d]" % H), ("o", "bt_[0]"), ("o", "bt_[1]"),
+               ("i", "rowmx[%d]" % H)]
+        add(g + 1, bk1, opr, kind="bk", prio=2)
+        resc = ["s_cbranch_vccz .La2_keep%d_%%="  % H]
+        for c in range(8):
+            lo = O_(H, 0) + 8 * c
+            resc += ["v_accvgpr_read_b32 {%d}, a%d" % (1 + i, lo + i) for i in range(8)]
+            resc += ["v_mul_f32 {%d}, {0}, {%d}" % (1 + i, 1 + i) for i in range(8)]
+            resc += ["v_accvgpr_write_b32 a%d, {%d}" % (lo + i, 1 + i) for i in range(8)]
+        resc += [".La2_keep%d_%%=:" % H]
+        add(g + 1, "\n\t".join(resc), [("i", "alpha[%d]" % H)] + [("o", "rt_[%d]" % i) for i in range(8)], cond="!FIRST", kind="bk", prio=3)
+        # E-phase (temporaries rotate: t lives one gap, p at most three)
         e0 = gb + 23
         for i in range(32):
             kt, rr = i >> 4, i & 15
-            add(e0 + i, 'asm volatile("v_fmamk_f32 %%0, %%1, 0x3e0293ee, %%2" : "=v"(t_[%s][%d]) : "v"(S[%s][%d][%d]), "v"(negm[%s]) : A2_ALLA);'
-                % (H, i, H, kt, rr, H), prio=6)
-            add(e0 + i + 1, 'asm volatile("v_exp_f32 %%0, %%1" : "=v"(p_[%s][%d]) : "v"(t_[%s][%d]) : A2_ALLA);' % (H, i, H, i), kind="exp", prio=4)
-            add(e0 + i + 2, 'asm volatile("v_add_f32 %%0, %%0, %%1" : "+v"(lsum[%s]) : "v"(p_[%s][%d]) : A2_ALLA);' % (H, H, i), prio=7)
+            t, pp, pm = "t_[%d][%d]" % (h, i % 2), "p_[%d][%d]" % (h, i % 4), "p_[%d][%d]" % (h, (i - 1) % 4)
+            add(e0 + i, "v_fmamk_f32 {0}, {1}, 0x3e0293ee, {2}", [("o", t), ("i", "S[%d][%d][%d]" % (h, kt, rr)), ("i", "negm[%d]" % h)], prio=6)
+            add(e0 + i + 1, "v_exp_f32 {0}, {1}", [("o", pp), ("i", t)], kind="exp", prio=4)
+            add(e0 + i + 2, "v_add_f32 {0}, {0}, {1}", [("io", "lsum[%d]" % h), ("i", pp)], prio=7)
             if i & 1:
-                add(e0 + i + 2, 'asm volatile("v_cvt_pk_bf16_f32 %%0, %%1, %%2" : "=v"(Pf[%s][%d][%d]) : "v"(p_[%s][%d]), "v"(p_[%s][%d]) : A2_ALLA);'
-                    % (H, i >> 3, (i >> 1) & 3, H, i - 1, H, i), prio=8)
-        add(e0 + 34, "l_run[%s] = lsum[%s];" % (H, H), prio=9)
+                add(e0 + i + 2, "v_cvt_pk_bf16_f32 {0}, {1}, {2}",
+                    [("o", "Pf[%d][%d][%d]" % (h, i >> 3, (i >> 1) & 3)), ("i", pm), ("i", pp)], prio=8)
 
     # ---------------- V^T fragment reads of block kb (fragment f = 4 s + dt is free after PV(B, kb-1)'s MFMA at gap 16 + f)
     for n in range(32):
@@ -132,63 +147,154 @@ def build():
         s, dt = f >> 2, f & 3
         g = 23 + (n * 18) // 32
         assert g >= 16 + f + 2 and g <= 46
-        add(g, 'asm volatile("ds_read_b64_tr_b16 %%0, %%1 offset:%%2" : "=v"(Vf[%d][%d][%d]) : "v"(vb[%d][%d]), "i"(VCUR + %d) : A2_ALLA);'
-            % (dt, s, jj, dt, jj, 4096 * s), kind="lds", prio=5)
+        add(g, "ds_read_b64_tr_b16 {0}, {1} offset:{2}", [("o", "Vf[%d][%d][%d]" % (dt, s, jj)), ("i", "vaddr_c"), ("n", "%d" % (4096 * dt + 1024 * s + 512 * jj))],
+            kind="lds", prio=5)
     # every V^T fragment has landed before PV(A) starts (the K reads of gaps 56.. come later)
-    add(47, 'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);', kind="wait", prio=9)
+    add(47, "s_waitcnt lgkmcnt(0)", [], kind="wait", prio=9)
     # ---------------- K fragment reads of block kb + 1 (K[kt][ks] is free after QK(B)'s MFMA at gap 32 + 8 kt + ks)
     for n in range(16):
         kt, ks = n >> 3, n & 7
         g = 56 + n // 2
         assert g >= 32 + 8 * kt + ks + 2
-        add(g, 'asm volatile("ds_read_b128 %s, %%0 offset:%%1" :: "v"(kaddr[%d]), "i"(KNEXT + %d) : %s);'
-            % (areg(K_(kt, ks), 4), ks, kt * 8192, clob(K_(kt, ks), 4)), kind="lds", prio=5)
+        add(g, "ds_read_b128 %s, {0} offset:{1}" % areg(K_(kt, ks), 4), [("i", "kaddr_n"), ("n", "%d" % (kt * 8192 + ks * 512))], kind="lds", prio=5)
     # ---------------- LDS-DMA of K(kb + 2) and V(kb + 1): early in the block, in the lightest gaps
+    dma = "s_mov_b32 m0, {0}\n\ts_nop 0\n\tbuffer_load_dwordx4 {1}, {2}, {3} offen lds"
     for i in range(4):
-        add(1 + 2 * i, "A2_DMA_K(%d)" % i, kind="dma", prio=5)
-        add(2 + 2 * i, "A2_DMA_V(%d)" % i, kind="dma", prio=5)
+        add(1 + 2 * i, dma, [("s", "dst_k + %d" % (1024 * i)), ("i", "koff"), ("s", "rs_k"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
+        add(2 + 2 * i, dma, [("s", "dst_v + %d" % (4096 * i)), ("i", "voff"), ("s", "rs_v"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
     # O[B] of a tile starts at zero: written in the FIRST block, whose PV(B) gaps carry no MFMA
     for dt in range(4):
         o = O_(1, dt)
-        code = 'asm volatile("' + "\\n\\t".join("v_accvgpr_write_b32 a%d, 0" % (o + i) for i in range(16)) + '" ::: %s);' % clob(o, 16)
-        add(16 + dt, code, "FIRST", prio=5)
+        add(16 + dt, "\n\t".join("v_accvgpr_write_b32 a%d, 0" % (o + i) for i in range(16)), [], "FIRST", kind="init", prio=5)
     return mf, ops
 
 
-def emit(mf, ops, lo, hi, wrap_only, f):
-    """gaps lo..hi-1. wrap_only: the drain stream (what a wave still owes after its last block)."""
+def merged_statement(inss):
+    """ONE asm volatile statement for a list of instructions (hipcc pads every asm statement with an s_nop: a statement per
+    instruction doubled the stream). Operands are unified by expression; an output is early-clobber unless it is also read."""
+    exprs, modes, first = [], {}, {}
+    for ins in inss:
+        # reads of an instruction happen before its writes: order an instruction's operands reads first
+        for mode, e in sorted(ins.operands, key=lambda t: 0 if t[0] in ("i", "io", "s", "n") else 1):
+            if e not in modes:
+                exprs.append(e)
+                modes[e] = set()
+                first[e] = mode
+            modes[e].add(mode)
+    outs = [e for e in exprs if modes[e] & {"o", "io"}]
+    ins_ = [e for e in exprs if not (modes[e] & {"o", "io"})]
+    order = outs + ins_
+    idx = {e: n for n, e in enumerate(order)}
+    lines = []
+    for ins in inss:
+        t = ins.text
+        for n, (mode, e) in reversed(list(enumerate(ins.operands))):
+            t = t.replace("{%d}" % n, "%%%d" % idx[e])
+        lines.append(t)
+    text = "\\n\\t".join(l.replace("\n\t", "\\n\\t") for l in lines)
+    text = text.replace(":\\n\\t", ":\\n\\t")
+    def con(e):
+        m = modes[e]
+        if ("io" in m or "o" in m) and first[e] == "o":
+            return '"=&v"(%s)' % e        # written before it is read: the statement does not need the incoming value
+        if "io" in m or ("o" in m and "i" in m):
+            return '"+&v"(%s)' % e       # early-clobber too: a plain "+v" may share its register with another INPUT that holds
+                                         # the same value (seen: ninf and a reference maximum still at -inf), which the statement
+                                         # then overwrites before its later instructions read that input
+        if "o" in m:
+            return '"=&v"(%s)' % e
+        if "s" in m:
+            return '"s"(%s)' % e
+        if "n" in m:
+            return '"i"(%s)' % e
+        return '"v"(%s)' % e
+    clobbers = ['"memory"'] if any(i.kind in ("wait",) for i in inss) else []
+    if any("vcc" in i.text for i in inss):
+        clobbers.append('"vcc"')
+    clobbers.append("A2_ALLA")
+    return 'asm volatile("%s" : %s : %s : %s);' % (text, ", ".join(con(e) for e in outs), ", ".join(con(e) for e in ins_), ", ".join(clobbers))
+
+
+import re
+TUPLES = ("S", "Pf", "Vf")
+MAXGAPS = int(os.environ.get("A2_MAXGAPS", "4"))   # gaps per asm statement (register allocation degrades with very long ones)
+
+
+def tuple_use(e):
+    """(tuple name, 'whole' / 'elem') of an operand expression, or None."""
+    m = re.match(r"^(S|Pf|Vf)\[(\d)\]\[(\d)\](\[\d+\])?$", e)
+    if not m:
+        return None
+    return ("%s[%s][%s]" % (m.group(1), m.group(2), m.group(3)), "elem" if m.group(4) else "whole")
+
+
+def emit(mf, ops, lo, hi, first, diag, drain, f):
+    """gaps lo..hi-1 of one variant. drain: what a wave still owes after its last block (B's wrapped ops + PV(B)).
+    Consecutive gaps are merged into ONE asm statement for as long as no register tuple would be named both whole (an MFMA
+    operand) and by element (a vector instruction's operand) in it -- the compiler would see two unrelated values."""
     by_gap = {}
     for o in ops:
-        g, cond = o.gap, o.cond
+        g = o.gap
         wrapped = g >= NG
         if wrapped:
             g -= NG
-        if wrap_only and not wrapped:
+        if drain != wrapped and drain:
             continue
-        by_gap.setdefault(g, []).append((o, wrapped))
+        if drain and g < 0:
+            continue
+        if not drain and wrapped and first:
+            continue                      # nothing wraps into a tile's first block
+        if o.cond == "DIAG" and not diag:
+            continue
+        if o.cond == "FIRST" and not first:
+            continue
+        if o.cond == "!FIRST" and first:
+            continue
+        by_gap.setdefault(g, []).append(o)
+    group, uses, ngaps = [], {}, 0
+
+    def flush():
+        nonlocal group, uses, ngaps
+        if group:
+            f.write(merged_statement(group) + "\n")
+        group, uses, ngaps = [], {}, 0
+
+    def push(ins):
+        nonlocal ngaps
+        for mode, e in ins.operands:
+            tu = tuple_use(e)
+            if tu and uses.get(tu[0], tu[1]) != tu[1]:
+                flush()
+                break
+        for mode, e in ins.operands:
+            tu = tuple_use(e)
+            if tu:
+                uses[tu[0]] = tu[1]
+        group.append(ins)
+
+    for o in sorted(by_gap.get(-1, []), key=lambda t: t.prio):
+        push(o)
     for g in range(lo, hi):
-        f.write("// ---- gap %d\n" % g)
         if g in mf:
-            code, cond = mf[g]
-            if wrap_only:
-                if cond == "!FIRST":      # PV(B, last block)
-                    f.write(code + "\n")
-            elif cond:
-                f.write("if constexpr (%s) { %s }\n" % (cond, code))
+            m = mf[g]
+            take = (m.cond == "!FIRST") if drain else not (m.cond == "!FIRST" and first)
+            if take:
+                if first and hasattr(m, "first_text"):
+                    m = Ins(g, m.first_text, m.operands)
+                if diag and hasattr(m, "diag_text"):
+                    m = Ins(g, m.diag_text, [("io", m.operands[0][1])])
+                m2 = Ins(g, "; ---- gap %d\n\t" % g + m.text, m.operands)
+                if ngaps >= MAXGAPS:
+                    flush()
+                ngaps += 1
+                push(m2)
+        for o in sorted(by_gap.get(g, []), key=lambda t: t.prio):
+            if o.raw is not None:           # a C++ statement: closes the running asm statement
+                flush()
+                f.write(o.raw + "\n")
             else:
-                f.write(code + "\n")
-        lst = sorted(by_gap.get(g, []), key=lambda t: t[0].prio)
-        for o, wrapped in lst:
-            conds = []
-            if wrapped and not wrap_only:
-                conds.append("!FIRST")
-            if o.cond:
-                conds.append(o.cond)
-            if conds:
-                f.write("if constexpr (%s) { %s }\n" % (" && ".join(conds), o.code))
-            else:
-                f.write(o.code + "\n")
-        f.write("__builtin_amdgcn_sched_barrier(0);\n")
+                push(o)
+    flush()
 
 
 def report(ops):
@@ -214,25 +320,14 @@ def emit_static(f):
     f.write("#ifdef A2_EMIT_QLOAD\n")
     for h in range(2):
         for ks in range(8):
-            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(kaddr[%d] + qoff) : %s);\n'
-                    % (areg(Q_(h, ks), 4), h * 8192, ks, clob(Q_(h, ks), 4)))
+            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(qaddr) : %s);\n'
+                    % (areg(Q_(h, ks), 4), h * 8192 + ks * 512, clob(Q_(h, ks), 4)))
     f.write("#endif\n#ifdef A2_EMIT_KLOAD\n")   # K fragments of a tile's block 0 (slot 0)
     for kt in range(2):
         for ks in range(8):
-            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(kaddr[%d]) : %s);\n'
-                    % (areg(K_(kt, ks), 4), kt * 8192, ks, clob(K_(kt, ks), 4)))
+            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(kaddr) : %s);\n'
+                    % (areg(K_(kt, ks), 4), kt * 8192 + ks * 512, clob(K_(kt, ks), 4)))
     f.write("#endif\n")
-    # O[half] *= alpha (a row's reference maximum moved): accumulator file -> VGPR -> multiply -> back, 8 at a time
-    for h in range(2):
-        f.write("#ifdef A2_EMIT_RESCALE_%d\n" % h)
-        for c in range(8):
-            lo = O_(h, 0) + 8 * c
-            rd = "\\n\\t".join("v_accvgpr_read_b32 %%%d, a%d" % (i, lo + i) for i in range(8))
-            ml = "\\n\\t".join("v_mul_f32 %%%d, %%8, %%%d" % (i, i) for i in range(8))
-            wr = "\\n\\t".join("v_accvgpr_write_b32 a%d, %%%d" % (lo + i, i) for i in range(8))
-            outs = ", ".join('"=&v"(rt_[%d])' % i for i in range(8))
-            f.write('asm volatile("%s\\n\\t%s\\n\\t%s" : %s : "v"(alpha[%d]) : %s);\n' % (rd, ml, wr, outs, h, clob(lo, 8)))
-        f.write("#endif\n")
     # epilogue: one O^T tile (16 registers) at a time into ov[], A2_OSTORE(half, dt) consumes it
     f.write("#ifdef A2_EMIT_OREAD\n")
     for h in range(2):
@@ -249,10 +344,13 @@ def main():
     last_wrapped = max(o.gap for o in ops) - NG
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_attn256.py -- do not edit. One key block of attn_mfma256_kernel.\n")
-        f.write("#ifdef A2_EMIT_BODY\n")
-        emit(mf, ops, 0, NG, False, f)
-        f.write("#endif\n#ifdef A2_EMIT_DRAIN\n")
-        emit(mf, ops, 0, max(32, last_wrapped + 1), True, f)
+        for first in (0, 1):
+            for diag in (0, 1):
+                f.write("#ifdef A2_EMIT_BODY_%d%d\n" % (first, diag))
+                emit(mf, ops, 0, NG, bool(first), bool(diag), False, f)
+                f.write("#endif\n")
+        f.write("#ifdef A2_EMIT_DRAIN\n")
+        emit(mf, ops, 0, max(32, last_wrapped + 1), False, False, True, f)
         f.write("#endif\n")
         emit_static(f)
     if "-v" in sys.argv:
