@@ -43,6 +43,9 @@ typedef unsigned a2_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned a2_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char a2_lds;
 
+#ifndef A2_BODY_INC
+#define A2_BODY_INC "llama_attn256_body.inc"   // tools/gpu_attn256_abl.sh builds timing-only ablations from other streams
+#endif
 #define A2_ROWS 256
 #define A2_KB 64
 #define A2_RING_BYTES 65536               // 2 slots x (K 16 KiB | V 16 KiB)
@@ -187,7 +190,20 @@ __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", A2_ALLA);
 }
 
+#ifdef A2_ABL_NOBARRIER   // timing-only ablation (wrong results): the waits without the rendezvous
+#define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", A2_ALLA)
+#else
 #define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
+#endif
+
+#ifdef A2_STAMPS   // diagnostic build only (tools/build_attn256_abl.sh stamps): per-block s_memtime deltas, wave 0 of 64 workgroups
+__device__ unsigned long long g_a256_stamps[64 * 12];
+extern "C" int lr_debug_attn256_stamps(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > 64 * 12) LR_FAIL(LR_EINVAL, "lr_debug_attn256_stamps: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_stamps), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
+}
+#endif
 
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict__ qkv, u16* out, const int32_t* cu,
@@ -231,13 +247,13 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   a2_int4 Pf[2][4];
   a2_i64x2 Vf[4][4];
   float t_[2][2], p_[2][4], bt_[2], rt_[8];          // rotating temporaries of the generated stream
-  float m_run[2], lsum[2], negm[2], alpha[2], mx0[2], mx1[2], rowmx[2];   // lsum: the running row sum l
+  float m_run[2], lsum[2], negm[2], alpha[2], mx[2], mthr[2];   // lsum: the running row sum l; mthr: (m + 2^THR) / scale
   int thr[2];
   const float ninf = -__builtin_inff();
   const int soff[4] = {0, 64, 128, 192};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    m_run[h] = lsum[h] = negm[h] = alpha[h] = mx0[h] = mx1[h] = rowmx[h] = 0.f;
+    m_run[h] = lsum[h] = negm[h] = alpha[h] = mx[h] = mthr[h] = 0.f;
     thr[h] = 0;
     t_[h][0] = t_[h][1] = 0.f;
 #pragma unroll
@@ -254,25 +270,32 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #pragma unroll
     for (int s = 0; s < 4; ++s) Vf[dt][s] = a2_i64x2{0, 0};
 
-  for (;;) {
-    // ================================================================ ticket -> tile
-    if (tid == 0) {
-      int item = -1;
-      const int cap = ws_ro[8];
-      for (int a = 0, s = (int)xcc; a < 8; ++a, s = (s + 1) & 7) {   // own stream first, then the neighbours' leftovers
-        const int len = ws_ro[s];
-        if (len <= 0) continue;
-        const int j = atomicAdd(&ctr[s], 1);
-        if (j < len) {
-          item = s * cap + j;
-          break;
-        }
-      }
-      *reinterpret_cast<volatile int*>(smem + A2_CTRL) = item;
+#ifdef A2_STAMPS
+  unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  // ---- tickets. Own XCD's stream first (the tiles of one (segment, head) follow each other there: their K/V blocks meet in
+  // that XCD's L2), then the neighbours' leftovers. The next tile's ticket is drawn at the START of a tile, so that the atomic's
+  // round trip runs beside the tile; only a workgroup whose own stream has run dry pays for the search.
+  const int cap = ws_ro[8], len_own = ws_ro[xcc];
+  auto steal = [&]() {
+    for (int a = 1; a < 8; ++a) {
+      const int s = ((int)xcc + a) & 7, len = ws_ro[s];
+      if (len <= 0) continue;
+      const int j = atomicAdd(&ctr[s], 1);
+      if (j < len) return s * cap + j;
     }
-    __syncthreads();   // also: every wave is done with the previous tile's ring slots
-    const int item = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + A2_CTRL));
-    if (item < 0) break;
+    return -1;
+  };
+  volatile int* const ctrl = reinterpret_cast<volatile int*>(smem + A2_CTRL);
+  if (tid == 0) {
+    const int j = len_own > 0 ? atomicAdd(&ctr[xcc], 1) : len_own;
+    ctrl[0] = j < len_own ? (int)xcc * cap + j : steal();
+  }
+  __syncthreads();
+  int item = __builtin_amdgcn_readfirstlane(ctrl[0]);
+  for (int tile_no = 0; item >= 0; ++tile_no) {
+    int j_next = 0x7fffffff;
+    if (tid == 0 && len_own > 0) j_next = atomicAdd(&ctr[xcc], 1);   // used at the end of this tile
     // an opaque zero, new for every tile: lane arithmetic of the prologue and the epilogue that hipcc would otherwise hoist
     // out of the tile loop (it is loop-invariant) and keep in ~100 registers across the key-block loop -- or spill
     int z_;
@@ -338,13 +361,15 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     if (!dead) {
 #define A2_EMIT_QLOAD
 #define A2_EMIT_KLOAD
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_QLOAD
 #undef A2_EMIT_KLOAD
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);
     }
-    m_run[0] = m_run[1] = -__builtin_inff();
-    lsum[0] = lsum[1] = 0.f;
+    // every wave holds K(0) in registers before any wave's first block sends K(2) into the same ring slot (a wave without live rows
+    // skips the reads and would be a whole block ahead: seen as an intermittent wrong tile)
+    A2_BARRIER();
+    m_run[0] = m_run[1] = mthr[0] = mthr[1] = -__builtin_inff();   // every row's maximum moves in its first block
+    negm[0] = negm[1] = lsum[0] = lsum[1] = 0.f;
 
     // ================================================================ one key block
     auto body = [&](auto first_c, auto diag_c, const int kb) {
@@ -361,21 +386,34 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       }
       if constexpr (FIRST && DIAG) {
 #define A2_EMIT_BODY_11
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_BODY_11
       } else if constexpr (FIRST) {
 #define A2_EMIT_BODY_10
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_BODY_10
       } else if constexpr (DIAG) {
 #define A2_EMIT_BODY_01
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_BODY_01
       } else {
 #define A2_EMIT_BODY_00
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_BODY_00
       }
+#ifdef A2_STAMPS
+      if constexpr (!FIRST && !DIAG) {   // steady-state blocks only: [0..7] eight-gap segments, [8] waits + barrier, [9] blocks
+        unsigned long long te_;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
+                       "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st_acc[i] += st_[i + 1] - st_[i];
+        st_acc[8] += te_ - st_[8];
+        st_acc[9] += 1;
+        st_acc[10] += te_ - st_[0];
+      } else
+#endif
       A2_BARRIER();
     };
     auto idle = [&](const int kb) {   // a wave with no work in this block still moves its share of K(kb + 2) and V(kb + 1)
@@ -398,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       for (int kb = max(n_full, 1); kb <= kl; ++kb) body(BF{}, BT{}, kb);     // the one or two blocks the diagonal crosses
       {   // what the wave still owes after its last block: the rest of B's softmax and PV(B, kl)
 #define A2_EMIT_DRAIN
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_DRAIN
       }
       for (int kb = kl + 1; kb <= kb_wg; ++kb) idle(kb);
@@ -429,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     }                                                                                                              \
   }
 #define A2_EMIT_OREAD
-#include "llama_attn256_body.inc"
+#include A2_BODY_INC
 #undef A2_EMIT_OREAD
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -440,7 +478,14 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         if (q >= P) *reinterpret_cast<a2_u32x4*>(out + (size_t)(vtok0 + q) * nh * hd + h * hd + (ppos ^ (row & 15)) * 8) = v;
       }
     }
+    if (tid == 0) ctrl[(tile_no + 1) & 1] = j_next < len_own ? (int)xcc * cap + j_next : steal();
+    __syncthreads();   // the next ticket is visible; every wave is done with this tile's ring slots
+    item = __builtin_amdgcn_readfirstlane(ctrl[(tile_no + 1) & 1]);
   }
+#ifdef A2_STAMPS
+  if (blockIdx.x < 64 && tid == 0)
+    for (int i = 0; i < 12; ++i) g_a256_stamps[blockIdx.x * 12 + i] = st_acc[i];
+#endif
   // ---- the last workgroup to leave re-arms the counters for the next launch over the same item list
   if (tid == 0) {
     const int d = atomicAdd(&ctr[8], 1);

@@ -1,0 +1,27 @@
+"""Reads the per-segment cycle stamps of the diagnostic build of attention variant 3 (LLAMAREC_LIB=.../abl/libllamarec_stamps.so)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from llamarec_amd._lib import check, stream_ptr, LIB_PATH
+l = C.CDLL(LIB_PATH)
+nh, hd = 32, 128
+lens = [int(x) for x in sys.argv[1:]] or [8192] * 4
+B, n = len(lens), sum(lens)
+qkv = (torch.randn(n, 3 * nh * hd, device="cuda") * 0.5).to(torch.bfloat16)
+out = torch.empty(n, nh * hd, dtype=torch.bfloat16, device="cuda")
+cu_h = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32); cu = torch.from_numpy(cu_h).cuda()
+l.lr_attention_workspace_bytes.restype = C.c_size_t
+wsb = l.lr_attention_workspace_bytes(n, B, nh); ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda")
+for _ in range(3):
+    rc = l.lr_attention_varlen_ws(C.c_void_p(qkv.data_ptr()), C.c_void_p(out.data_ptr()), None, C.c_void_p(cu.data_ptr()), C.c_void_p(cu_h.ctypes.data),
+                                  B, nh, nh, hd, 3, C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), C.c_void_p(stream_ptr()))
+    assert rc == 0
+torch.cuda.synchronize()
+st = np.zeros(64 * 12, dtype=np.uint64)
+assert l.lr_debug_attn256_stamps(st.ctypes.data_as(C.c_void_p), 64 * 12) == 0
+st = st.reshape(64, 12).astype(np.float64)
+blocks = st[:, 9]
+per = st[:, :9] / blocks[:, None]
+print("steady-state blocks per workgroup (wave 0): median %d" % np.median(blocks))
+print("cycles per 8-gap segment (median over 64 workgroups):", " ".join("%.0f" % x for x in np.median(per[:, :8], 0)))
+print("waits + barrier: %.0f   block total: %.0f   (64 MFMAs = 2048 cycles)" % (np.median(per[:, 8]), np.median(st[:, 10] / blocks)))

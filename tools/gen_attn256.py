@@ -23,7 +23,31 @@ e0+i+2, v_cvt_pk_bf16_f32 of a pair behind its second add: one exp per gap, ever
 import os
 import sys
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "llamarec_amd", "csrc", "llama_attn256_body.inc")
+OUT = os.environ.get("A2_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "llamarec_amd", "csrc", "llama_attn256_body.inc")
+# timing-only ablation builds (tools/gpu_attn256_abl.sh; results are WRONG): a comma list of
+#   nodma notr nokr noe nomax nobk nowait mfmaonly
+ABL = set(x for x in os.environ.get("A2_ABL", "").split(",") if x)
+
+
+def ablated(ins):
+    t = ins.text or ""
+    if "mfmaonly" in ABL:
+        return True
+    if "nodma" in ABL and "buffer_load" in t:
+        return True
+    if "notr" in ABL and "ds_read_b64_tr" in t:
+        return True
+    if "nokr" in ABL and "ds_read_b128" in t:
+        return True
+    if "noe" in ABL and (t.startswith("v_fmamk") or t.startswith("v_exp_f32 {0}, {1}") or t.startswith("v_add_f32 {0}, {0}") or t.startswith("v_cvt_pk")):
+        return True
+    if "nomax" in ABL and (t.startswith("v_max3") or t.startswith("v_max_f32 {0}, {0}")):
+        return True
+    if "nobk" in ABL and ins.kind == "bk":
+        return True
+    if "nowait" in ABL and ins.kind == "wait":
+        return True
+    return False
 
 NG = 64
 
@@ -97,38 +121,48 @@ def build():
                 c = 32 * kt + (rr & 3) + 8 * (rr >> 2)
                 add(g0 + (rr >> 1) if g0 >= 0 else -1, "v_cmp_gt_i32 vcc, %d, {1}\n\tv_cndmask_b32 {0}, 0, {2}, vcc" % c,
                     [("o", "S[%d][%d][%d]" % (h, kt, rr)), ("i", "thr[%d]" % h), ("i", "ninf")], "DIAG", kind="mask", prio=1)
-        # row maximum: 8 v_max3 / v_max per 16-value tile; S[h][0] is complete after gap gb+7, S[h][1] after gb+15 and an
-        # asm MFMA's result may be read two gaps later at the earliest (nothing pads an asm statement's hazards)
-        for kt, g_first, per_gap in ((0, gb + 9, 1), (1, gb + 17, 2)):
-            v = "S[%d][%d]" % (h, kt)
-            mx = "mx%d[%d]" % (kt, h)
-            seq = [("v_max3_f32 {0}, {1}, {2}, {3}", [("o", mx), ("i", v + "[0]"), ("i", v + "[1]"), ("i", v + "[2]")])]
-            for j in range(1, 7):
-                seq.append(("v_max3_f32 {0}, {0}, {1}, {2}", [("io", mx), ("i", "%s[%d]" % (v, 2 * j + 1)), ("i", "%s[%d]" % (v, 2 * j + 2))]))
-            seq.append(("v_max_f32 {0}, {0}, {1}", [("io", mx), ("i", v + "[15]")]))
-            for n, (t, o) in enumerate(seq):
-                add(g_first + n // per_gap, t, o, prio=2)
-        g = gb + 21
+        # row maximum (this lane's 32 keys of the row): one chain over both tiles, 8 v_max3 each; S[h][0] is complete after gap
+        # gb+7, S[h][1] after gb+15, and an asm MFMA's result may be read two gaps later at the earliest (nothing pads it)
         H = h
-        # row maximum of the block: the two key tiles, then the two lane halves of a row (v_permlane32_swap of two copies)
-        add(g, "v_max_f32 {0}, {2}, {3}\n\tv_max_f32 {1}, {2}, {3}\n\ts_nop 1\n\tv_permlane32_swap_b32 {0}, {1}\n\ts_nop 1\n\tv_max_f32 {4}, {0}, {1}",
-            [("o", "bt_[0]"), ("o", "bt_[1]"), ("i", "mx0[%d]" % H), ("i", "mx1[%d]" % H), ("o", "rowmx[%d]" % H)], kind="bk", prio=2)
-        # mxs = rowmax * scale; need (vcc) = mxs > m + 2^THR; m' = need ? mxs : m; alpha = 2^(m - m'); -m'; the row sum carries on
-        # from l * alpha; O[half] *= alpha if some row's reference maximum moved (not in a tile's first block: O starts there)
-        bk1 = ("v_mul_f32 {4}, 0x3e0293ee, {6}\n\tv_add_f32 {5}, 0x41000000, {0}\n\tv_cmp_gt_f32 vcc, {4}, {5}\n\t"
-               "v_cndmask_b32 {4}, {0}, {4}, vcc\n\tv_sub_f32 {5}, {0}, {4}\n\tv_exp_f32 {2}, {5}\n\tv_mov_b32 {0}, {4}\n\t"
-               "v_xor_b32 {1}, 0x80000000, {4}\n\ts_nop 0\n\tv_mul_f32 {3}, {3}, {2}")
-        opr = [("io", "m_run[%d]" % H), ("o", "negm[%d]" % H), ("o", "alpha[%d]" % H), ("io", "lsum[%d]" % H), ("o", "bt_[0]"), ("o", "bt_[1]"),
-               ("i", "rowmx[%d]" % H)]
-        add(g + 1, bk1, opr, kind="bk", prio=2)
-        resc = ["s_cbranch_vccz .La2_keep%d_%%="  % H]
+        mx = "mx[%d]" % H
+        v0, v1 = "S[%d][0]" % H, "S[%d][1]" % H
+        seq = [("v_max3_f32 {0}, {1}, {2}, {3}", [("o", mx), ("i", v0 + "[0]"), ("i", v0 + "[1]"), ("i", v0 + "[2]")])]
+        for j in range(1, 7):
+            seq.append(("v_max3_f32 {0}, {0}, {1}, {2}", [("io", mx), ("i", "%s[%d]" % (v0, 2 * j + 1)), ("i", "%s[%d]" % (v0, 2 * j + 2))]))
+        seq.append(("v_max_f32 {0}, {0}, {1}", [("io", mx), ("i", v0 + "[15]")]))
+        for n, (t, o) in enumerate(seq):
+            add(gb + 9 + n, t, o, prio=2)
+        for j in range(8):
+            add(gb + 17 + j // 2, "v_max3_f32 {0}, {0}, {1}, {2}", [("io", mx), ("i", "%s[%d]" % (v1, 2 * j)), ("i", "%s[%d]" % (v1, 2 * j + 1))], prio=2)
+        # Deferred maximum. Common path: does this lane's maximum exceed the row's cached raw threshold (m + 2^THR) / scale? The two
+        # lanes of a row are combined on the scalar side; nothing else happens while no row of the half moves. Rare path (always in
+        # a tile's first block): the row maximum across the lane halves, m' = need ? max * scale : m, alpha = 2^(m - m'), -m', the
+        # new threshold, the row sum and O[half] (not in a first block: O starts there) times alpha. alpha = 1 exactly for the rows
+        # that keep their m, so the rows of a tile do not couple.
+        g = gb + 21
+        rare = ["v_cmp_gt_f32 vcc, {0}, {1}", "s_or_b32 vcc_lo, vcc_lo, vcc_hi", "s_mov_b32 vcc_hi, vcc_lo",
+                "s_mov_b64 vcc, vcc",            # gfx9: a write of one half of VCC leaves VCCZ stale
+                "s_cbranch_vccz .La2_keep%d_%%=" % H,
+                "v_mov_b32 {2}, {0}", "v_mov_b32 {3}, {0}", "s_nop 1", "v_permlane32_swap_b32 {2}, {3}", "s_nop 1", "v_max_f32 {2}, {2}, {3}",
+                "v_mul_f32 {2}, 0x3e0293ee, {2}",            # scaled row maximum
+                "v_cndmask_b32 {2}, {4}, {2}, vcc",           # m'
+                "v_sub_f32 {3}, {4}, {2}", "v_exp_f32 {5}, {3}", "v_mov_b32 {4}, {2}", "v_xor_b32 {6}, 0x80000000, {2}",
+                "v_add_f32 {3}, 0x41000000, {2}", "v_mul_f32 {1}, 0x40fae54b, {3}",   # (m' + 8) / scale: 1 / scale = 7.84316
+                "s_nop 0", "v_mul_f32 {7}, {7}, {5}"]
+        opr = [("i", mx), ("io", "mthr[%d]" % H), ("o", "bt_[0]"), ("o", "bt_[1]"), ("io", "m_run[%d]" % H), ("o", "alpha[%d]" % H),
+               ("io", "negm[%d]" % H), ("io", "lsum[%d]" % H)]
+        resc = []
         for c in range(8):
             lo = O_(H, 0) + 8 * c
-            resc += ["v_accvgpr_read_b32 {%d}, a%d" % (1 + i, lo + i) for i in range(8)]
-            resc += ["v_mul_f32 {%d}, {0}, {%d}" % (1 + i, 1 + i) for i in range(8)]
-            resc += ["v_accvgpr_write_b32 a%d, {%d}" % (lo + i, 1 + i) for i in range(8)]
-        resc += [".La2_keep%d_%%=:" % H]
-        add(g + 1, "\n\t".join(resc), [("i", "alpha[%d]" % H)] + [("o", "rt_[%d]" % i) for i in range(8)], cond="!FIRST", kind="bk", prio=3)
+            resc += ["v_accvgpr_read_b32 {%d}, a%d" % (8 + i, lo + i) for i in range(8)]
+            resc += ["v_mul_f32 {%d}, {5}, {%d}" % (8 + i, 8 + i) for i in range(8)]
+            resc += ["v_accvgpr_write_b32 a%d, {%d}" % (lo + i, 8 + i) for i in range(8)]
+        ropr = [("o", "rt_[%d]" % i) for i in range(8)]
+        tail = [".La2_keep%d_%%=:" % H]
+        bk = Ins(g, "\n\t".join(rare + resc + tail), opr + ropr, kind="bk", prio=3)
+        bk.first_text = "\n\t".join(rare + tail)
+        bk.first_operands = opr
+        ops.append(bk)
         # E-phase (temporaries rotate: t lives one gap, p at most three)
         e0 = gb + 23
         for i in range(32):
@@ -162,6 +196,10 @@ def build():
     for i in range(4):
         add(1 + 2 * i, dma, [("s", "dst_k + %d" % (1024 * i)), ("i", "koff"), ("s", "rs_k"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
         add(2 + 2 * i, dma, [("s", "dst_v + %d" % (4096 * i)), ("i", "voff"), ("s", "rs_v"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
+    if os.environ.get("A2_STAMPS"):   # diagnostic build (tools/build_attn256_abl.sh stamps): where a block's cycles go
+        for k in range(8):
+            add(8 * k, "s_memtime {0}", [("so", "st_[%d]" % k)], kind="stamp", prio=0)
+        add(63, "s_memtime {0}", [("so", "st_[8]")], kind="stamp", prio=99)
     # O[B] of a tile starts at zero: written in the FIRST block, whose PV(B) gaps carry no MFMA
     for dt in range(4):
         o = O_(1, dt)
@@ -176,13 +214,15 @@ def merged_statement(inss):
     for ins in inss:
         # reads of an instruction happen before its writes: order an instruction's operands reads first
         for mode, e in sorted(ins.operands, key=lambda t: 0 if t[0] in ("i", "io", "s", "n") else 1):
+            if mode == "so":
+                first[e] = "o"
             if e not in modes:
                 exprs.append(e)
                 modes[e] = set()
                 first[e] = mode
             modes[e].add(mode)
-    outs = [e for e in exprs if modes[e] & {"o", "io"}]
-    ins_ = [e for e in exprs if not (modes[e] & {"o", "io"})]
+    outs = [e for e in exprs if modes[e] & {"o", "io", "so"}]
+    ins_ = [e for e in exprs if not (modes[e] & {"o", "io", "so"})]
     order = outs + ins_
     idx = {e: n for n, e in enumerate(order)}
     lines = []
@@ -203,6 +243,8 @@ def merged_statement(inss):
                                          # then overwrites before its later instructions read that input
         if "o" in m:
             return '"=&v"(%s)' % e
+        if "so" in m:
+            return '"=&s"(%s)' % e
         if "s" in m:
             return '"s"(%s)' % e
         if "n" in m:
@@ -211,6 +253,8 @@ def merged_statement(inss):
     clobbers = ['"memory"'] if any(i.kind in ("wait",) for i in inss) else []
     if any("vcc" in i.text for i in inss):
         clobbers.append('"vcc"')
+    if any("s_or_b32" in i.text for i in inss):
+        clobbers.append('"scc"')          # hipcc keeps loop conditions in SCC across a statement that does not name it (seen: a hang)
     clobbers.append("A2_ALLA")
     return 'asm volatile("%s" : %s : %s : %s);' % (text, ", ".join(con(e) for e in outs), ", ".join(con(e) for e in ins_), ", ".join(clobbers))
 
@@ -250,6 +294,10 @@ def emit(mf, ops, lo, hi, first, diag, drain, f):
             continue
         if o.cond == "!FIRST" and first:
             continue
+        if ABL and ablated(o):
+            continue
+        if first and hasattr(o, "first_text"):
+            o = Ins(o.gap, o.first_text, o.first_operands, kind=o.kind, prio=o.prio)
         by_gap.setdefault(g, []).append(o)
     group, uses, ngaps = [], {}, 0
 

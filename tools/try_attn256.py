@@ -42,7 +42,7 @@ if __name__ == "__main__":
     ok = True
     for (lens, nh, nkv, scale) in [([64], 8, 8, 1.0), ([1, 63, 64, 65, 128, 129, 300, 2, 256, 257, 600], 8, 8, 1.0),
                                    ([255, 511, 513, 1125, 740], 8, 2, 1.0), ([700, 33], 3, 1, 3.0), ([2048], 8, 8, 0.5)]:
-        for var in (3, 2):
+        for var in (3, 3, 2):
             qkv, out, lse, cu = run(lens, nh, nkv, 128, var, scale)
             r, rl = ref(qkv, cu, nh, nkv, 128)
             e = np.abs(out - r); el = np.abs(lse - rl)
@@ -52,5 +52,9 @@ if __name__ == "__main__":
             if var == 3 and (bad.any() or e.max() > 2e-2 * max(1.0, scale) or el.max() > 2e-2):
                 ok = False
                 rows = np.where((e.max(1) > 2e-2 * max(1.0, scale)) | bad.any(1))[0]
-                print("   bad rows (first 20):", rows[:20], "of", len(rows), flush=True)
+                for b in range(len(cu) - 1):
+                    rb = rows[(rows >= cu[b]) & (rows < cu[b + 1])] - cu[b]
+                    if len(rb):
+                        heads = sorted(set(int(hh) for r_ in rb for hh in np.where(e[cu[b] + r_].reshape(nh, -1).max(1) > 2e-2 * max(1.0, scale))[0]))
+                        print("   segment %d (T=%d): %d bad rows, local %d..%d, heads %s" % (b, cu[b + 1] - cu[b], len(rb), rb.min(), rb.max(), heads), flush=True)
     print("OK" if ok else "FAILED")
