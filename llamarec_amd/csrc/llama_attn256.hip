@@ -190,6 +190,9 @@ __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", A2_ALLA);
 }
 
+// a tile's first block: the wave's 16 output-row stores of the previous tile are YOUNGER than this block's operands (pre_issue)
+// and may still be in flight
+#define A2_BARRIER_16() asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
 #ifdef A2_ABL_NOBARRIER   // timing-only ablation (wrong results): the waits without the rendezvous
 #define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", A2_ALLA)
 #else
@@ -203,12 +206,27 @@ extern "C" int lr_debug_attn256_stamps(unsigned long long* out, int n) {
   LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_stamps), (size_t)n * sizeof(unsigned long long)));
   return LR_OK;
 }
+__device__ unsigned long long g_a256_phases[64 * 2 * 8];   // [workgroup][wave 0 | wave 3][prologue, blocks, drain+idle, epilogue, seam, tiles]
+extern "C" int lr_debug_attn256_phases(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > 64 * 16) LR_FAIL(LR_EINVAL, "lr_debug_attn256_phases: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_phases), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
+}
+#define A2_PHASE(i)                                                                          \
+  {                                                                                          \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory", A2_ALLA);      \
+    ph_acc[i] += t_ - ph_prev;                                                               \
+    ph_prev = t_;                                                                            \
+  }
+#else
+#define A2_PHASE(i)
 #endif
 
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict__ qkv, u16* out, const int32_t* cu,
                                                            int prefix_len, int nh, int nkv, const int32_t* ws_ro,
-                                                           int32_t* ctr, float* lse) {
+                                                           int32_t* ctr, float* lse, unsigned qkv_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int hd = 128;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -228,7 +246,6 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   //  V piece (column group G, key group g): lane L <- key 16 g + (L >> 2), bytes 64 G + 16 (L & 3). Wave w moves group w of both,
   //  so the per-lane source offset is one constant per operand and the piece index is the load's scalar offset (64 p).
   const unsigned kaddr = lds0 + (r >> 4) * 4096 + (r & 15) * 16 + hi * 256;           // + 512 ks + 8192 kt + slot
-  const unsigned qaddr = kaddr + A2_QBUF + wave * 16384;                             // + 512 ks + 8192 half
   const unsigned qoff = A2_QBUF + wave * 16384;                                      // the wave's own Q / O rows
   unsigned vaddr;                                                                    // + 4096 dt + 1024 s + 512 jj + slot
   {
@@ -272,10 +289,12 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 
 #ifdef A2_STAMPS
   unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_prev)::"memory");
 #endif
   // ---- tickets. Own XCD's stream first (the tiles of one (segment, head) follow each other there: their K/V blocks meet in
-  // that XCD's L2), then the neighbours' leftovers. The next tile's ticket is drawn at the START of a tile, so that the atomic's
-  // round trip runs beside the tile; only a workgroup whose own stream has run dry pays for the search.
+  // that XCD's L2), then the neighbours' leftovers. A workgroup always knows its current AND its next tile (the K / V / Q stream
+  // runs across the seam); the ticket of the tile after that is drawn at the start of a tile and read at its end.
   const int cap = ws_ro[8], len_own = ws_ro[xcc];
   auto steal = [&]() {
     for (int a = 1; a < 8; ++a) {
@@ -286,103 +305,171 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     }
     return -1;
   };
+  auto draw = [&]() {
+    const int j = len_own > 0 ? atomicAdd(&ctr[xcc], 1) : 0;
+    return j < len_own ? (int)xcc * cap + j : steal();
+  };
   volatile int* const ctrl = reinterpret_cast<volatile int*>(smem + A2_CTRL);
-  if (tid == 0) {
-    const int j = len_own > 0 ? atomicAdd(&ctr[xcc], 1) : len_own;
-    ctrl[0] = j < len_own ? (int)xcc * cap + j : steal();
-  }
+  if (tid == 0) ctrl[0] = draw();
   __syncthreads();
-  int item = __builtin_amdgcn_readfirstlane(ctrl[0]);
-  for (int tile_no = 0; item >= 0; ++tile_no) {
-    int j_next = 0x7fffffff;
-    if (tid == 0 && len_own > 0) j_next = atomicAdd(&ctr[xcc], 1);   // used at the end of this tile
-    // an opaque zero, new for every tile: lane arithmetic of the prologue and the epilogue that hipcc would otherwise hoist
-    // out of the tile loop (it is loop-invariant) and keep in ~100 registers across the key-block loop -- or spill
-    int z_;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z_));
-    const int2 it = items[item];
+
+  // ---- a tile's scalars
+  struct Tile {
+    int T, P, row0, kb_wg, vtok0, hcol;   // hcol: the head's first q column (elements)
+    const char* kbase;                    // K element 0 of the sequence's position 0 in this head (own rows: position p >= P)
+    int rec0;                             // bytes from there to the end of the sequence's last V row
+    int kcol;                             // the head's first K column (elements)
+    bool valid;
+  };
+  const int kv_tail = (nkv * hd + hd) * 2;                        // bytes from a row's K element 0 to the end of its V row
+  const unsigned blk_bytes = (unsigned)A2_KB * stride * 2;        // one key block of rows
+  auto decode = [&](int item) {
+    Tile t;
+    t.valid = item >= 0;
+    const int2 it = items[t.valid ? item : 0];
     const int seg = __builtin_amdgcn_readfirstlane(it.x);
     const int h = __builtin_amdgcn_readfirstlane(it.y >> 16), tk = __builtin_amdgcn_readfirstlane(it.y & 0xffff);
     const int tok0 = cu[seg];
-    const int P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;   // keys [0, P) live in segment 0's rows [0, P)
-    const int T = P + cu[seg + 1] - tok0;
-    const int row0 = T - A2_ROWS * (tk + 1);                      // may be negative for a sequence's first tile
+    t.P = (prefix_len > 0 && seg > 0) ? prefix_len : 0;           // keys [0, P) live in segment 0's rows [0, P)
+    t.T = t.P + cu[seg + 1] - tok0;
+    t.row0 = t.T - A2_ROWS * (tk + 1);                            // may be negative for a sequence's first tile
+    t.kb_wg = (t.row0 + A2_ROWS - 1) >> 6;                        // the tile's last key block
+    t.vtok0 = tok0 - t.P;                                         // the row of position p >= P is vtok0 + p
+    t.hcol = h * hd;
+    t.kcol = (nh + h / (nh / nkv)) * hd;
+    t.kbase = reinterpret_cast<const char*>(qkv + (size_t)t.vtok0 * stride + t.kcol);
+    t.rec0 = (t.T - 1) * stride * 2 + kv_tail;
+    return t;
+  };
+  // descriptor of key block kbx of a tile's OWN rows: rows past T - 1 are range-checked to zero; kbx > kb_wg: nothing
+  auto own_rsrc = [&](const Tile& t, int kbx) {
+    const unsigned off = (unsigned)kbx * blk_bytes;
+    int rec = t.rec0 - (int)off;
+    if (kbx > t.kb_wg || !t.valid) rec = 0;
+    return a2_make_rsrc(t.kbase + off, rec);
+  };
+  // Source of key block kbx of the STREAM that starts at tile `c` and runs on into tile `n` (its blocks 0 and 1 only): the
+  // descriptor, and the per-lane byte offset to ADD to koff / voff (non-zero only for block 0 of a tile that shares a prefix:
+  // one descriptor over the whole buffer, own rows shifted by the segment's first row; a key past the sequence end then reads
+  // the following rows -- finite, and causally masked for every live query row -- where an own-rows descriptor zero-fills).
+  auto stream_src = [&](const Tile& c, const Tile& n, int kbx, int key_lane, a2_int4& rs, unsigned& delta) {
+    delta = 0;
+    if (kbx <= c.kb_wg) {
+      rs = own_rsrc(c, kbx);
+      return;
+    }
+    const int j = kbx - c.kb_wg - 1;
+    if (!n.valid || j > 1 || j > n.kb_wg) {
+      rs = a2_make_rsrc(qkv, 0);
+    } else if (j == 0 && n.P > 0) {
+      const long long left = (long long)qkv_bytes - (long long)n.kcol * 2;
+      rs = a2_make_rsrc(reinterpret_cast<const char*>(qkv + n.kcol), (int)(left > 0x7fffffffLL ? 0x7fffffffLL : left));
+      delta = key_lane >= n.P ? (unsigned)n.vtok0 * (unsigned)stride * 2u : 0u;
+    } else {
+      rs = own_rsrc(n, j);
+    }
+  };
+  const int klane_k = 16 * wave + (lane & 15), klane_v = 16 * wave + (lane >> 2);   // the key (in its block) a lane stages
+
+  // synchronous staging of one block with per-lane source addresses (a workgroup's first tile; block 0 behind a one-block tile):
+  // keys < P come from segment 0's rows, keys >= T are clamped to T - 1
+  auto stage_sync = [&](const Tile& t, int kbx, int slot, bool do_k, bool do_v) {
+    const unsigned dst = lds0 + slot * 32768 + wave * 4096;
+    const int kk = min(kbx * A2_KB + klane_k, t.T - 1), kv = min(kbx * A2_KB + klane_v, t.T - 1);
+    const unsigned ok = (unsigned)(((kk < t.P ? kk : t.vtok0 + kk) * stride + t.kcol) * 2 + (lane >> 4) * 16);
+    const unsigned ov = (unsigned)(((kv < t.P ? kv : t.vtok0 + kv) * stride + t.kcol + nkv * hd) * 2 + (lane & 3) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (do_k) a2_glds16(qkv, ok + i * 64, dst + i * 1024);
+      if (do_v) a2_glds16(qkv, ov + i * 64, dst + 16384 + i * 4096 - wave * 3072);
+    }
+  };
+  // Q fragments of a tile straight from global memory into a[128:191] (B operand: lane = row 32 half + (l & 31), 16 bytes at
+  // 32 ks + 16 (l >> 5)); rows outside [P, T) are clamped (computed, never stored)
+  auto q_load = [&](const Tile& t) {
+    const int q0 = t.row0 + 64 * wave;
+    unsigned qvo[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int qr = min(max(q0 + 32 * hf + r, t.P), t.T - 1);
+      qvo[hf] = (unsigned)((t.vtok0 + qr) * stride + t.hcol) * 2u + hi * 16;
+    }
+#define A2_EMIT_QGLOAD
+#include A2_BODY_INC
+#undef A2_EMIT_QGLOAD
+  };
+  auto k_load = [&](int slot) {   // K fragments of the block in ring slot `slot` -> a[192:255]
+    const unsigned kaddr_n = kaddr + slot * 32768;
+#define A2_EMIT_KLOAD
+#include A2_BODY_INC
+#undef A2_EMIT_KLOAD
+  };
+
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      out, 0, (int)((size_t)qkv_bytes / (unsigned)(nh + 2 * nkv) * (unsigned)nh), 0x00020000);
+  // A workgroup draws its SECOND ticket only after its first tile's requests are on their way: two draws in a row would hand it
+  // two consecutive items -- two tiles of ONE (segment, head) -- which then run one after the other on this CU instead of side
+  // by side on two CUs of the XCD, and their K/V blocks no longer meet in L2 (measured: L2 hit rate 0.58 -> 0.40).
+  Tile cur = decode(__builtin_amdgcn_readfirstlane(ctrl[0]));
+  int gblk = 0;            // running index of the current tile's block 0 in the workgroup's block stream: ring slot = index & 1
+  int prev_blocks = 0;     // key blocks of the previous tile (0: none): what of the current tile was streamed in behind it
+  bool had_epilogue = false;   // this wave stored output rows at the end of the previous tile
+  // K(2) and V(1) of a tile -- what its first block would request -- are requested behind the previous tile's last barrier
+  // instead: in front of that tile's output stores in the wave's vector-memory queue, so that the first block waits for its
+  // operands with vmcnt(16) and not for those stores (they take 6-8 k cycles to drain: measured)
+  auto pre_issue = [&](const Tile& t, int g0) {
+    const int par = (g0 & 1) * 32768;
+    const a2_int4 rs_k = own_rsrc(t, 2), rs_v = own_rsrc(t, 1);
+    const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a2_dma16(rs_k, dst_k + i * 1024, koff, i * 64);
+      a2_dma16(rs_v, dst_v + i * 4096, voff, i * 64);
+    }
+  };
+  if (cur.valid && cur.row0 + 64 * wave + 63 >= cur.P) q_load(cur);   // the workgroup's first tile: nothing was streamed in
+  if (tid == 0) ctrl[1] = cur.valid ? draw() : -1;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);
+  Tile nxt = decode(__builtin_amdgcn_readfirstlane(ctrl[1]));
+  for (int tile_no = 0; cur.valid; ++tile_no) {
+    int item_nn = -1;      // the tile after next (drawn by wave 0 in its slack behind its last key block)
+    const int T = cur.T, P = cur.P, row0 = cur.row0, kb_wg = cur.kb_wg, vtok0 = cur.vtok0;
     const int q0 = row0 + 64 * wave;
-    const int kb_wg = (row0 + A2_ROWS - 1) >> 6;                  // the tile's last key block
     const bool dead = q0 + 63 < P;                                // no live row in this wave
     const int n_full = q0 >= 0 ? (q0 + 1) >> 6 : 0;               // blocks every row of the wave sees unmasked
     const int kl = dead ? -1 : (q0 + 63) >> 6;                    // the wave's last block
-    const int kvh = __builtin_amdgcn_readfirstlane(h / (nh / nkv));
-    const int vtok0 = tok0 - P;                                   // the row of position p >= P is vtok0 + p
-    const char* kbase = reinterpret_cast<const char*>(qkv + (size_t)vtok0 * stride + (nh + kvh) * hd);
-    const char* pkbase = reinterpret_cast<const char*>(qkv + (nh + kvh) * hd);   // prefix rows start at packed row 0
-    const unsigned blk_bytes = (unsigned)A2_KB * stride * 2;      // < 2^31 / blocks: lr_launch_attention256 checks n_tok
-    const int kv_tail = (nkv * hd + hd) * 2;                      // bytes from a row's K element 0 to the end of its V row
-    const int rec0 = (T - 1) * stride * 2 + kv_tail;              // bytes from the sequence's K element 0 to its end
-    int qm[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) qm[hf] = max(q0 + 32 * hf + r, 0);
-
-    // descriptor of key block kbx of this tile's own rows: rows past T - 1 are range-checked to zero; kbx > kb_wg: nothing
-    auto own_rsrc = [&](int kbx) {
-      const unsigned off = (unsigned)kbx * blk_bytes;
-      int rec = rec0 - (int)off;
-      if (kbx > kb_wg) rec = 0;
-      return a2_make_rsrc(kbase + off, rec);
-    };
-    // prologue staging of one block with per-lane source addresses: keys < P come from segment 0's rows, keys >= T are
-    // clamped to T - 1 (they are causally masked for every live row; the descriptor path zero-fills them instead)
-    auto stage_generic = [&](int kbx, bool do_k, bool do_v) {
-      const unsigned dst = lds0 + (kbx & 1) * 32768 + wave * 4096;
-      const int kk = min(kbx * A2_KB + 16 * wave + (lane & 15), T - 1), kv = min(kbx * A2_KB + 16 * wave + (lane >> 2), T - 1);
-      const unsigned ok = (unsigned)(((kk < P ? kk : vtok0 + kk) * stride + (nh + kvh) * hd) * 2 + (lane >> 4) * 16);
-      const unsigned ov = (unsigned)(((kv < P ? kv : vtok0 + kv) * stride + (nh + nkv + kvh) * hd) * 2 + (lane & 3) * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (do_k) a2_glds16(qkv, ok + i * 64, dst + i * 1024);
-        if (do_v) a2_glds16(qkv, ov + i * 64, dst + 16384 + i * 4096 - wave * 3072);
-      }
-    };
-
-    // ================================================================ prologue: Q, K(0), K(1), V(0)
-    if (!dead) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = 16 * g + ((lane & 15) | z_);
-        const int qr = min(max(q0 + row, P), T - 1);
-        const unsigned qo = (unsigned)((vtok0 + qr) * stride + h * hd) * 2u + (lane >> 4) * 16;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) a2_glds16(qkv, qo + p * 64, lds0 + qoff + g * 4096 + p * 1024);
-      }
+    if (prev_blocks < 3) {
+      // Not everything was streamed in behind the previous tile: K(0) needs a previous tile of >= 3 blocks (requested in its block
+      // kb_wg - 1, which must not be ITS pre-issued block 0), K(1) and V(0) one of >= 2. Stage what is missing now, then every
+      // wave reads K(0) BEFORE this tile's K(2) goes into the same ring slot.
+      const bool none = prev_blocks < 2;
+      stage_sync(cur, 0, gblk & 1, true, none);
+      if (none) stage_sync(cur, 1, (gblk + 1) & 1, true, false);
+      A2_BARRIER();
+      if (!dead) k_load(gblk & 1);
+      A2_BARRIER();
+      pre_issue(cur, gblk);
+      had_epilogue = false;   // (the first block then waits for everything)
     }
-    stage_generic(0, true, true);
-    stage_generic(1, true, false);
-    A2_BARRIER();
-    if (!dead) {
-#define A2_EMIT_QLOAD
-#define A2_EMIT_KLOAD
-#include A2_BODY_INC
-#undef A2_EMIT_QLOAD
-#undef A2_EMIT_KLOAD
-    }
-    // every wave holds K(0) in registers before any wave's first block sends K(2) into the same ring slot (a wave without live rows
-    // skips the reads and would be a whole block ahead: seen as an intermittent wrong tile)
-    A2_BARRIER();
     m_run[0] = m_run[1] = mthr[0] = mthr[1] = -__builtin_inff();   // every row's maximum moves in its first block
     negm[0] = negm[1] = lsum[0] = lsum[1] = 0.f;
+    A2_PHASE(0)   // seam
 
     // ================================================================ one key block
     auto body = [&](auto first_c, auto diag_c, const int kb) {
       constexpr bool FIRST = decltype(first_c)::value, DIAG = decltype(diag_c)::value;
-      const int par = (kb & 1) * 32768;                   // K(kb), V(kb) and K(kb + 2) live in slot kb & 1; K(kb + 1), V(kb + 1) in the other
-      const a2_int4 rs_k = own_rsrc(kb + 2), rs_v = own_rsrc(kb + 1);
+      const int par = ((gblk + kb) & 1) * 32768;          // K(kb), V(kb) and K(kb + 2) use this slot; K(kb + 1), V(kb + 1) the other
+      a2_int4 rs_k, rs_v;
+      unsigned dk, dv;
+      stream_src(cur, nxt, kb + 2, klane_k, rs_k, dk);
+      stream_src(cur, nxt, kb + 1, klane_v, rs_v, dv);
+      const unsigned koff_x = koff + dk, voff_x = voff + dv;
       const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
       const unsigned kaddr_n = kaddr + (par ^ 32768), vaddr_c = vaddr + par + 16384;
-      (void)rt_; (void)bt_; (void)t_; (void)p_; (void)soff; (void)ninf; (void)kaddr_n; (void)vaddr_c;   // named here so that the generic lambda captures them (the
-                                                                          // asm operands inside the if-constexpr arms alone do not)
+      (void)rt_; (void)bt_; (void)t_; (void)p_; (void)soff; (void)ninf; (void)kaddr_n; (void)vaddr_c; (void)koff_x; (void)voff_x;
       if constexpr (DIAG) {
-        thr[0] = qm[0] - kb * A2_KB - 4 * hi;
-        thr[1] = qm[1] - kb * A2_KB - 4 * hi;
+        thr[0] = max(q0 + r, 0) - kb * A2_KB - 4 * hi;
+        thr[1] = max(q0 + 32 + r, 0) - kb * A2_KB - 4 * hi;
       }
       if constexpr (FIRST && DIAG) {
 #define A2_EMIT_BODY_11
@@ -414,34 +501,70 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         st_acc[10] += te_ - st_[0];
       } else
 #endif
-      A2_BARRIER();
+      if (FIRST && had_epilogue) A2_BARRIER_16(); else A2_BARRIER();
     };
     auto idle = [&](const int kb) {   // a wave with no work in this block still moves its share of K(kb + 2) and V(kb + 1)
-      const a2_int4 rs_k = own_rsrc(kb + 2), rs_v = own_rsrc(kb + 1);
-      const unsigned dst_k = lds0 + (kb & 1) * 32768 + wave * 4096, dst_v = lds0 + ((kb + 1) & 1) * 32768 + 16384 + wave * 1024;
+      const int par = ((gblk + kb) & 1) * 32768;
+      a2_int4 rs_k, rs_v;
+      unsigned dk, dv;
+      stream_src(cur, nxt, kb + 2, klane_k, rs_k, dk);
+      stream_src(cur, nxt, kb + 1, klane_v, rs_v, dv);
+      const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
+      if (kb > 0) {   // (block 0's requests were made behind the previous tile: pre_issue)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a2_dma16(rs_k, dst_k + i * 1024, koff, i * 64);
-        a2_dma16(rs_v, dst_v + i * 4096, voff, i * 64);
+        for (int i = 0; i < 4; ++i) {
+          a2_dma16(rs_k, dst_k + i * 1024, koff + dk, i * 64);
+          a2_dma16(rs_v, dst_v + i * 4096, voff + dv, i * 64);
+        }
       }
-      A2_BARRIER();
+      // the tile's last block: K(0) of the next tile (streamed in one block ago) goes to the fragment registers before the seam's
+      // barrier, like the waves that compute this block do in its last gaps
+      if (kb == kb_wg && kb_wg >= 2 && nxt.valid) k_load(((gblk + kb + 1) & 1));
+      if (kb == 0 && had_epilogue) A2_BARRIER_16(); else A2_BARRIER();
     };
     using BF = std::false_type;
     using BT = std::true_type;
+    // the ticket of the tile after next: drawn by wave 0 in its slack (it has the fewest key blocks of a tile); the atomic's round trip
+    // is waited for on the spot (hipcc's wave-aggregated form), which a wave in front of its key blocks cannot afford
+    auto draw_next = [&]() {
+      if (wave == 0 && nxt.valid) {
+        if (tid == 0) item_nn = draw();
+      }
+    };
     if (dead) {
+      draw_next();
       for (int kb = 0; kb <= kb_wg; ++kb) idle(kb);
+      A2_PHASE(2)
     } else {
       if (n_full == 0) body(BT{}, BT{}, 0); else body(BT{}, BF{}, 0);
       for (int kb = 1; kb < n_full; ++kb) body(BF{}, BF{}, kb);               // the steady state: ONE instance, a self-loop
       for (int kb = max(n_full, 1); kb <= kl; ++kb) body(BF{}, BT{}, kb);     // the one or two blocks the diagonal crosses
+      A2_PHASE(1)   // the wave's key blocks
+      draw_next();
+    }
+    // the next tile's Q fragments: their registers are free behind the wave's last score MFMA; the loads land beside the drain,
+    // the staging-only blocks and the epilogue
+    const bool q_next = nxt.valid && nxt.row0 + 64 * wave + 63 >= nxt.P;
+    if (q_next) q_load(nxt);
+    if (!dead) {
       {   // what the wave still owes after its last block: the rest of B's softmax and PV(B, kl)
 #define A2_EMIT_DRAIN
 #include A2_BODY_INC
 #undef A2_EMIT_DRAIN
       }
       for (int kb = kl + 1; kb <= kb_wg; ++kb) idle(kb);
-
+      A2_PHASE(2)   // drain + the blocks the wave only stages for
+    }
+    // behind the tile's last barrier: the next tile's first requests (its K(0) is in the fragment registers of every wave by now)
+    const bool streamed = kb_wg >= 2 && nxt.valid;
+    if (streamed) pre_issue(nxt, gblk + kb_wg + 1);
+    if (dead && q_next) {
+      if (streamed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory", A2_ALLA); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A2_ALLA);
+    }
+    if (!dead) {
       // ============================================================== epilogue: O^T / l -> bf16 rows via the wave's own LDS region -> global
+      int z_;   // an opaque zero: keeps this lane arithmetic (loop-invariant across tiles) out of the key-block loop's live ranges
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z_));
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory", A2_ALLA);   // the last asm MFMAs' results (the compiler pads nothing)
       float inv[2];
 #pragma unroll
@@ -451,7 +574,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         const float l = a_ + b_;
         inv[hf] = 1.0f / l;
         const int q = q0 + 32 * hf + r;
-        if (lse && hi == 0 && q >= P) lse[(size_t)(vtok0 + q) * nh + h] = (m_run[hf] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+        if (lse && hi == 0 && q >= P) lse[(size_t)(vtok0 + q) * nh + (cur.hcol >> 7)] = (m_run[hf] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
       }
       a2_lds* const obase = (a2_lds*)smem + qoff;
       float ov[16];
@@ -471,20 +594,41 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #undef A2_EMIT_OREAD
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      // the next tile's Q fragments have landed (requested before the drain) -- waited for HERE, in front of the output stores, so
+      // that the seam does not have to wait for those stores
+      if (streamed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory", A2_ALLA); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A2_ALLA);
+      // 16 stores per lane, ALWAYS issued (the next tile's first block counts on them: vmcnt(16)): a row that is not this
+      // segment's gets an offset past the buffer's end, which the range check drops
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int row = 4 * k + (prow | z_), q = q0 + row;
-        const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ppos * 16);
-        if (q >= P) *reinterpret_cast<a2_u32x4*>(out + (size_t)(vtok0 + q) * nh * hd + h * hd + (ppos ^ (row & 15)) * 8) = v;
+        // lane ppos takes the row's LOGICAL chunk ppos (it sits at position ppos ^ (row & 15) of the staged row): the 16 lanes of
+        // a row then store 256 bytes in lane order (in the staged order the same bytes cost 1.5 x the write requests: WRITE_SIZE)
+        const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ((ppos ^ (row & 15)) << 4));
+        const unsigned off = q >= P ? (unsigned)(((vtok0 + q) * nh * hd + cur.hcol + ppos * 8) * 2) : 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
       }
     }
-    if (tid == 0) ctrl[(tile_no + 1) & 1] = j_next < len_own ? (int)xcc * cap + j_next : steal();
-    __syncthreads();   // the next ticket is visible; every wave is done with this tile's ring slots
-    item = __builtin_amdgcn_readfirstlane(ctrl[(tile_no + 1) & 1]);
+    had_epilogue = !dead;
+    A2_PHASE(3)   // epilogue
+    // ---- the seam: the ticket of the tile after next becomes visible; every wave is done with this tile's ring slots. LDS only: the
+    // output rows' stores drain beside the next tile (a __syncthreads() here waits for them: 6-8 k cycles per tile, measured)
+    if (tid == 0) ctrl[tile_no & 1] = item_nn;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);
+    prev_blocks = kb_wg + 1;
+    gblk += kb_wg + 1;
+    cur = nxt;
+    nxt = decode(__builtin_amdgcn_readfirstlane(ctrl[tile_no & 1]));
+    A2_PHASE(4)   // ticket + rendezvous
+#ifdef A2_STAMPS
+    ph_acc[5] += 1;
+#endif
   }
 #ifdef A2_STAMPS
   if (blockIdx.x < 64 && tid == 0)
     for (int i = 0; i < 12; ++i) g_a256_stamps[blockIdx.x * 12 + i] = st_acc[i];
+  if (blockIdx.x < 64 && (tid == 0 || tid == 192))
+    for (int i = 0; i < 8; ++i) g_a256_phases[(blockIdx.x * 2 + (tid == 192)) * 8 + i] = ph_acc[i];
 #endif
   // ---- the last workgroup to leave re-arms the counters for the next launch over the same item list
   if (tid == 0) {
@@ -502,8 +646,8 @@ int lr_launch_attention256(const u16* qkv, u16* out, const int32_t* cu, const in
   if (hd != 128 || nh % nkv != 0 || nh > 0xffff) LR_FAIL(LR_EUNSUPPORTED, "attention (256-row tiles): head_dim 128, nh %% nkv == 0 only");
   if (prefix_len < 0 || prefix_len % 4 != 0 || prefix_len > A2_KB || (prefix_len > 0 && cu_host[1] - cu_host[0] != prefix_len))
     LR_FAIL(LR_EINVAL, "attention (256-row tiles): shared prefix of %d tokens (multiple of 4, <= 64, = segment 0)", prefix_len);
-  if ((long long)n_tok * (nh + 2 * nkv) * hd * 2 > 0x7fffffffLL * 2)
-    LR_FAIL(LR_EUNSUPPORTED, "attention: packed qkv of %d tokens exceeds the 4 GiB a buffer descriptor addresses", n_tok);
+  if ((long long)n_tok * (nh + 2 * nkv) * hd * 2 > 0x7fffffffLL)
+    LR_FAIL(LR_EUNSUPPORTED, "attention (256-row tiles): packed qkv of %d tokens exceeds 2 GiB (32-bit byte offsets)", n_tok);
   if (!items_ws) LR_FAIL(LR_EINVAL, "attention (256-row tiles): no item list");
   double work = 0;
   for (int b = 0; b < S; ++b) {
@@ -525,7 +669,7 @@ int lr_launch_attention256(const u16* qkv, u16* out, const int32_t* cu, const in
   static bool lds_set[LR_MAX_DEVICES] = {};
   if (int rc = lr_ensure_dynamic_lds(reinterpret_cast<const void*>(attn_mfma256_kernel), A2_LDS_BYTES, lds_set)) return rc;
   hipLaunchKernelGGL(attn_mfma256_kernel, dim3(cus), dim3(256), A2_LDS_BYTES, st, qkv, out, cu, prefix_len, nh, nkv,
-                     (const int32_t*)ws, ws + A2_HDR_INTS, lse);
+                     (const int32_t*)ws, ws + A2_HDR_INTS, lse, (unsigned)((size_t)n_tok * (nh + 2 * nkv) * hd * 2));
   LR_CHECK_LAUNCH("attn_mfma256_kernel");
   return LR_OK;
 }

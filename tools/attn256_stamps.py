@@ -25,3 +25,13 @@ per = st[:, :9] / blocks[:, None]
 print("steady-state blocks per workgroup (wave 0): median %d" % np.median(blocks))
 print("cycles per 8-gap segment (median over 64 workgroups):", " ".join("%.0f" % x for x in np.median(per[:, :8], 0)))
 print("waits + barrier: %.0f   block total: %.0f   (64 MFMAs = 2048 cycles)" % (np.median(per[:, 8]), np.median(st[:, 10] / blocks)))
+
+ph = np.zeros(64 * 16, dtype=np.uint64)
+assert l.lr_debug_attn256_phases(ph.ctypes.data_as(C.c_void_p), 64 * 16) == 0
+ph = ph.reshape(64, 2, 8).astype(np.float64)
+for w, name in ((0, "wave 0"), (1, "wave 3")):
+    tiles = np.maximum(ph[:, w, 5], 1)
+    m = np.median(ph[:, w, :5] / tiles[:, None], 0)
+    tot = np.median(ph[:, w, :5].sum(1))
+    print("%s: tiles %d; cycles per tile: prologue %.0f, key blocks %.0f, drain+staging-only blocks %.0f, epilogue %.0f, ticket+rendezvous %.0f; kernel total %.0f"
+          % (name, np.median(ph[:, w, 5]), m[0], m[1], m[2], m[3], m[4], tot))

@@ -37,7 +37,12 @@ def run(lens, var=0, name=""):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[1] == "beauty":      # the token-budget Beauty step alone: python tools/bench_attn.py beauty VAR
+        from llamarec_amd.packing import token_budget_steps
+        from llamarec_amd.synth import synth_users
+        T = synth_users("beauty", 100)[3]
+        run(T[token_budget_steps(T)[0]], int(sys.argv[2]), name="beauty token-budget step")
+    elif len(sys.argv) > 2:
         run([int(sys.argv[2])] * int(sys.argv[1]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     else:
         from llamarec_amd.packing import token_budget_steps

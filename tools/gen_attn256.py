@@ -194,8 +194,8 @@ def build():
     # ---------------- LDS-DMA of K(kb + 2) and V(kb + 1): early in the block, in the lightest gaps
     dma = "s_mov_b32 m0, {0}\n\ts_nop 0\n\tbuffer_load_dwordx4 {1}, {2}, {3} offen lds"
     for i in range(4):
-        add(1 + 2 * i, dma, [("s", "dst_k + %d" % (1024 * i)), ("i", "koff"), ("s", "rs_k"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
-        add(2 + 2 * i, dma, [("s", "dst_v + %d" % (4096 * i)), ("i", "voff"), ("s", "rs_v"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
+        add(1 + 2 * i, dma, [("s", "dst_k + %d" % (1024 * i)), ("i", "koff_x"), ("s", "rs_k"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
+        add(2 + 2 * i, dma, [("s", "dst_v + %d" % (4096 * i)), ("i", "voff_x"), ("s", "rs_v"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
     if os.environ.get("A2_STAMPS"):   # diagnostic build (tools/build_attn256_abl.sh stamps): where a block's cycles go
         for k in range(8):
             add(8 * k, "s_memtime {0}", [("so", "st_[%d]" % k)], kind="stamp", prio=0)
@@ -296,6 +296,12 @@ def emit(mf, ops, lo, hi, first, diag, drain, f):
             continue
         if ABL and ablated(o):
             continue
+        if o.kind == "dma" and first:
+            continue     # a tile's first block: its K(2) / V(1) were requested behind the PREVIOUS tile's last barrier (the kernel's
+                         # pre_issue), in front of that tile's output stores, so that this block's wait need not cover those stores
+        if o.kind == "stamp" and (first or diag or drain):
+            continue     # only the steady-state variant waits for the stamps (an s_memtime landing in a register hipcc has reused
+                         # since -- the outputs are dead in the other variants -- overwrote an address: a memory fault)
         if first and hasattr(o, "first_text"):
             o = Ins(o.gap, o.first_text, o.first_operands, kind=o.kind, prio=o.prio)
         by_gap.setdefault(g, []).append(o)
@@ -364,16 +370,16 @@ def report(ops):
 
 
 def emit_static(f):
-    # Q fragments of a tile: LDS (the wave's own 64 x 256 B region) -> a[128:191]
-    f.write("#ifdef A2_EMIT_QLOAD\n")
+    # Q fragments of a tile: global memory -> a[128:191] (lane: row 32 half + (l & 31), 16 bytes at 32 ks + 16 (l >> 5))
+    f.write("#ifdef A2_EMIT_QGLOAD\n")
     for h in range(2):
         for ks in range(8):
-            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(qaddr) : %s);\n'
-                    % (areg(Q_(h, ks), 4), h * 8192 + ks * 512, clob(Q_(h, ks), 4)))
-    f.write("#endif\n#ifdef A2_EMIT_KLOAD\n")   # K fragments of a tile's block 0 (slot 0)
+            f.write('asm volatile("global_load_dwordx4 %s, %%0, %%1 offset:%d" :: "v"(qvo[%d]), "s"(qkv) : "memory", %s);\n'
+                    % (areg(Q_(h, ks), 4), ks * 32, h, clob(Q_(h, ks), 4)))
+    f.write("#endif\n#ifdef A2_EMIT_KLOAD\n")   # K fragments of the block in the ring slot kaddr_n points at
     for kt in range(2):
         for ks in range(8):
-            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(kaddr) : %s);\n'
+            f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(kaddr_n) : %s);\n'
                     % (areg(K_(kt, ks), 4), kt * 8192 + ks * 512, clob(K_(kt, ks), 4)))
     f.write("#endif\n")
     # epilogue: one O^T tile (16 registers) at a time into ov[], A2_OSTORE(half, dt) consumes it
