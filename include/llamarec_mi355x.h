@@ -215,8 +215,9 @@ void lr_llama_destroy(lr_llama_t* h);
 
 /* Kernel selection: 0 = auto (default), 1 = generic kernels (any shape; the in-library cross-check of the fast
  * ones), attention 2 = head_dim-128 MFMA flash attention (K/V by LDS-DMA, 128 query rows per workgroup),
- * attention 3 = head_dim-128 flash attention on 256-row tiles, one wave per SIMD, persistent workgroups (what auto picks for
- * head_dim 128 when the shared prefix is a multiple of 4 and <= 64 tokens; falls back to 2 otherwise),
+ * attention 3 = head_dim-128 flash attention on 256-row tiles, one wave per SIMD, persistent workgroups (shared prefix of at
+ * most 64 tokens, falls back to 2 otherwise; ahead of 2 on long prompts -- thousands of tokens -- and behind it on this
+ * path's 460 .. 1 125-token prompts, so auto keeps 2),
  * gemm 4 = the ping-pong pipelined 256x256x64 MFMA GEMM (an error if a shape does not fit).
  * gemm 5 = LATENCY MODE for the online single-user path (demo/inference.py:56-76):
  * variant 4 plus split-K wherever the output tiles alone would leave most CUs idle (a 460-token prompt

@@ -199,8 +199,9 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   RUN(lr_launch_token_meta(cu, B, P, ws.seg_start, ws.tok_pos, ws.tok_src, ws.last_rows, st, ws.last_pos, ids,
                            ws.prefix_bad));
   RUN(lr_launch_rope_table(ws.rope, maxT, hd, c.rope_theta, st, ws.rope16));
-  // attention: 3 = 256-row tiles (auto for head_dim 128 when the prefix allows), its item list built once per call
-  const bool attn256 = (h->attn_variant == 3 || h->attn_variant == 0) && lr_attention256_takes(hd, P);
+  // attention: 3 = 256-row tiles, one wave per SIMD (llama_attn256.hip), its item list built once per call. Auto keeps variant 2:
+  // on the prompts of this path (460 .. 1 125 tokens) the 128-row kernel with two workgroups per CU is still ahead
+  const bool attn256 = h->attn_variant == 3 && lr_attention256_takes(hd, P);
   if (h->attn_variant == 3 && !attn256 && hd != 128)
     LR_FAIL(LR_EUNSUPPORTED, "llama prefill: attention variant 3 needs head_dim 128 (got %d)", hd);
   const int attn_var = attn256 ? 3 : (h->attn_variant == 3 ? 2 : h->attn_variant);

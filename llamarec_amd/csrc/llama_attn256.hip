@@ -48,9 +48,9 @@ typedef __attribute__((address_space(3))) char a2_lds;
 #endif
 #define A2_ROWS 256
 #define A2_KB 64
-#define A2_RING_BYTES 65536               // 2 slots x (K 16 KiB | V 16 KiB)
-#define A2_QBUF 65536                     // 4 waves x 16 KiB
-#define A2_CTRL (A2_QBUF + 65536)         // ticket word
+#define A2_RING_BYTES 98304               // 3 slots x (K 16 KiB | V 16 KiB): K is requested three blocks ahead, V two
+#define A2_QBUF A2_RING_BYTES             // output staging: 4 waves x 8 KiB (32 rows at a time)
+#define A2_CTRL (A2_QBUF + 32768)         // ticket words
 #define A2_LDS_BYTES (A2_CTRL + 64)
 #define A2_THR 8.0f                       // deferred maximum: log2 units
 
@@ -190,9 +190,11 @@ __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", A2_ALLA);
 }
 
-// a tile's first block: the wave's 16 output-row stores of the previous tile are YOUNGER than this block's operands (pre_issue)
-// and may still be in flight
-#define A2_BARRIER_16() asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
+// End of a key block: everything requested BEFORE this block's own 8 pieces has landed (K three blocks ahead, V two: a request has
+// two blocks to arrive). A tile's first block: its 8 pieces were requested behind the previous tile (pre_issue) and the wave's 16
+// output-row stores of that tile are younger still.
+#define A2_BARRIER_8() asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
+#define A2_BARRIER_24() asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
 #ifdef A2_ABL_NOBARRIER   // timing-only ablation (wrong results): the waits without the rendezvous
 #define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", A2_ALLA)
 #else
@@ -200,13 +202,19 @@ __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsi
 #endif
 
 #ifdef A2_STAMPS   // diagnostic build only (tools/build_attn256_abl.sh stamps): per-block s_memtime deltas, wave 0 of 64 workgroups
-__device__ unsigned long long g_a256_stamps[64 * 12];
+__device__ unsigned long long g_a256_stamps[64 * 24];   // [workgroup][steady | first blocks][12]
 extern "C" int lr_debug_attn256_stamps(unsigned long long* out, int n) {
-  if (!out || n < 1 || n > 64 * 12) LR_FAIL(LR_EINVAL, "lr_debug_attn256_stamps: bad arguments");
+  if (!out || n < 1 || n > 64 * 24) LR_FAIL(LR_EINVAL, "lr_debug_attn256_stamps: bad arguments");
   LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_stamps), (size_t)n * sizeof(unsigned long long)));
   return LR_OK;
 }
+__device__ unsigned long long g_a256_blocks[64 * 16];      // wave 3: [bucket][cycles, count]: first, second, steady, third-last, second-last, last
 __device__ unsigned long long g_a256_phases[64 * 2 * 8];   // [workgroup][wave 0 | wave 3][prologue, blocks, drain+idle, epilogue, seam, tiles]
+extern "C" int lr_debug_attn256_blocks(unsigned long long* out, int n) {
+  if (!out || n < 1 || n > 64 * 16) LR_FAIL(LR_EINVAL, "lr_debug_attn256_blocks: bad arguments");
+  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_blocks), (size_t)n * sizeof(unsigned long long)));
+  return LR_OK;
+}
 extern "C" int lr_debug_attn256_phases(unsigned long long* out, int n) {
   if (!out || n < 1 || n > 64 * 16) LR_FAIL(LR_EINVAL, "lr_debug_attn256_phases: bad arguments");
   LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_phases), (size_t)n * sizeof(unsigned long long)));
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   //  V piece (column group G, key group g): lane L <- key 16 g + (L >> 2), bytes 64 G + 16 (L & 3). Wave w moves group w of both,
   //  so the per-lane source offset is one constant per operand and the piece index is the load's scalar offset (64 p).
   const unsigned kaddr = lds0 + (r >> 4) * 4096 + (r & 15) * 16 + hi * 256;           // + 512 ks + 8192 kt + slot
-  const unsigned qoff = A2_QBUF + wave * 16384;                                      // the wave's own Q / O rows
+  const unsigned qoff = A2_QBUF + wave * 8192;                                       // the wave's own output staging rows
   unsigned vaddr;                                                                    // + 4096 dt + 1024 s + 512 jj + slot
   {
     const int i = lane & 15, q = i >> 2, p = i & 3, g1 = (lane >> 4) & 1;
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 
 #ifdef A2_STAMPS
   unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_prev;
+  unsigned long long stF_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_prev, bk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_prev)::"memory");
 #endif
   // ---- tickets. Own XCD's stream first (the tiles of one (segment, head) follow each other there: their K/V blocks meet in
@@ -348,18 +357,18 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     if (kbx > t.kb_wg || !t.valid) rec = 0;
     return a2_make_rsrc(t.kbase + off, rec);
   };
-  // Source of key block kbx of the STREAM that starts at tile `c` and runs on into tile `n` (its blocks 0 and 1 only): the
+  // Source of key block kbx of the STREAM that starts at tile `c` and runs on into tile `n` (its blocks 0 .. jmax only): the
   // descriptor, and the per-lane byte offset to ADD to koff / voff (non-zero only for block 0 of a tile that shares a prefix:
   // one descriptor over the whole buffer, own rows shifted by the segment's first row; a key past the sequence end then reads
   // the following rows -- finite, and causally masked for every live query row -- where an own-rows descriptor zero-fills).
-  auto stream_src = [&](const Tile& c, const Tile& n, int kbx, int key_lane, a2_int4& rs, unsigned& delta) {
+  auto stream_src = [&](const Tile& c, const Tile& n, int kbx, int jmax, int key_lane, a2_int4& rs, unsigned& delta) {
     delta = 0;
     if (kbx <= c.kb_wg) {
       rs = own_rsrc(c, kbx);
       return;
     }
     const int j = kbx - c.kb_wg - 1;
-    if (!n.valid || j > 1 || j > n.kb_wg) {
+    if (!n.valid || j > jmax || j > n.kb_wg) {
       rs = a2_make_rsrc(qkv, 0);
     } else if (j == 0 && n.P > 0) {
       const long long left = (long long)qkv_bytes - (long long)n.kcol * 2;
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   // synchronous staging of one block with per-lane source addresses (a workgroup's first tile; block 0 behind a one-block tile):
   // keys < P come from segment 0's rows, keys >= T are clamped to T - 1
   auto stage_sync = [&](const Tile& t, int kbx, int slot, bool do_k, bool do_v) {
-    const unsigned dst = lds0 + slot * 32768 + wave * 4096;
+    const unsigned dst = lds0 + slot * 32768 + wave * 4096;   // slot 0 .. 2
     const int kk = min(kbx * A2_KB + klane_k, t.T - 1), kv = min(kbx * A2_KB + klane_v, t.T - 1);
     const unsigned ok = (unsigned)(((kk < t.P ? kk : t.vtok0 + kk) * stride + t.kcol) * 2 + (lane >> 4) * 16);
     const unsigned ov = (unsigned)(((kv < t.P ? kv : t.vtok0 + kv) * stride + t.kcol + nkv * hd) * 2 + (lane & 3) * 16);
@@ -411,16 +420,16 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   // two consecutive items -- two tiles of ONE (segment, head) -- which then run one after the other on this CU instead of side
   // by side on two CUs of the XCD, and their K/V blocks no longer meet in L2 (measured: L2 hit rate 0.58 -> 0.40).
   Tile cur = decode(__builtin_amdgcn_readfirstlane(ctrl[0]));
-  int gblk = 0;            // running index of the current tile's block 0 in the workgroup's block stream: ring slot = index & 1
+  int sl0 = 0;             // ring slot (0 .. 2) of the current tile's block 0: the workgroup's blocks take the slots in turn
   int prev_blocks = 0;     // key blocks of the previous tile (0: none): what of the current tile was streamed in behind it
   bool had_epilogue = false;   // this wave stored output rows at the end of the previous tile
-  // K(2) and V(1) of a tile -- what its first block would request -- are requested behind the previous tile's last barrier
-  // instead: in front of that tile's output stores in the wave's vector-memory queue, so that the first block waits for its
-  // operands with vmcnt(16) and not for those stores (they take 6-8 k cycles to drain: measured)
-  auto pre_issue = [&](const Tile& t, int g0) {
-    const int par = (g0 & 1) * 32768;
-    const a2_int4 rs_k = own_rsrc(t, 2), rs_v = own_rsrc(t, 1);
-    const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
+  // K(3) and V(2) of a tile -- what its first block would request -- are requested behind the previous tile's last barrier
+  // instead: in front of that tile's output stores in the wave's vector-memory queue, so that the first block's wait leaves those
+  // stores in flight (they take 6-8 k cycles to drain: measured)
+  auto nx = [](int sl) { return sl == 2 ? 0 : sl + 1; };   // ring slot of the following block
+  auto pre_issue = [&](const Tile& t, int s0) {             // s0: the ring slot of the tile's block 0
+    const a2_int4 rs_k = own_rsrc(t, 3), rs_v = own_rsrc(t, 2);
+    const unsigned dst_k = lds0 + s0 * 32768 + wave * 4096, dst_v = lds0 + nx(nx(s0)) * 32768 + 16384 + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       a2_dma16(rs_k, dst_k + i * 1024, koff, i * 64);
@@ -438,34 +447,37 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     const bool dead = q0 + 63 < P;                                // no live row in this wave
     const int n_full = q0 >= 0 ? (q0 + 1) >> 6 : 0;               // blocks every row of the wave sees unmasked
     const int kl = dead ? -1 : (q0 + 63) >> 6;                    // the wave's last block
-    if (prev_blocks < 3) {
-      // Not everything was streamed in behind the previous tile: K(0) needs a previous tile of >= 3 blocks (requested in its block
-      // kb_wg - 1, which must not be ITS pre-issued block 0), K(1) and V(0) one of >= 2. Stage what is missing now, then every
-      // wave reads K(0) BEFORE this tile's K(2) goes into the same ring slot.
-      const bool none = prev_blocks < 2;
-      stage_sync(cur, 0, gblk & 1, true, none);
-      if (none) stage_sync(cur, 1, (gblk + 1) & 1, true, false);
+    if (prev_blocks < 4) {
+      // Not everything was streamed in behind the previous tile: K(0) needs a previous tile of >= 4 blocks (requested in its block
+      // kb_wg - 2, which must not be ITS pre-issued block 0), K(1) and V(0) one of >= 3, K(2) and V(1) one of >= 2. Stage what is
+      // missing now, then every wave reads K(0) BEFORE this tile's K(3) goes into the same ring slot.
+      stage_sync(cur, 0, sl0, true, prev_blocks < 3);
+      if (prev_blocks < 3) stage_sync(cur, 1, nx(sl0), true, prev_blocks < 2);
+      if (prev_blocks < 2) stage_sync(cur, 2, nx(nx(sl0)), true, false);
       A2_BARRIER();
-      if (!dead) k_load(gblk & 1);
+      if (!dead) k_load(sl0);
       A2_BARRIER();
-      pre_issue(cur, gblk);
-      had_epilogue = false;   // (the first block then waits for everything)
+      pre_issue(cur, sl0);
+      had_epilogue = false;   // (the stores are behind us: the first block leaves only its own requests in flight)
     }
     m_run[0] = m_run[1] = mthr[0] = mthr[1] = -__builtin_inff();   // every row's maximum moves in its first block
     negm[0] = negm[1] = lsum[0] = lsum[1] = 0.f;
     A2_PHASE(0)   // seam
 
     // ================================================================ one key block
+    int sl = sl0;   // ring slot of the block about to run: K(kb), V(kb) and the request K(kb + 3) use it; K(kb + 1) the next one; the
+                    // request V(kb + 2) the one after (V(kb - 1)'s)
     auto body = [&](auto first_c, auto diag_c, const int kb) {
       constexpr bool FIRST = decltype(first_c)::value, DIAG = decltype(diag_c)::value;
-      const int par = ((gblk + kb) & 1) * 32768;          // K(kb), V(kb) and K(kb + 2) use this slot; K(kb + 1), V(kb + 1) the other
       a2_int4 rs_k, rs_v;
       unsigned dk, dv;
-      stream_src(cur, nxt, kb + 2, klane_k, rs_k, dk);
-      stream_src(cur, nxt, kb + 1, klane_v, rs_v, dv);
+      stream_src(cur, nxt, kb + 3, 2, klane_k, rs_k, dk);
+      stream_src(cur, nxt, kb + 2, 1, klane_v, rs_v, dv);
       const unsigned koff_x = koff + dk, voff_x = voff + dv;
-      const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
-      const unsigned kaddr_n = kaddr + (par ^ 32768), vaddr_c = vaddr + par + 16384;
+      const int sn = nx(sl), sp = nx(sn);
+      const unsigned dst_k = lds0 + sl * 32768 + wave * 4096, dst_v = lds0 + sp * 32768 + 16384 + wave * 1024;
+      const unsigned kaddr_n = kaddr + sn * 32768, vaddr_c = vaddr + sl * 32768 + 16384;
+      sl = sn;
       (void)rt_; (void)bt_; (void)t_; (void)p_; (void)soff; (void)ninf; (void)kaddr_n; (void)vaddr_c; (void)koff_x; (void)voff_x;
       if constexpr (DIAG) {
         thr[0] = max(q0 + r, 0) - kb * A2_KB - 4 * hi;
@@ -489,27 +501,35 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #undef A2_EMIT_BODY_00
       }
 #ifdef A2_STAMPS
-      if constexpr (!FIRST && !DIAG) {   // steady-state blocks only: [0..7] eight-gap segments, [8] waits + barrier, [9] blocks
+      if constexpr (!DIAG) {   // [0..7] eight-gap segments, [8] waits + barrier, [9] blocks; first blocks in the second set
         unsigned long long te_;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
-                       "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
+        unsigned long long tw_ = 0;
+        if (FIRST && had_epilogue)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %10\n\ts_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                       "s_mov_b64 %8, %10\n\ts_mov_b64 %9, %0\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
+                         "+s"(st_[7]), "+s"(st_[8]), "=&s"(tw_) :: "memory", A2_ALLA);
+        else
+          asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
+                         "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
+        unsigned long long* acc_ = FIRST ? stF_acc : st_acc;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) st_acc[i] += st_[i + 1] - st_[i];
-        st_acc[8] += te_ - st_[8];
-        st_acc[9] += 1;
-        st_acc[10] += te_ - st_[0];
+        for (int i = 0; i < 8; ++i) acc_[i] += st_[i + 1] - st_[i];
+        acc_[8] += te_ - st_[8];
+        acc_[9] += 1;
+        acc_[10] += te_ - st_[0];
       } else
 #endif
-      if (FIRST && had_epilogue) A2_BARRIER_16(); else A2_BARRIER();
+      if (FIRST && had_epilogue) A2_BARRIER_24(); else A2_BARRIER_8();
     };
-    auto idle = [&](const int kb) {   // a wave with no work in this block still moves its share of K(kb + 2) and V(kb + 1)
-      const int par = ((gblk + kb) & 1) * 32768;
+    auto idle = [&](const int kb) {   // a wave with no work in this block still moves its share of K(kb + 3) and V(kb + 2)
       a2_int4 rs_k, rs_v;
       unsigned dk, dv;
-      stream_src(cur, nxt, kb + 2, klane_k, rs_k, dk);
-      stream_src(cur, nxt, kb + 1, klane_v, rs_v, dv);
-      const unsigned dst_k = lds0 + par + wave * 4096, dst_v = lds0 + (par ^ 32768) + 16384 + wave * 1024;
+      stream_src(cur, nxt, kb + 3, 2, klane_k, rs_k, dk);
+      stream_src(cur, nxt, kb + 2, 1, klane_v, rs_v, dv);
+      const int sn = nx(sl), sp = nx(sn);
+      const unsigned dst_k = lds0 + sl * 32768 + wave * 4096, dst_v = lds0 + sp * 32768 + 16384 + wave * 1024;
       if (kb > 0) {   // (block 0's requests were made behind the previous tile: pre_issue)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -517,10 +537,11 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
           a2_dma16(rs_v, dst_v + i * 4096, voff + dv, i * 64);
         }
       }
-      // the tile's last block: K(0) of the next tile (streamed in one block ago) goes to the fragment registers before the seam's
+      // the tile's last block: K(0) of the next tile (streamed in two blocks ago) goes to the fragment registers before the seam's
       // barrier, like the waves that compute this block do in its last gaps
-      if (kb == kb_wg && kb_wg >= 2 && nxt.valid) k_load(((gblk + kb + 1) & 1));
-      if (kb == 0 && had_epilogue) A2_BARRIER_16(); else A2_BARRIER();
+      if (kb == kb_wg && kb_wg >= 3 && nxt.valid) k_load(sn);
+      sl = sn;
+      if (kb == 0 && had_epilogue) A2_BARRIER_24(); else A2_BARRIER_8();
     };
     using BF = std::false_type;
     using BT = std::true_type;
@@ -536,28 +557,43 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       for (int kb = 0; kb <= kb_wg; ++kb) idle(kb);
       A2_PHASE(2)
     } else {
+#ifdef A2_STAMPS
+      auto timed = [&](int kb, auto&& fn) {
+        unsigned long long t0_, t1_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory", A2_ALLA);
+        fn();
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory", A2_ALLA);
+        const int b = kb == 0 ? 0 : (kb_wg - kb <= 2 ? 5 - (kb_wg - kb) : (kb == 1 ? 1 : 2));
+        bk_acc[2 * b] += t1_ - t0_;
+        bk_acc[2 * b + 1] += 1;
+      };
+      timed(0, [&]() { if (n_full == 0) body(BT{}, BT{}, 0); else body(BT{}, BF{}, 0); });
+      for (int kb = 1; kb < n_full; ++kb) timed(kb, [&]() { body(BF{}, BF{}, kb); });
+      for (int kb = max(n_full, 1); kb <= kl; ++kb) timed(kb, [&]() { body(BF{}, BT{}, kb); });
+#else
       if (n_full == 0) body(BT{}, BT{}, 0); else body(BT{}, BF{}, 0);
       for (int kb = 1; kb < n_full; ++kb) body(BF{}, BF{}, kb);               // the steady state: ONE instance, a self-loop
       for (int kb = max(n_full, 1); kb <= kl; ++kb) body(BF{}, BT{}, kb);     // the one or two blocks the diagonal crosses
+#endif
       A2_PHASE(1)   // the wave's key blocks
-      draw_next();
-    }
-    // the next tile's Q fragments: their registers are free behind the wave's last score MFMA; the loads land beside the drain,
-    // the staging-only blocks and the epilogue
-    const bool q_next = nxt.valid && nxt.row0 + 64 * wave + 63 >= nxt.P;
-    if (q_next) q_load(nxt);
-    if (!dead) {
       {   // what the wave still owes after its last block: the rest of B's softmax and PV(B, kl)
 #define A2_EMIT_DRAIN
 #include A2_BODY_INC
 #undef A2_EMIT_DRAIN
       }
+      draw_next();
+    }
+    // the next tile's Q fragments: their registers are free behind the wave's last score MFMA; the loads land beside the
+    // staging-only blocks and the epilogue
+    const bool q_next = nxt.valid && nxt.row0 + 64 * wave + 63 >= nxt.P;
+    if (q_next) q_load(nxt);
+    if (!dead) {
       for (int kb = kl + 1; kb <= kb_wg; ++kb) idle(kb);
       A2_PHASE(2)   // drain + the blocks the wave only stages for
     }
     // behind the tile's last barrier: the next tile's first requests (its K(0) is in the fragment registers of every wave by now)
-    const bool streamed = kb_wg >= 2 && nxt.valid;
-    if (streamed) pre_issue(nxt, gblk + kb_wg + 1);
+    const bool streamed = kb_wg >= 3 && nxt.valid;
+    if (streamed) pre_issue(nxt, sl);   // (sl has walked past the tile's last block: the next tile's block 0)
     if (dead && q_next) {
       if (streamed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory", A2_ALLA); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A2_ALLA);
     }
@@ -576,7 +612,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         const int q = q0 + 32 * hf + r;
         if (lse && hi == 0 && q >= P) lse[(size_t)(vtok0 + q) * nh + (cur.hcol >> 7)] = (m_run[hf] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
       }
-      a2_lds* const obase = (a2_lds*)smem + qoff;
+      a2_lds* const obase = (a2_lds*)smem + qoff;   // 32 rows x 256 B, chunk c of row r at position c ^ (r & 15)
       float ov[16];
       // lane: query row 32 hf + r, d = 32 dt + 8 g + 4 hi + 0..3 in registers 4g .. 4g+3: 8 bytes of 16-byte chunk 4 dt + g
 #define A2_OSTORE(hf, dt)                                                                                          \
@@ -586,28 +622,36 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       w_[0] = (unsigned)f2bf(ov[4 * g] * inv[hf]) | ((unsigned)f2bf(ov[4 * g + 1] * inv[hf]) << 16);               \
       w_[1] = (unsigned)f2bf(ov[4 * g + 2] * inv[hf]) | ((unsigned)f2bf(ov[4 * g + 3] * inv[hf]) << 16);           \
       *reinterpret_cast<__attribute__((address_space(3))) a2_u32x2*>(                                              \
-          obase + (32 * hf + (r | z_)) * 256 + (((4 * dt + g) ^ (r & 15)) << 4) + 8 * hi) = w_;                    \
+          obase + (r | z_) * 256 + (((4 * dt + g) ^ (r & 15)) << 4) + 8 * hi) = w_;                                \
     }                                                                                                              \
   }
-#define A2_EMIT_OREAD
-#include A2_BODY_INC
-#undef A2_EMIT_OREAD
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // the next tile's Q fragments have landed (requested before the drain) -- waited for HERE, in front of the output stores, so
-      // that the seam does not have to wait for those stores
-      if (streamed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory", A2_ALLA); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A2_ALLA);
-      // 16 stores per lane, ALWAYS issued (the next tile's first block counts on them: vmcnt(16)): a row that is not this
-      // segment's gets an offset past the buffer's end, which the range check drops
+      // 8 stores per half and lane, 16 in all, ALWAYS issued (the next tile's first block counts on them: vmcnt(24)): a row that is
+      // not this segment's gets an offset past the buffer's end, which the range check drops. Lane ppos takes the row's LOGICAL
+      // chunk ppos (it sits at position ppos ^ (row & 15) of the staged row): the 16 lanes of a row store 256 bytes in lane order.
+      auto flush_half = [&](int hf) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int row = 4 * k + (prow | z_), q = q0 + row;
-        // lane ppos takes the row's LOGICAL chunk ppos (it sits at position ppos ^ (row & 15) of the staged row): the 16 lanes of
-        // a row then store 256 bytes in lane order (in the staged order the same bytes cost 1.5 x the write requests: WRITE_SIZE)
-        const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ((ppos ^ (row & 15)) << 4));
-        const unsigned off = q >= P ? (unsigned)(((vtok0 + q) * nh * hd + cur.hcol + ppos * 8) * 2) : 0xfffffff0u;
-        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
-      }
+        for (int k = 0; k < 8; ++k) {
+          const int row = 4 * k + (prow | z_), q = q0 + 32 * hf + row;
+          const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ((ppos ^ (row & 15)) << 4));
+          const unsigned off = q >= P ? (unsigned)(((vtok0 + q) * nh * hd + cur.hcol + ppos * 8) * 2) : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      };
+#define A2_EMIT_OREAD_0
+#include A2_BODY_INC
+#undef A2_EMIT_OREAD_0
+      // the next tile's Q fragments have landed (requested behind the wave's last key block) -- waited for HERE, in front of the
+      // output stores, so that nothing behind has to wait for those stores
+      if (streamed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory", A2_ALLA); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory", A2_ALLA);
+      flush_half(0);
+#define A2_EMIT_OREAD_1
+#include A2_BODY_INC
+#undef A2_EMIT_OREAD_1
+      flush_half(1);
     }
     had_epilogue = !dead;
     A2_PHASE(3)   // epilogue
@@ -616,7 +660,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     if (tid == 0) ctrl[tile_no & 1] = item_nn;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory", A2_ALLA);
     prev_blocks = kb_wg + 1;
-    gblk += kb_wg + 1;
+    sl0 = sl;
     cur = nxt;
     nxt = decode(__builtin_amdgcn_readfirstlane(ctrl[tile_no & 1]));
     A2_PHASE(4)   // ticket + rendezvous
@@ -625,8 +669,13 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #endif
   }
 #ifdef A2_STAMPS
-  if (blockIdx.x < 64 && tid == 0)
-    for (int i = 0; i < 12; ++i) g_a256_stamps[blockIdx.x * 12 + i] = st_acc[i];
+  if (blockIdx.x < 64 && tid == 192)   // wave 3
+    for (int i = 0; i < 12; ++i) {
+      g_a256_stamps[blockIdx.x * 24 + i] = st_acc[i];
+      g_a256_stamps[blockIdx.x * 24 + 12 + i] = stF_acc[i];
+    }
+  if (blockIdx.x < 64 && tid == 192)
+    for (int i = 0; i < 16; ++i) g_a256_blocks[blockIdx.x * 16 + i] = bk_acc[i];
   if (blockIdx.x < 64 && (tid == 0 || tid == 192))
     for (int i = 0; i < 8; ++i) g_a256_phases[(blockIdx.x * 2 + (tid == 192)) * 8 + i] = ph_acc[i];
 #endif
@@ -644,8 +693,8 @@ int lr_launch_attention256(const u16* qkv, u16* out, const int32_t* cu, const in
                            int nkv, int hd, float* lse, void* items_ws, hipStream_t st, int prefix_len) {
   if (n_tok <= 0 || S <= 0) return LR_OK;
   if (hd != 128 || nh % nkv != 0 || nh > 0xffff) LR_FAIL(LR_EUNSUPPORTED, "attention (256-row tiles): head_dim 128, nh %% nkv == 0 only");
-  if (prefix_len < 0 || prefix_len % 4 != 0 || prefix_len > A2_KB || (prefix_len > 0 && cu_host[1] - cu_host[0] != prefix_len))
-    LR_FAIL(LR_EINVAL, "attention (256-row tiles): shared prefix of %d tokens (multiple of 4, <= 64, = segment 0)", prefix_len);
+  if (prefix_len < 0 || prefix_len > A2_KB || (prefix_len > 0 && cu_host[1] - cu_host[0] != prefix_len))
+    LR_FAIL(LR_EINVAL, "attention (256-row tiles): shared prefix of %d tokens (<= 64, = segment 0)", prefix_len);
   if ((long long)n_tok * (nh + 2 * nkv) * hd * 2 > 0x7fffffffLL)
     LR_FAIL(LR_EUNSUPPORTED, "attention (256-row tiles): packed qkv of %d tokens exceeds 2 GiB (32-bit byte offsets)", n_tok);
   if (!items_ws) LR_FAIL(LR_EINVAL, "attention (256-row tiles): no item list");

@@ -89,9 +89,9 @@ int lr_launch_attention(const unsigned short* qkv, unsigned short* out, const in
 // attention variant 3 (llama_attn256.hip): 256-row query tiles, one wave per SIMD, persistent workgroups over a
 // device-built item list. lr_launch_attn256_items builds the list for (cu, S, nh, prefix_len) into items_ws
 // (lr_attn256_ws_bytes); any number of lr_launch_attention256 calls over the same segments may follow (one per layer).
-// prefix_len must be a multiple of 4 and <= 64 (lr_attention256_takes).
+// prefix_len must be <= 64 (lr_attention256_takes): only a tile's block 0 may hold shared-prefix keys.
 size_t lr_attn256_ws_bytes(int n_tok, int S, int nh);
-static inline bool lr_attention256_takes(int hd, int prefix_len) { return hd == 128 && prefix_len % 4 == 0 && prefix_len <= 64; }
+static inline bool lr_attention256_takes(int hd, int prefix_len) { return hd == 128 && prefix_len <= 64; }
 int lr_launch_attn256_items(const int32_t* cu, int S, int n_tok, int nh, int prefix_len, void* items_ws, size_t ws_bytes,
                             hipStream_t st);
 int lr_launch_attention256(const unsigned short* qkv, unsigned short* out, const int32_t* cu, const int32_t* cu_host, int S,

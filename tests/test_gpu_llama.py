@@ -123,8 +123,14 @@ def attention(qkv, cu, nh, nkv, hd, variant):
     out = torch.full((n, nh * hd), 0x7FC0, dtype=torch.int16, device="cuda")
     cu = np.ascontiguousarray(cu, dtype=np.int32)
     cud = torch.from_numpy(cu).cuda()
-    check(lib().lr_attention_varlen(q.data_ptr(), out.data_ptr(), cud.data_ptr(), cu.ctypes.data, len(cu) - 1,
-                                    nh, nkv, hd, variant, stream_ptr()), "attention")
+    if variant == 3:   # 256-row tiles (llama_attn256.hip): needs a workspace for its work-item list
+        wsb = lib().lr_attention_workspace_bytes(n, len(cu) - 1, nh)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda")
+        check(lib().lr_attention_varlen_ws(q.data_ptr(), out.data_ptr(), None, cud.data_ptr(), cu.ctypes.data, len(cu) - 1,
+                                           nh, nkv, hd, 3, ws.data_ptr(), wsb, stream_ptr()), "attention")
+    else:
+        check(lib().lr_attention_varlen(q.data_ptr(), out.data_ptr(), cud.data_ptr(), cu.ctypes.data, len(cu) - 1,
+                                        nh, nkv, hd, variant, stream_ptr()), "attention")
     torch.cuda.synchronize()
     return host_f32(out)
 
@@ -148,9 +154,11 @@ def attention_ref(qkv, cu, nh, nkv, hd):
 
 
 @pytest.mark.parametrize("nh,nkv,hd,variant", [(4, 4, 128, 2), (4, 2, 128, 2), (4, 4, 128, 1),
-                                               (4, 2, 16, 1), (2, 2, 64, 1)])
+                                               (4, 2, 16, 1), (2, 2, 64, 1), (4, 4, 128, 3), (4, 2, 128, 3), (12, 4, 128, 3)])
 def test_attention_vs_numpy(nh, nkv, hd, variant):
-    lens = [1, 63, 64, 65, 128, 129, 300, 2, 256, 257, 600]
+    # (variant 3: tiles are anchored at a sequence's END, so lengths on every side of 64 / 256 exercise the partial first tile,
+    # the two diagonal blocks of a wave and the streaming across tile seams; 1125 = four tiles)
+    lens = [1, 63, 64, 65, 128, 129, 300, 2, 256, 257, 600] + ([1125, 513, 31] if variant == 3 else [])
     cu = np.concatenate([[0], np.cumsum(lens)])
     qkv = bf16_round(hash_uniform(nh * 100 + hd, (cu[-1], (nh + 2 * nkv) * hd), 1.0))
     got = attention(qkv, cu, nh, nkv, hd, variant)
@@ -395,6 +403,42 @@ def test_shared_prefix_is_bit_identical_and_matches_oracle(nkv):
     assert torch.equal(full, full_plain)
 
 
+def test_shared_prefix_is_bit_identical_with_256_row_attention():
+    """The same promise for attention variant 3 (llama_attn256.hip): tiles anchored at the sequence end, the K/V/Q stream running
+    across tile seams, block 0 of a prefix-sharing segment gathered from two places through one descriptor. A row's bits
+    depend on its own keys only, so shared and plain runs are equal bit for bit; prefixes past 64 tokens fall back to the
+    128-row kernel (also equal). And the scores agree with variant 2's to bf16 noise."""
+    from llamarec_amd.llm import LlamaRanker
+
+    cfg = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+               num_key_value_heads=2, max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=10000.0)
+    sd = synth_llama_state(cfg, 11)
+    model = LlamaRanker.from_state_dict(sd, cfg)
+    label_ids = list(range(40, 60))
+    tails = [1, 5, 100, 300, 64, 27, 700, 1100, 256, 220]
+    for P in (1, 4, 36, 63, 64, 65, 130):
+        seqs = _prefixed_prompts(P, tails, 320, P)
+        model.set_variants(0, 3)
+        shared = model.prefill_verbalize(seqs, label_ids, share_prefix=True)
+        plain = model.prefill_verbalize(seqs, label_ids, share_prefix=False)
+        alone = torch.cat([model.prefill_verbalize([q], label_ids, share_prefix=False) for q in seqs[-3:]])
+        model.set_variants(0, 2)
+        v2 = model.prefill_verbalize(seqs, label_ids, share_prefix=False)
+        model.set_variants(0, 0)
+        assert torch.isfinite(plain).all() and torch.isfinite(shared).all(), P
+        if P <= 64:
+            assert torch.equal(shared, plain), P
+        else:   # the shared run falls back to the 128-row kernel (other MFMA shape, other summation order): bf16 noise apart
+            assert (shared - plain).abs().max().item() < 3e-2, P
+        assert torch.equal(alone, plain[-3:]), P                  # batch invariance
+        assert (plain - v2).abs().max().item() < 3e-2, P
+    seqs = _prefixed_prompts(36, tails, 320, 5)
+    full = model.set_variants(0, 3).set_last_layer_pruning(False).prefill_verbalize(seqs, label_ids, share_prefix=True)
+    full_plain = model.prefill_verbalize(seqs, label_ids, share_prefix=False)
+    model.set_variants(0, 0).set_last_layer_pruning(True)
+    assert torch.equal(full, full_plain)
+
+
 def test_shared_prefix_rejects_bad_lengths():
     from llamarec_amd._lib import LlamaRecError
     from llamarec_amd.llm import LlamaRanker, pack_prompts
@@ -410,7 +454,8 @@ def test_shared_prefix_rejects_bad_lengths():
             model.prefill_verbalize_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), cu, lab, prefix_len=bad)
 
 
-def test_full_width_shared_prefix_and_token_budget_batch():
+@pytest.mark.parametrize("attention", [0, 3])
+def test_full_width_shared_prefix_and_token_budget_batch(attention):
     """Llama-2-7b layer shapes, 2 layers: a 32 768-token batch built by llamarec_amd.packing (the bench's step) with the
     36-token template prefix shared gives bit-identical scores to the same prompts run unshared in the reference's
     16-prompt batches."""
@@ -418,7 +463,7 @@ def test_full_width_shared_prefix_and_token_budget_batch():
     from llamarec_amd.packing import TOKEN_BUDGET, token_budget_steps
     from llamarec_amd.synth import synth_prompt_tokens, synth_users
 
-    model = LlamaRanker.random_init(dict(LLAMA2_7B, num_hidden_layers=2), seed=5)
+    model = LlamaRanker.random_init(dict(LLAMA2_7B, num_hidden_layers=2), seed=5).set_variants(0, attention)
     _, _, _, T = synth_users("beauty", 100)
     step = token_budget_steps(T)[0]
     ids, cu = synth_prompt_tokens(T[step], seed=4)
@@ -630,8 +675,11 @@ def test_gemm_epilogues_fast_kernel_equals_generic_kernel_bit_for_bit(M):
     assert not torch.isnan(run(3, 4).view(torch.bfloat16).float()).any()
 
 
-def test_attention_online_softmax_with_forced_maximum_jumps():
-    """The online softmax rescales O only when some row's running maximum moved (`__any(grew)`), a data-dependent
+@pytest.mark.parametrize("variant", [2, 3])
+def test_attention_online_softmax_with_forced_maximum_jumps(variant):
+    """(Variant 3 DEFERS the maximum: a row's reference maximum moves only when a block exceeds it by more than 2^8, decided
+    per row from a cached threshold; the jumps below cross that threshold at chosen blocks for some rows of a tile only.)
+    The online softmax rescales O only when some row's running maximum moved (`__any(grew)`), a data-dependent
     branch that bounded random data exercises in the first blocks only (cdna_hip_programming.md, rule 26). Inputs that
     force it late and hard: keys far into the prompt that are large multiples of some queries, so a block's maximum
     jumps by 2^8 .. 2^60 over the running one at chosen off-diagonal blocks, for some rows of a tile only; small jumps;
@@ -655,7 +703,7 @@ def test_attention_online_softmax_with_forced_maximum_jumps():
         for h in range(nh):
             k[key, h] = gain * np.mean([q[j, h] for j in qs], axis=0)
     qkv = bf16_round(qkv)
-    got = attention(qkv, cu, nh, nkv, hd, 2)
+    got = attention(qkv, cu, nh, nkv, hd, variant)
     # float64 reference with bf16 probabilities (the kernel's rounding point)
     ref = np.zeros((n, nh * hd))
     qq = qkv[:, : nh * hd].reshape(n, nh, hd).astype(np.float64)

@@ -120,3 +120,52 @@ def test_diag_prototypes_still_compile(tmp_path):
     for f in srcs:
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-c", "--cuda-device-only", os.path.join(diag, f), "-o", str(tmp_path / (f + ".o"))],
                        check=True, capture_output=True)
+
+
+def test_attn256_accumulator_file_is_left_alone(tmp_path):
+    """llama_attn256.hip keeps O, Q and K in a[0:255] under names hipcc never sees; every asm statement clobbers the whole
+    accumulator file so that the compiler cannot park a value of its own there (it did, in the first build: Q fragments
+    overwritten). Checked on what the Makefile builds: no v_accvgpr_* outside the asm statements anywhere in the kernel, no
+    scratch access in any basic block that holds MFMAs of the steady state (64 per block), every s_barrier behind a
+    vector-memory wait, and every LDS-DMA with its own M0 write."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = tmp_path / "llama_attn256.s"
+    subprocess.run([HIPCC] + FLAGS + ["-fno-slp-vectorize", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-Wno-unused-variable", "-Wno-unused-value",
+                                      "-S", "--cuda-device-only", os.path.join(CSRC, "llama_attn256.hip"), "-o", str(out)],
+                   check=True, capture_output=True, cwd=CSRC)
+    text = out.read_text()
+    m = re.search(r"^(_Z\w*attn_mfma256_kernel\w*):[^\n]*\n(.*?)^\s*s_endpgm", text, flags=re.M | re.S)
+    assert m, "attn_mfma256_kernel not found"
+    in_asm, outside_acc, blocks, cur = False, [], [], []
+    for ln in m.group(2).splitlines():
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        code = t.split(";")[0].strip()
+        if not code:
+            continue
+        if re.match(r"^\.?\w+:$", code) and not in_asm:      # a compiler basic-block label
+            blocks.append(cur)
+            cur = []
+            continue
+        if not in_asm and code.startswith("v_accvgpr"):
+            outside_acc.append(code)
+        cur.append(code)
+    blocks.append(cur)
+    assert not outside_acc, outside_acc[:5]
+    steady = [b for b in blocks if sum(x.startswith("v_mfma") for x in b) == 64]
+    assert steady, "no 64-MFMA block found"
+    for b in steady:
+        assert not any(x.startswith("scratch_") for x in b), "scratch access in a steady-state key block"
+    body = [x for b in blocks for x in b]
+    for i, ln in enumerate(body):
+        if ln.startswith("s_barrier"):
+            back = body[max(0, i - 4):i]
+            assert any("s_waitcnt" in x for x in back), (i, back)
+        if DMA.match(ln):
+            assert any(re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", x) for x in body[max(0, i - 3):i]), (ln, body[max(0, i - 3):i])
+    for key in ("vgpr_spill_count", "sgpr_spill_count"):
+        pass   # (spills outside the key-block loop are allowed: they go to scratch, never to the accumulator file)

@@ -17,14 +17,16 @@ for _ in range(3):
                                   B, nh, nh, hd, 3, C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), C.c_void_p(stream_ptr()))
     assert rc == 0
 torch.cuda.synchronize()
-st = np.zeros(64 * 12, dtype=np.uint64)
-assert l.lr_debug_attn256_stamps(st.ctypes.data_as(C.c_void_p), 64 * 12) == 0
-st = st.reshape(64, 12).astype(np.float64)
-blocks = st[:, 9]
-per = st[:, :9] / blocks[:, None]
-print("steady-state blocks per workgroup (wave 0): median %d" % np.median(blocks))
-print("cycles per 8-gap segment (median over 64 workgroups):", " ".join("%.0f" % x for x in np.median(per[:, :8], 0)))
-print("waits + barrier: %.0f   block total: %.0f   (64 MFMAs = 2048 cycles)" % (np.median(per[:, 8]), np.median(st[:, 10] / blocks)))
+st2 = np.zeros(64 * 24, dtype=np.uint64)
+assert l.lr_debug_attn256_stamps(st2.ctypes.data_as(C.c_void_p), 64 * 24) == 0
+st2 = st2.reshape(64, 2, 12).astype(np.float64)
+for w, name in ((0, "steady-state blocks"), (1, "first blocks (not diagonal)")):
+    st = st2[:, w]
+    blocks = np.maximum(st[:, 9], 1)
+    per = st[:, :9] / blocks[:, None]
+    print("wave 3, %s per workgroup: median %d" % (name, np.median(st[:, 9])))
+    print("  cycles per 8-gap segment (median over 64 workgroups):", " ".join("%.0f" % x for x in np.median(per[:, :8], 0)))
+    print("  waits + barrier: %.0f   block total: %.0f   (64 MFMAs = 2048 cycles)" % (np.median(per[:, 8]), np.median(st[:, 10] / blocks)))
 
 ph = np.zeros(64 * 16, dtype=np.uint64)
 assert l.lr_debug_attn256_phases(ph.ctypes.data_as(C.c_void_p), 64 * 16) == 0
@@ -35,3 +37,11 @@ for w, name in ((0, "wave 0"), (1, "wave 3")):
     tot = np.median(ph[:, w, :5].sum(1))
     print("%s: tiles %d; cycles per tile: prologue %.0f, key blocks %.0f, drain+staging-only blocks %.0f, epilogue %.0f, ticket+rendezvous %.0f; kernel total %.0f"
           % (name, np.median(ph[:, w, 5]), m[0], m[1], m[2], m[3], m[4], tot))
+
+bk = np.zeros(64 * 16, dtype=np.uint64)
+assert l.lr_debug_attn256_blocks(bk.ctrypes.data_as(C.c_void_p) if False else bk.ctypes.data_as(C.c_void_p), 64 * 16) == 0
+bk = bk.reshape(64, 8, 2).astype(np.float64)
+names = ["first", "second", "steady", "third-last", "second-last", "last"]
+print("wave 3, cycles per key block (incl. its barrier) by position in the tile: " +
+      ", ".join("%s %.0f (x%.1f per tile)" % (names[i], np.median(bk[:, i, 0] / np.maximum(bk[:, i, 1], 1)), np.median(bk[:, i, 1]) / max(1.0, np.median(ph[:, 1, 5])))
+                for i in range(6)))

@@ -299,7 +299,7 @@ def emit(mf, ops, lo, hi, first, diag, drain, f):
         if o.kind == "dma" and first:
             continue     # a tile's first block: its K(2) / V(1) were requested behind the PREVIOUS tile's last barrier (the kernel's
                          # pre_issue), in front of that tile's output stores, so that this block's wait need not cover those stores
-        if o.kind == "stamp" and (first or diag or drain):
+        if o.kind == "stamp" and (diag or drain):
             continue     # only the steady-state variant waits for the stamps (an s_memtime landing in a register hipcc has reused
                          # since -- the outputs are dead in the other variants -- overwrote an address: a memory fault)
         if first and hasattr(o, "first_text"):
@@ -382,15 +382,15 @@ def emit_static(f):
             f.write('asm volatile("ds_read_b128 %s, %%0 offset:%d" :: "v"(kaddr_n) : %s);\n'
                     % (areg(K_(kt, ks), 4), kt * 8192 + ks * 512, clob(K_(kt, ks), 4)))
     f.write("#endif\n")
-    # epilogue: one O^T tile (16 registers) at a time into ov[], A2_OSTORE(half, dt) consumes it
-    f.write("#ifdef A2_EMIT_OREAD\n")
+    # epilogue: one O^T tile (16 registers) at a time into ov[], A2_OSTORE(half, dt) consumes it; one section per 32-row half
     for h in range(2):
+        f.write("#ifdef A2_EMIT_OREAD_%d\n" % h)
         for dt in range(4):
             o = O_(h, dt)
             rd = "\\n\\t".join("v_accvgpr_read_b32 %%%d, a%d" % (i, o + i) for i in range(16))
             outs = ", ".join('"=v"(ov[%d])' % i for i in range(16))
             f.write('{ asm volatile("%s" : %s :: A2_ALLA); A2_OSTORE(%d, %d) }\n' % (rd, outs, h, dt))
-    f.write("#endif\n")
+        f.write("#endif\n")
 
 
 def main():
