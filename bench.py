@@ -530,6 +530,7 @@ def main():
         out = {
             "metric": "users/sec through retrieve+rerank", "value": users / elapsed, "unit": "users/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "peak_device_mem_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{args.workload} two-stage: LRURec(V={w['V']}, L={w['L']}, D=64, 2 blocks) top-50 with "
@@ -683,6 +684,35 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
     out[other.replace("-", "") + "_shape"] = {"users_per_s": nu / tb, "steps": len(timed), "users_per_step": nu / len(timed),
                                               "mean_prompt_tokens_per_step": float(np.mean([s["cu"][-1] for s in timed])),
                                               "ms_per_step": tb / len(timed) * 1e3}
+    # SURVEY.md 8(f) #3, the online single-user caller (demo/inference.py:46-76): one 30-item history -> top 20 (no mask) -> one
+    # 460-token prompt -> prefill in LATENCY mode (split-K where the tiles alone would leave most CUs idle) -> verbalizer -> rank
+    from llamarec_amd import metrics as M
+
+    on_tokens = 460
+    rng_o = np.random.default_rng(0)
+    hist_o = rng_o.integers(1, wo["V"] + 1, size=(1, 30)).astype(np.int64)
+    prompt_o = [np.concatenate([[1], rng_o.integers(3, 32000, size=on_tokens - 1)]).astype(np.int32)]
+    lab_o = np.asarray(label_ids, dtype=np.int32)
+    ranker.set_variants(5, 0)
+
+    def online_once():
+        t0 = time.perf_counter()
+        idx, _ = ro.retrieve_topk(hist_o, 20, exclude_history=False)
+        idx.cpu()
+        t1 = time.perf_counter()
+        M.rank_classes(ranker.prefill_verbalize(prompt_o, lab_o)).cpu()
+        return (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
+
+    for _ in range(3):
+        online_once()
+    tr_, tp_ = zip(*[online_once() for _ in range(15)])
+    ranker.set_variants(0, 0)
+    nl = args.layers
+    fl_o = (on_tokens * 12.95e9 + on_tokens ** 2 * 2.62e5) * nl / 32
+    out["online_shape"] = {"users": 1, "prompt_tokens": on_tokens, "layers": nl, "mode": "latency (gemm variant 5)",
+                           "ms_retrieve": float(np.median(tr_)), "ms_prefill": float(np.median(tp_)),
+                           "ms_total": float(np.median(tr_) + np.median(tp_)), "ms_total_min": float(min(a + b for a, b in zip(tr_, tp_))),
+                           "compute_floor_ms": fl_o / 2.5e15 * 1e3, "weight_stream_floor_ms": 13.5e9 * nl / 32 / 8e12 * 1e3}
     # the ranker's LoRA fine-tuning step (reference micro-batch: 16 prompts, config.py:90-97)
     from llamarec_amd.rank_train import LoraTrainEngine
 

@@ -64,6 +64,7 @@ extern "C" int lr_lru_pack(const LrLruWeightsDesc* d, void* host_out, size_t hos
     }
     o[L.item_stats + 0] = nextafterf((float)emax, INFINITY);
     o[L.item_stats + 1] = nextafterf((float)bmax, INFINITY);
+    o[L.item_stats + 2] = LR_LRU_IMAGE_FORMAT;   // what item_stats[32..63] mean depends on it: lr_lru_create rejects another value
     for (size_t r = 0; r < 32; ++r) {   // the last tile's accumulator start values for the bf16 passes (lru_topk.hip, tk_stage_issue)
       const size_t i = (size_t)L.rows_padded - 32 + r;
       o[L.item_stats + 32 + r] = i < rows ? d->item_bias[i] : -INFINITY;
@@ -114,10 +115,19 @@ extern "C" int lr_lru_create(const void* packed_dev, size_t packed_bytes, int32_
   LR_CHECK_HIP(hipPointerGetAttributes(&attr, packed_dev));
   if (attr.type != hipMemoryTypeDevice)
     LR_FAIL(LR_EINVAL, "lr_lru_create: packed image must live in device memory");
+  // The image's meaning changed without its size changing (round 4: item_stats[32..63] became the last tile's accumulator start
+  // values, -inf on padding rows; an older image has zeros there and would score padding rows 0 -- silently wrong top-K). A
+  // caller that caches images across library versions is told so instead.
+  const LrLruLayout lay = lr_lru_layout(num_items, num_blocks);
+  float tag = 0.f;
+  LR_CHECK_HIP(hipMemcpy(&tag, (const float*)packed_dev + lay.item_stats + 2, sizeof(float), hipMemcpyDeviceToHost));
+  if (tag != LR_LRU_IMAGE_FORMAT)
+    LR_FAIL(LR_EINVAL, "lr_lru_create: packed image has format tag %g, this library reads %g: repack it with lr_lru_pack", (double)tag,
+            (double)LR_LRU_IMAGE_FORMAT);
   lr_lru* h = (lr_lru*)calloc(1, sizeof(lr_lru));
   if (!h) LR_FAIL(LR_EINVAL, "lr_lru_create: out of host memory");
   h->img = (const float*)packed_dev;
-  h->lay = lr_lru_layout(num_items, num_blocks);
+  h->lay = lay;
   h->device = attr.device;
   h->encoder_pipeline = 1;
   *out = h;

@@ -195,11 +195,7 @@ __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsi
 // output-row stores of that tile are younger still.
 #define A2_BARRIER_8() asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
 #define A2_BARRIER_24() asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
-#ifdef A2_ABL_NOBARRIER   // timing-only ablation (wrong results): the waits without the rendezvous
-#define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", A2_ALLA)
-#else
 #define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
-#endif
 
 #ifdef A2_STAMPS   // diagnostic build only (tools/build_attn256_abl.sh stamps): per-block s_memtime deltas, wave 0 of 64 workgroups
 __device__ unsigned long long g_a256_stamps[64 * 24];   // [workgroup][steady | first blocks][12]

@@ -219,13 +219,6 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const u16* __restrict
 // 256 x 256 x 64 kernel
 // =============================================================================================
 #define G2_STAGE_BYTES 65536  // A tile 32 KiB + B tile 32 KiB
-// Ablation builds only (tools/gpu_r4_gemm_abl.sh compiles this file with -DG2_ABL=n into SEPARATE libraries; results are
-// garbage, timings and counters are the point; the product is built without it): bit 0 = no DMA after the prologue,
-// bit 1 = no fragment reads after the first K tile's, bit 2 = every workgroup streams tile (0, 0)'s operand panels (same
-// DMA and LDS traffic, operands L2-resident: nothing crosses the fabric).
-#ifndef G2_ABL
-#define G2_ABL 0
-#endif
 #define G2_GROUP_M 8
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -359,11 +352,11 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
       const int row = rows[t] + srow;
       const int chunk = spos ^ ((row >> 1) & 7);
       if (isA[t]) {
-        const int arow = min(((G2_ABL & 4) ? 0 : m0) + row, M - 1);
+        const int arow = min(m0 + row, M - 1);
         src[t][j] = reinterpret_cast<const char*>(A) + ((size_t)arow * K) * 2 + chunk * 16 + (size_t)kt_first * 128;
         ldsoff[t][j] = rows[t] * 128;
       } else {
-        src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(((G2_ABL & 4) ? 0 : n0) + row) * K) * 2 + chunk * 16 + (size_t)kt_first * 128;
+        src[t][j] = reinterpret_cast<const char*>(B) + ((size_t)(n0 + row) * K) * 2 + chunk * 16 + (size_t)kt_first * 128;
         ldsoff[t][j] = 32768 + rows[t] * 128;
       }
     }
@@ -421,29 +414,29 @@ __global__ __launch_bounds__(512) void gemm256rb_kernel(const u16* __restrict__ 
     const bool more = (kt) + 1 < nkt;                                                                 \
     const bool more2 = (kt) + 2 < nkt;                                                                \
     /* phase 0: quadrant (0,0) */                                                                     \
-    if (!(G2_ABL & 2) || (kt) == 0) { RB_LOAD_A(cur, 0) }                                             \
-    if (more && !(G2_ABL & 1)) RB_DMA(3, (kt) + 1);                                                   \
+    RB_LOAD_A(cur, 0)                                                                                 \
+    if (more) RB_DMA(3, (kt) + 1);                                                                    \
     RB_WAIT(more2)                                                                                    \
     PP_BARRIER();                                                                                     \
     RB_MFMA(b0cur, 0, 0)                                                                              \
     PP_BARRIER();                                                                                     \
     /* phase 1: quadrant (0,1) */                                                                     \
-    if (!(G2_ABL & 2) || (kt) == 0) { RB_LOAD_B(b1, cur, 1) }                                         \
-    if (more2 && !(G2_ABL & 1)) RB_DMA(1, (kt) + 2);                                                  \
+    RB_LOAD_B(b1, cur, 1)                                                                             \
+    if (more2) RB_DMA(1, (kt) + 2);                                                                   \
     RB_WAIT(more2)                                                                                    \
     PP_BARRIER();                                                                                     \
     RB_MFMA(b1, 0, 1)                                                                                 \
     PP_BARRIER();                                                                                     \
     /* phase 2: quadrant (1,1) */                                                                     \
-    if (!(G2_ABL & 2) || (kt) == 0) { RB_LOAD_A(cur, 1) }                                             \
-    if (more2 && !(G2_ABL & 1)) RB_DMA(0, (kt) + 2);                                                  \
+    RB_LOAD_A(cur, 1)                                                                                 \
+    if (more2) RB_DMA(0, (kt) + 2);                                                                   \
     RB_WAIT(more2)                                                                                    \
     PP_BARRIER();                                                                                     \
     RB_MFMA(b1, 1, 1)                                                                                 \
     PP_BARRIER();                                                                                     \
     /* phase 3: quadrant (1,0); reads the next tile's B(nh0) */                                       \
-    if (more && (!(G2_ABL & 2) || (kt) == 0)) { RB_LOAD_B(b0nxt, nxt, 0) }                            \
-    if (more2 && !(G2_ABL & 1)) RB_DMA(2, (kt) + 2);                                                  \
+    if (more) { RB_LOAD_B(b0nxt, nxt, 0) }                                                            \
+    if (more2) RB_DMA(2, (kt) + 2);                                                                   \
     RB_WAIT(more2)                                                                                    \
     PP_BARRIER();                                                                                     \
     RB_MFMA(b0cur, 1, 0)                                                                              \

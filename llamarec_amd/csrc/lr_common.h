@@ -46,6 +46,7 @@ static inline int lr_ensure_dynamic_lds(const void* kernel, int bytes, bool* don
 // ---- packed LRURec device image (all float32; offsets in floats) ----------------------------
 // Produced by lr_lru_pack() on the host, consumed by the kernels in lru_encoder.hip / lru_topk.hip.
 #define LR_ITEM_TILE 32  // items per MFMA tile; the table is zero-padded to a multiple of this
+#define LR_LRU_IMAGE_FORMAT 5.0f   // written to item_stats[2] by lr_lru_pack; bump when an array of the image changes meaning
 
 struct LrLruBlockLayout {
   size_t lam_re, lam_im, gamma;  // [128] each
@@ -68,7 +69,7 @@ struct LrLruLayout {
   size_t item_emb;       // [rows_padded][64]
   size_t item_bias;      // [rows_padded]
   size_t item_emb_bf16;  // [rows_padded][64] bfloat16 (round-to-nearest-even copy of item_emb): the top-K bound pre-pass
-  size_t item_stats;     // [0] >= max_i ||item_emb[i]||_2, [1] >= max_i |item_bias[i]|  (rounded up); [32..63] the biases of the
+  size_t item_stats;     // [0] >= max_i ||item_emb[i]||_2, [1] >= max_i |item_bias[i]|  (rounded up); [2] LR_LRU_IMAGE_FORMAT; [32..63] the biases of the
                          // table's LAST 32-row tile with -inf on its padding rows (item_bias has NaN there): the bf16 passes'
                          // accumulator start values, so that a padding row's approximate score is -inf and needs no row test
   size_t emb_ln_w, emb_ln_b;

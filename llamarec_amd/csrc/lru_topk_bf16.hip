@@ -146,9 +146,6 @@ __global__ __launch_bounds__(512, 4) void item_bound_kernel(BoundParams p) {
       tk_stage_issue<ST>(p.emb16, p.bias, p.bias_tail, tile_begin + (st + 1) * ST, p.n_tiles, smem + ((st + 1) & 1) * TkStage<ST>::BYTES,
                          wave, lane);
     if constexpr (GROUPED) {
-#if defined(TK_ABL) && (TK_ABL & 2)
-      TkTile tl0;
-#endif
       // (an explicit two-register-set prefetch of tile u + 1's fragments ahead of tile u's MFMAs does not fit the 128
       // VGPRs that two workgroups per CU leave a wave: hipcc spilled 85 registers; four waves per SIMD cover the reads)
 #pragma unroll 1
@@ -156,20 +153,10 @@ __global__ __launch_bounds__(512, 4) void item_bound_kernel(BoundParams p) {
         const int tile = tile_begin + st * ST + u;
         if (tile >= tile_end) break;   // wave-uniform
         TkTile tl;   // (a tile past the table cannot occur here: tile < tile_end <= n_tiles)
-#if defined(TK_ABL) && (TK_ABL & 2)   // ablation: every tile of the stage multiplies the stage's FIRST tile (fragments read once)
-        if (u == 0) tl0.load(buf, buf + TkStage<ST>::FRAG_BYTES, lane, half);
-        tl = tl0;
-#else
         tl.load(buf + u * 4096, buf + TkStage<ST>::FRAG_BYTES + u * 128, lane, half);
-#endif
 #pragma unroll
         for (int c = 0; c < UC; ++c) {
-#if defined(TK_ABL) && (TK_ABL & 1)   // ablation build (tools/gpu_r4_stage1_abl.sh), never shipped: no 16-register maximum
-          const floatx16 acc = tl.scores(bq[c]);
-          gm[c] = fmaxf(gm[c], fmaxf(acc[0], acc[15]));
-#else
           gm[c] = fmaxf(gm[c], tk_max16(tl.scores(bq[c])));
-#endif
         }
         if ((((tile + 1) >> p.gshift) != (tile >> p.gshift)) || tile + 1 >= tile_end) {   // last tile of its group (wave-uniform)
 #pragma unroll

@@ -37,19 +37,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define TS_LP 68           // LDS pitch (floats) of a wave's [16][64] logits tile: 17 chunks of 16 B, conflict-free both ways
 
 
-// -DTS_STAMP (experiment builds only): s_memtime around the load-issue and compute sections of a wave's loop, printed for a few waves
-#ifdef TS_STAMP
-#include <stdio.h>
-#define TS_STAMP_DECL unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tl_ = 0, tc_ = 0, n_ = 0, tb_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb_)::"memory");
-#define TS_T(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");
-#define TS_ACC tl_ += (t1 - t0) + (t3 - t2); tc_ += (t2 - t1) + (t4 - t3); n_ += 2;
-#define TS_REPORT(name) { unsigned long long te_; TS_T(te_) if ((threadIdx.x & 63) == 0 && blockIdx.x % 61 == 0 && blockIdx.y == 0) printf(name " wg %d wave %d: %llu computes, load issue %llu, compute %llu, loop total %llu cycles -> %llu per compute\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), n_, tl_, tc_, te_ - tb_, n_ ? tc_ / n_ : 0ull); }
-#else
-#define TS_STAMP_DECL
-#define TS_T(x)
-#define TS_ACC
-#define TS_REPORT(name)
-#endif
 
 struct TsArgs {
   const float *x, *E, *bias;
@@ -177,7 +164,11 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
         m[q] = mn;
       }
     }
-    // the wave's (16 TS_P) x 64 tile leaves through LDS: 4 rows x 256 B per store instruction (lane = row 4 i + g, chunk li)
+    // the wave's (16 TS_P) x 64 tile leaves through LDS: 4 rows x 256 B per store instruction (lane = row 4 i + g, chunk li).
+    // The tile is wave-private, written by one set of lanes and read straight back by another: the wave barrier + fence pin the
+    // order of those may-alias LDS accesses for any future scheduler (no instruction is emitted for them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const int col = v0 + 4 * li;
 #pragma unroll
     for (int i = 0; i < 4 * TS_P; ++i) {
@@ -185,6 +176,8 @@ __global__ __launch_bounds__(256) void ts_scores_kernel(TsArgs a) {
       const float4 o = *reinterpret_cast<const float4*>(tile + r * TS_LP + 4 * li);
       if (row0 + r < a.Rpad) *reinterpret_cast<float4*>(a.logits + (size_t)(row0 + r) * a.ldl + col) = o;   // padding rows: finite values
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // ... and the next block's stores stay behind these reads
   };
   // One register set of loads ahead. The sched_barrier keeps hipcc from sinking the next set's loads below the MFMAs (it
   // does, to save registers). The loads are UNCONDITIONAL (index clamped; a set that is not needed is loaded and dropped):
@@ -312,12 +305,16 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
     *reinterpret_cast<float4*>(tile + (4 + g) * TS_LP + 4 * li) = l_##1;                                          \
     *reinterpret_cast<float4*>(tile + (8 + g) * TS_LP + 4 * li) = l_##2;                                          \
     *reinterpret_cast<float4*>(tile + (12 + g) * TS_LP + 4 * li) = l_##3;                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   /* the wave-private tile: stores by one set of lanes, reads by another */ \
+    __builtin_amdgcn_wave_barrier();                                                                              \
     /* all 16 softmax values first, then the 64 MFMAs back to back: left to itself hipcc forms one value per four MFMAs */ \
     /* in ONE register, the subtract -> v_exp_f32 chain behind every fourth MFMA (67-68 -> 65-66 us; the same regrouping in */ \
     /* ts_de_kernel, whose values feed sixteen MFMAs each, cost 57 -> 77 us: there the interleaved form hides them)      */ \
     float4 dl_[4];                                                                                                \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
       dl_[j] = ts_p4(*reinterpret_cast<const float4*>(tile + li * TS_LP + 16 * j + 4 * g), lse2);                 \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   /* the next block's stores stay behind these reads */ \
+    __builtin_amdgcn_wave_barrier();                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                               \
@@ -399,23 +396,15 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
   };
   TsDeLoads A, B;   // unconditional loads, see ts_scores_kernel
   int it = it0 + wave;
-  TS_STAMP_DECL
   load(min(it, nit - 1), A);
   for (; it < nit; it += 8) {
-    TS_T(t0)
     load(min(it + 4, nit - 1), B);
     __builtin_amdgcn_sched_barrier(0);
-    TS_T(t1)
     compute(A);
-    TS_T(t2)
     load(min(it + 8, nit - 1), A);
     __builtin_amdgcn_sched_barrier(0);
-    TS_T(t3)
     if (it + 4 < nit) compute(B);
-    TS_T(t4)
-    TS_ACC
   }
-  TS_REPORT("de")
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
 #pragma unroll

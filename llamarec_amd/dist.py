@@ -55,3 +55,16 @@ def all_reduce_max_float(x: float, device=None) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
+
+
+def broadcast_shard_edges(edges, device=None):
+    """Every rank scores the shard RANK 0 cut: [(lo, hi)] * world as an int64 tensor broadcast from rank 0, so that the ranks
+    agree on the edges by construction (the lazy evaluation path derives them from a least-squares estimate of the prompt
+    lengths, which two nodes could round differently) -- and a disagreement is impossible BEFORE the LLM evaluation runs, not
+    discovered after it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return edges
+    t = torch.tensor(edges, dtype=torch.int64, device=device).reshape(-1)
+    dist.broadcast(t, src=0)
+    t = t.cpu().reshape(-1, 2)
+    return [(int(a), int(b)) for a, b in t]

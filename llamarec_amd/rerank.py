@@ -70,7 +70,7 @@ class LLMEvaluator:
         if isinstance(self.items, LazyEvalItems):
             # shard FIRST (by the title-cache estimate of every prompt's tokens), tokenise only this rank's users, in a
             # producer thread that stays ahead of the GPU loop
-            lo, hi = PK.shard_by_tokens(self.items.estimate_lengths(), world)[rank]
+            lo, hi = D.broadcast_shard_edges(PK.shard_by_tokens(self.items.estimate_lengths(), world), self.model.device)[rank]
             self._shard = (lo, hi)
             if self.token_budget:
                 stream = stream_token_budget_batches(self.items, lo, hi, self.token_budget, self.max_text_len,
@@ -84,7 +84,7 @@ class LLMEvaluator:
             return self._finish(hist, t0)
         # contiguous shards balanced by prompt TOKENS, then token-budget batches inside the shard
         lens = np.array([min(len(it["input_ids"]), self.max_text_len) for it in self.items], dtype=np.int64)
-        lo, hi = PK.shard_by_tokens(lens, world)[rank]
+        lo, hi = D.broadcast_shard_edges(PK.shard_by_tokens(lens, world), self.model.device)[rank]
         self._shard = (lo, hi)
         mine = self.items[lo:hi]
         if self.token_budget:
@@ -110,7 +110,7 @@ class LLMEvaluator:
         # every rank cut its own shard (the lazy path from its own least-squares estimate of the prompt lengths): the
         # shards must tile the items exactly and the all-reduced histogram must count every user once, or a rounding
         # difference between nodes would silently drop or double-count users
-        lo, hi = getattr(self, "_shard", (0, len(self.items)))
+        lo, hi = self._shard          # set by predict() on every path (no default: a path that forgot it must fail here)
         cover = torch.tensor([hi - lo], dtype=torch.int64, device=hist.device)
         D.all_reduce_sum_(cover)
         D.all_reduce_sum_(hist)

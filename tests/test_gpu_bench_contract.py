@@ -76,6 +76,26 @@ def test_bench_two_ranks_on_one_card_over_gloo():
 
 
 @pytest.mark.gpu
+def test_bench_four_ranks_on_one_card_over_gloo():
+    """The spawn path with more ranks than the 2-rank rehearsal (make the driver's first 8-rank run
+    boring): 4 ranks on cuda:0 over gloo, one layer, one step. The pool allows at most 6 processes on a card, so the 8-rank case
+    itself is the driver's to run; everything rank-count-dependent -- the port/rank plumbing of spawn_ranks, N random inits,
+    the census, the all-reduced histogram -- is the same code at 4. Rank 0's peak device memory rides in the line."""
+    r = _run_bench(["--gpus", "4", "--share-gpu", "--dist-backend", "gloo", "--layers", "1", "--steps", "1", "--warmup", "0",
+                    "--no-other-shapes"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["steps"] == 1 and d["config"]["parallelism"] == "dp4"
+    per_rank = d["config"]["users_per_step"] * d["steps"]
+    counted = d["metrics"]["users_counted"]
+    assert abs(counted - 4 * per_rank) <= 0.3 * per_rank, (counted, per_rank)
+    assert d["metrics"]["retrieve_matches_expected"] is True
+    assert 0.0 < d["peak_device_mem_gb_rank0"] < 24.0      # one layer + embeddings + head + the 32 768-row workspace
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_ranks_than_gpus():
     """--gpus N on a node with fewer than N cards (and no --share-gpu): exit code 2, a message, NO result line -- a
     1-GPU number is never reported as n_gpus = N."""
@@ -103,3 +123,7 @@ def test_bench_side_fields_carry_the_training_steps():
     lt = d["lora_train_shape"]
     assert lt["loss_finite"] is True and lt["workspace_allocations_in_timed_loop"] == 0 and lt["tokens_per_s"] > 0
     assert d["ml100k_shape"]["users_per_s"] > 0
+    on = d["online_shape"]     # SURVEY 8(f) #3 in the driver's line
+    assert on["users"] == 1 and on["prompt_tokens"] == 460 and on["layers"] == 32
+    assert abs(on["ms_total"] - (on["ms_retrieve"] + on["ms_prefill"])) < 1e-6
+    assert 0.0 < on["compute_floor_ms"] < on["ms_prefill"] < 50.0 and 0.0 < on["ms_retrieve"] < 10.0

@@ -582,6 +582,58 @@ def test_full_depth_full_width_parity_vs_oracle():
           f"clear top-1 prompts={int(clear_top1.sum())} of {ref.shape[0]}")
 
 
+@pytest.mark.parametrize("attention", [0, 3])
+def test_eight_layers_long_prompts_parity_vs_oracle(attention):
+    """Depth AND length together: 8 layers at the full width of Llama-2-7b over two prompts of 740 and
+    1 100 tokens -- attention over 12 .. 18 key blocks feeding 8 layers of bf16 drift, the regime the headline runs in (the
+    32-layer gate uses short prompts, the bench's parity block 4 layers). Same three statements as the full-depth test plus
+    >= 50 decided pairs: max |HIP - oracle_bf16| <= 2 GAP, rms vs the fp32 oracle <= 1.25 x the oracle's own, the order of every
+    pair the oracle separates by 4 GAP, top-1 where it leads by 2 GAP; for the default attention and the 256-row kernel."""
+    from llamarec_amd.llm import LLAMA2_7B, LlamaRanker
+    from llamarec_amd.synth import llama_param_shapes
+    from oracle import llama_oracle as LO
+
+    cfg = dict(LLAMA2_7B, num_hidden_layers=8)
+    g = torch.Generator(device="cuda").manual_seed(31)
+    sd = {}
+    for name, shape in llama_param_shapes(cfg):
+        if len(shape) == 1:
+            w = 1.0 + (torch.rand(shape, generator=g, device="cuda") * 0.2 - 0.1)
+        else:
+            w = torch.randn(shape, generator=g, device="cuda") * 0.02
+        sd[name] = w.to(torch.bfloat16).float().cpu().numpy()
+    rng = np.random.default_rng(5)
+    head = np.concatenate([[1], rng.integers(3, 32000, size=35)])            # a 36-token template prefix, like the bench's
+    seqs = [np.concatenate([head, rng.integers(3, 32000, size=n - 36)]).astype(np.int32) for n in (740, 1100)]
+    label_ids = list(range(319, 339))
+    key = "_oracle_8x"                                                        # the two oracle runs are shared by both parameters
+    cache = globals().setdefault(key, {})
+    if not cache:
+        cache["ref"] = LO.prefill_verbalize(sd, cfg, seqs, label_ids, "bf16")
+        cache["exact"] = LO.prefill_verbalize(sd, cfg, seqs, label_ids, "fp32")
+    ref, exact = cache["ref"], cache["exact"]
+    gap = float(np.abs(ref - exact).max())
+    rms_gap = float(np.sqrt(((ref - exact) ** 2).mean()))
+    assert 1e-2 < gap < 0.6 and float(np.abs(ref).max()) > 0.5
+    d_ref = ref[:, :, None] - ref[:, None, :]
+    decided = np.abs(d_ref) > 4 * gap
+    n_decided = int(decided.sum()) // 2
+    print(f"8 layers x (740, 1100) tokens: gap={gap:.3f} max|score|={np.abs(ref).max():.2f} decided pairs={n_decided} of {ref.shape[0] * 190}")
+    assert n_decided >= 50, (n_decided, gap)
+    srt = np.sort(ref, axis=1)
+    clear_top1 = (srt[:, -1] - srt[:, -2]) > 2 * gap
+    model = LlamaRanker.from_state_dict(sd, cfg).set_variants(0, attention)
+    for share, prune in ((True, True), (False, False)):
+        model.set_last_layer_pruning(prune)
+        got = model.prefill_verbalize(seqs, label_ids, share_prefix=share).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 2 * gap, (share, prune, np.abs(got - ref).max(), gap)
+        assert np.sqrt(((got - exact) ** 2).mean()) <= 1.25 * rms_gap, (share, prune)
+        d_got = got[:, :, None] - got[:, None, :]
+        assert (np.sign(d_ref[decided]) == np.sign(d_got[decided])).all(), (share, prune)
+        assert (got.argmax(1)[clear_top1] == ref.argmax(1)[clear_top1]).all(), (share, prune)
+
+
 def test_full_width_new_paths_vs_generic_kernels():
     """the loose full-width gate (2 x the bf16 noise floor) would let a moderate regression in a NEW path
     through, and the bit-equality tests compare new paths with each other. Tight checks against the generic kernels:

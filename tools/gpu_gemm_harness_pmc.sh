@@ -1,12 +1,13 @@
 #!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}   # set before any cd: a missing variable must not turn into /gpurun_out and /tools paths
 # Counters over the stand-alone GEMM harness (tools/diag/gemm_bm.hip, quick mode = the product's tile on the two batch shapes):
 # what the vector-memory path of a CU looks like under the K loop -- texture-addresser busy, L1 stalls, and the L2 read latency a CU sees.
 # Separate --pmc passes (no trace domains besides --kernel-trace), outputs under gpurun_out/gemm_harness_pmc/.
 set -e
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/gemm_harness_pmc
+OUT=$R/gpurun_out/gemm_harness_pmc
 mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/gemm_bm $GRAFT_REPO_ROOT/tools/diag/gemm_bm.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/gemm_bm $R/tools/diag/gemm_bm.hip
 rocprofv3 -L > $OUT/counters.txt 2>&1 || true
 grep -o -E "\b(TA_[A-Z0-9_]+|TCP_[A-Z0-9_]+|TD_[A-Z0-9_]+)\b" $OUT/counters.txt | sort -u > $OUT/ta_tcp_names.txt || true
 wc -l $OUT/ta_tcp_names.txt

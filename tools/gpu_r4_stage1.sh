@@ -1,4 +1,5 @@
 #!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}   # set before any cd: a missing variable must not turn into /gpurun_out and /tools paths
 # round 4, stage 1: bit-exactness tests of the retriever, its throughput at the BASELINE shapes, per-kernel breakdown at
 # Synth-1M (4 096 users) and Beauty.   usage: bash tools/gpu_r4_stage1.sh <tag>
 TAG=${1:-r4s1}
@@ -12,8 +13,8 @@ echo "pytest rc=$rc"
 timeout -k 10 300 python tools/bench_stage1.py 2>&1 | grep -v amdgpu.ids | tee $OUT/bench.log
 cd /tmp && export TMPDIR=/tmp
 for w in synth-1m beauty; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/kt_$w -- python3 $GRAFT_REPO_ROOT/tools/bench_stage1.py $w > $GRAFT_REPO_ROOT/$OUT/kt_$w.log 2>&1 || exit 1
-  f=$(find $GRAFT_REPO_ROOT/$OUT/kt_$w -name '*kernel_stats.csv' | head -1)
-  cp $f $GRAFT_REPO_ROOT/$OUT/stage1_${w}_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kt_$w -- python3 $R/tools/bench_stage1.py $w > $R/$OUT/kt_$w.log 2>&1 || exit 1
+  f=$(find $R/$OUT/kt_$w -name '*kernel_stats.csv' | head -1)
+  cp $f $R/$OUT/stage1_${w}_kernel_stats.csv
   head -14 $f | cut -c1-150
 done
