@@ -1034,7 +1034,7 @@ int lr_launch_item_topk(const lr_lru* h, const float* q, const int64_t* ids, int
       if (target_wgs > 0) chunks = (target_wgs + n_ut - 1) / n_ut;
     }
     if (chunks < min_chunks) chunks = min_chunks;
-    const int unit = bp.gshift > 2 ? (1 << bp.gshift) : 4;   // a chunk is whole float4 iterations AND whole tile groups
+    const int unit = bp.gshift >= 2 ? (4 << bp.gshift) : 4;  // a chunk is whole float4 iterations / whole quads of tile groups
     const int units = (p.n_tiles + unit - 1) / unit;
     if (chunks > units) chunks = units;
     bp.tiles_per_chunk = unit * ((units + chunks - 1) / chunks);

@@ -127,15 +127,21 @@ __global__ __launch_bounds__(512, 4) void item_bound_kernel(BoundParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the DMA's LDS base goes through M0 (an SGPR)
   const int half = lane >> 5, col = lane & 31;
-  const int tile_begin = blockIdx.x * p.tiles_per_chunk;
+  const TkWho who = tk_who(p.n_chunks, p.n_user_groups);
+  if (who.chunk < 0) return;
+  const int tile_begin = who.chunk * p.tiles_per_chunk;
   const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
   if (tile_begin >= tile_end) return;
   const int n_stages = (tile_end - tile_begin + ST - 1) / ST;
   tk_stage_issue<ST>(p.emb16, p.bias, p.bias_tail, tile_begin, p.n_tiles, smem, wave, lane);
   int user[UC];
   tk_bf16x8 bq[UC][4];
-  tk_load_q_bf16<UC>(p.q, p.B, (blockIdx.y * 8 + wave) * (32 * UC), col, half, user, bq);
+  tk_load_q_bf16<UC>(p.q, p.B, (who.group * 8 + wave) * (32 * UC), col, half, user, bq);
   float gm[UC];   // GROUPED: running maximum of the lane's rows over the current group
+  float4 g4[UC];  // GROUPED: the maxima of four consecutive groups, stored as one 16-byte piece (a 4-byte store per user and group
+                  // touched a line each: 259 MB of write traffic per launch for 32 MB of maxima, measured in round 4)
+#pragma unroll
+  for (int c = 0; c < UC; ++c) g4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int c = 0; c < UC; ++c) gm[c] = -__builtin_inff();
   for (int st = 0; st < n_stages; ++st) {
@@ -159,10 +165,17 @@ __global__ __launch_bounds__(512, 4) void item_bound_kernel(BoundParams p) {
           gm[c] = fmaxf(gm[c], tk_max16(tl.scores(bq[c])));
         }
         if ((((tile + 1) >> p.gshift) != (tile >> p.gshift)) || tile + 1 >= tile_end) {   // last tile of its group (wave-uniform)
+          const int grp = tile >> p.gshift, slot = grp & 3;   // (a chunk starts at a multiple of four groups or is the ragged last one:
+                                                              // tmax rows are padded to a multiple of 4, so a whole float4 is always in bounds)
+          const bool flush = slot == 3 || tile + 1 >= tile_end;
 #pragma unroll
           for (int c = 0; c < UC; ++c) {
             const float m = fmaxf(gm[c], __shfl_xor(gm[c], 32, 64));   // the other lane half holds the tiles' other 16 rows
-            if (user[c] < p.B && half == 0) p.tmax[(size_t)user[c] * p.ld + (tile >> p.gshift)] = m;
+            g4[c].x = slot == 0 ? m : g4[c].x;
+            g4[c].y = slot == 1 ? m : g4[c].y;
+            g4[c].z = slot == 2 ? m : g4[c].z;
+            g4[c].w = slot == 3 ? m : g4[c].w;
+            if (flush && user[c] < p.B && half == 0) *reinterpret_cast<float4*>(p.tmax + (size_t)user[c] * p.ld + (grp & ~3)) = g4[c];
             gm[c] = -__builtin_inff();
           }
         }
@@ -215,7 +228,9 @@ __global__ __launch_bounds__(512, 4) void item_cand_kernel(CandParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the DMA's LDS base goes through M0 (an SGPR)
   const int half = lane >> 5, col = lane & 31;
-  const int tile_begin = blockIdx.x * p.tiles_per_chunk;
+  const TkWho who = tk_who(p.n_chunks, p.n_user_groups);
+  if (who.chunk < 0) return;
+  const int tile_begin = who.chunk * p.tiles_per_chunk;
   const int tile_end = min(p.n_tiles, tile_begin + p.tiles_per_chunk);
   if (tile_begin >= tile_end) return;
   const int n_stages = (tile_end - tile_begin + ST - 1) / ST;
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(512, 4) void item_cand_kernel(CandParams p) {
   int user[UC];
   float thr[UC];
   tk_bf16x8 bq[UC][4];
-  tk_load_q_bf16<UC>(p.q, p.B, (blockIdx.y * 8 + wave) * (32 * UC), col, half, user, bq);
+  tk_load_q_bf16<UC>(p.q, p.B, (who.group * 8 + wave) * (32 * UC), col, half, user, bq);
 #pragma unroll
   for (int c = 0; c < UC; ++c) thr[c] = user[c] < p.B ? p.cand_thresh[user[c]] : __builtin_inff();
   for (int st = 0; st < n_stages; ++st) {
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(512, 4) void item_cand_kernel(CandParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no DMA is pending here: the last stage issues none; tests/test_isa_checks.py)
   __syncthreads();
   for (int ul = tid; ul < USERS; ul += 512) {  // thread = one user of the workgroup: reserve room in the global list once, copy
-    const int gu = blockIdx.y * USERS + ul;
+    const int gu = who.group * USERS + ul;
     const int n = lcnt[ul];
     if (gu < p.B && n > 0) {
       // (entries past LCAP went to the global list when they were found; a global count past TK_CAND_CAP makes
@@ -296,23 +311,30 @@ __global__ __launch_bounds__(512, 4) void item_cand_kernel(CandParams p) {
 // 449 / 566 us, 83 / 104 us against 53 / 84 us on Beauty. The kernels keep the template parameter.
 int lr_bf16_users_per_wg(int B) { (void)B; return 512; }
 
-int lr_launch_item_bound(const BoundParams& p, int chunks, hipStream_t st) {
-  if (p.gshift < 0 || p.gshift == 1 || p.tiles_per_chunk % (p.gshift > 2 ? (1 << p.gshift) : 4) != 0)
+int lr_launch_item_bound(const BoundParams& p0, int chunks, hipStream_t st) {
+  BoundParams p = p0;
+  // a chunk is whole float4 iterations (one maximum per tile) or whole QUADS of tile groups (grouped: four groups' maxima leave
+  // as one 16-byte store)
+  if (p.gshift < 0 || p.gshift == 1 || p.tiles_per_chunk % (p.gshift >= 2 ? (4 << p.gshift) : 4) != 0)
     LR_FAIL(LR_EINVAL, "item_bound_kernel: gshift=%d tiles_per_chunk=%d", p.gshift, p.tiles_per_chunk);
   const int upw = lr_bf16_users_per_wg(p.B);
-  const dim3 grid(chunks, (p.B + upw - 1) / upw);
+  p.n_chunks = chunks;
+  p.n_user_groups = (p.B + upw - 1) / upw;
+  const dim3 grid(tk_grid(p.n_chunks, p.n_user_groups));
   if (p.gshift == 0) hipLaunchKernelGGL((item_bound_kernel<false, 2>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((item_bound_kernel<true, 2>), grid, dim3(512), 0, st, p);
   LR_CHECK_LAUNCH("item_bound_kernel");
   return LR_OK;
 }
 
-int lr_launch_item_cand(const CandParams& p, int chunks, hipStream_t st) {
-  (void)0;
+int lr_launch_item_cand(const CandParams& p0, int chunks, hipStream_t st) {
+  CandParams p = p0;
   const int upw = lr_bf16_users_per_wg(p.B);
   if (p.tiles_per_chunk > lr_bf16_max_chunk_tiles(p.B))
     LR_FAIL(LR_EINVAL, "item_cand_kernel: %d tiles per chunk, at most %d", p.tiles_per_chunk, lr_bf16_max_chunk_tiles(p.B));
-  const dim3 grid(chunks, (p.B + upw - 1) / upw);
+  p.n_chunks = chunks;
+  p.n_user_groups = (p.B + upw - 1) / upw;
+  const dim3 grid(tk_grid(p.n_chunks, p.n_user_groups));
   hipLaunchKernelGGL((item_cand_kernel<2>), grid, dim3(512), 0, st, p);
   LR_CHECK_LAUNCH("item_cand_kernel");
   return LR_OK;

@@ -100,7 +100,7 @@ def test_out_of_range_labels_are_ignored_and_counted(golden_dir):
     z, names = load(golden_dir)
     eng = make_engine(z, names)
     ref = float(eng.loss_and_grads(z["tokens"], z["labels"]))
-    g_ref = eng.grads.clone()
+    g_ref = eng.grad_dict()
     assert eng.bad_labels == 0
     lab = z["labels"].copy()
     tok = z["tokens"].copy()
@@ -109,8 +109,14 @@ def test_out_of_range_labels_are_ignored_and_counted(golden_dir):
     tok2 = np.concatenate([tok, tok[:3]])
     loss = float(eng.loss_and_grads(tok2, lab2))
     assert eng.bad_labels == 3 * lab.shape[1]
-    # the loss sum is accumulated with fp32 atomics: the extra rows change their order, not the terms
-    assert abs(loss - ref) < 1e-5 and torch.allclose(eng.grads, g_ref, rtol=2e-4, atol=1e-6)   # a row that leaked would add ~1e-3
+    # the loss and the weight-gradient sums are accumulated with fp32 atomics: the extra rows change the ORDER of the terms, not the
+    # terms. A row that leaked would add ~1e-3 of a tensor's scale; the order noise is ~1e-6 of it. The check is per tensor and
+    # relative to the tensor's largest entry, so that a leak into a small-magnitude tensor cannot hide under an absolute bound
+    # sized for the large ones.
+    assert abs(loss - ref) < 1e-5
+    got = eng.grad_dict()
+    for n in names:
+        assert rel_err(as_pairs(got[n]), as_pairs(g_ref[n])) < 2e-5, (n, rel_err(as_pairs(got[n]), as_pairs(g_ref[n])))
 
 
 def test_graph_replay_equals_direct_launches(golden_dir):
