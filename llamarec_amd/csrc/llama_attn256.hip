@@ -499,12 +499,10 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #ifdef A2_STAMPS
       if constexpr (!DIAG) {   // [0..7] eight-gap segments, [8] waits + barrier, [9] blocks; first blocks in the second set
         unsigned long long te_;
-        unsigned long long tw_ = 0;
         if (FIRST && had_epilogue)
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %10\n\ts_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\t"
-                       "s_mov_b64 %8, %10\n\ts_mov_b64 %9, %0\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
+          asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
                        : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
-                         "+s"(st_[7]), "+s"(st_[8]), "=&s"(tw_) :: "memory", A2_ALLA);
+                         "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
         else
           asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
                        : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
