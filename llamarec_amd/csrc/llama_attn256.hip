@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 
 #ifdef A2_STAMPS
   unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_blk0 = 0;
   unsigned long long stF_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_prev, bk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_prev)::"memory");
@@ -331,7 +332,16 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   auto decode = [&](int item) {
     Tile t;
     t.valid = item >= 0;
-    const int2 it = items[t.valid ? item : 0];
+    // a SCALAR load: hipcc reads the list with a vector load (it cannot prove the words invariant beside the ticket atomics), and
+    // a vector load's wait is vmcnt(0) -- placed in the next tile's first block, in front of the first use, where it waited for the
+    // previous tile's 16 output stores (the first block took 8.4 k cycles instead of ~3 k: profiles/r05_attn256_stamps.txt)
+    int2 it;
+    {
+      unsigned long long v_;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_) : "s"(items + (t.valid ? item : 0)) : "memory");
+      it.x = (int)(unsigned)v_;
+      it.y = (int)(unsigned)(v_ >> 32);
+    }
     const int seg = __builtin_amdgcn_readfirstlane(it.x);
     const int h = __builtin_amdgcn_readfirstlane(it.y >> 16), tk = __builtin_amdgcn_readfirstlane(it.y & 0xffff);
     const int tok0 = cu[seg];
@@ -479,6 +489,10 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         thr[0] = max(q0 + r, 0) - kb * A2_KB - 4 * hi;
         thr[1] = max(q0 + 32 + r, 0) - kb * A2_KB - 4 * hi;
       }
+#ifdef A2_STAMPS
+      unsigned long long tB_ = 0, tA_ = 0;
+      if constexpr (FIRST && !DIAG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_)::"memory", A2_ALLA);
+#endif
       if constexpr (FIRST && DIAG) {
 #define A2_EMIT_BODY_11
 #include A2_BODY_INC
@@ -497,13 +511,23 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #undef A2_EMIT_BODY_00
       }
 #ifdef A2_STAMPS
+      if constexpr (FIRST && !DIAG) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA_)::"memory", A2_ALLA);
+        bk_acc[12] += tB_ - t_blk0;     // block entry: the request descriptors and addresses (compiler code)
+        bk_acc[13] += st_[0] - tB_;     // into the first statement
+        bk_acc[14] += tA_ - st_[8];     // behind the last statement: the wait for its LDS reads
+      }
       if constexpr (!DIAG) {   // [0..7] eight-gap segments, [8] waits + barrier, [9] blocks; first blocks in the second set
         unsigned long long te_;
-        if (FIRST && had_epilogue)
-          asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
+        if (FIRST && had_epilogue) {
+          unsigned long long ta_, tb_;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(24)\n\ts_memtime %2\n\ts_waitcnt lgkmcnt(0)\n\t"
+                       "s_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&s"(te_), "=&s"(ta_), "=&s"(tb_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
                          "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
-        else
+          bk_acc[15] += ta_ - tA_;
+          stF_acc[11] += (tb_ - ta_) + ((te_ - tb_) << 32);   // low word: the vmcnt(24) wait alone; high word: the barrier alone
+        } else
           asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
                        : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
                          "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
@@ -555,6 +579,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       auto timed = [&](int kb, auto&& fn) {
         unsigned long long t0_, t1_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory", A2_ALLA);
+        t_blk0 = t0_;
         fn();
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory", A2_ALLA);
         const int b = kb == 0 ? 0 : (kb_wg - kb <= 2 ? 5 - (kb_wg - kb) : (kb == 1 ? 1 : 2));
@@ -629,7 +654,11 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         for (int k = 0; k < 8; ++k) {
           const int row = 4 * k + (prow | z_), q = q0 + 32 * hf + row;
           const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ((ppos ^ (row & 15)) << 4));
+#ifdef A2_NOSTORE   // timing-only diagnostic: every output row is dropped by the descriptor's range check
+          const unsigned off = 0xfffffff0u;
+#else
           const unsigned off = q >= P ? (unsigned)(((vtok0 + q) * nh * hd + cur.hcol + ppos * 8) * 2) : 0xfffffff0u;
+#endif
           __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -19,7 +19,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 st2 = np.zeros(64 * 24, dtype=np.uint64)
 assert l.lr_debug_attn256_stamps(st2.ctypes.data_as(C.c_void_p), 64 * 24) == 0
-st2 = st2.reshape(64, 2, 12).astype(np.float64)
+st2u = st2.reshape(64, 2, 12)
+st2 = st2u.astype(np.float64)
 for w, name in ((0, "steady-state blocks"), (1, "first blocks (not diagonal)")):
     st = st2[:, w]
     blocks = np.maximum(st[:, 9], 1)
@@ -27,6 +28,10 @@ for w, name in ((0, "steady-state blocks"), (1, "first blocks (not diagonal)")):
     print("wave 3, %s per workgroup: median %d" % (name, np.median(st[:, 9])))
     print("  cycles per 8-gap segment (median over 64 workgroups):", " ".join("%.0f" % x for x in np.median(per[:, :8], 0)))
     print("  waits + barrier: %.0f   block total: %.0f   (64 MFMAs = 2048 cycles)" % (np.median(per[:, 8]), np.median(st[:, 10] / blocks)))
+    if w == 1:
+        raw = st2u[:, 1, 11]
+        print("  first blocks behind an epilogue: vmcnt(24) wait %.0f, barrier %.0f (per first block)"
+              % (np.median((raw & np.uint64(0xffffffff)).astype(np.float64) / blocks), np.median((raw >> np.uint64(32)).astype(np.float64) / blocks)))
 
 ph = np.zeros(64 * 16, dtype=np.uint64)
 assert l.lr_debug_attn256_phases(ph.ctypes.data_as(C.c_void_p), 64 * 16) == 0
@@ -39,9 +44,13 @@ for w, name in ((0, "wave 0"), (1, "wave 3")):
           % (name, np.median(ph[:, w, 5]), m[0], m[1], m[2], m[3], m[4], tot))
 
 bk = np.zeros(64 * 16, dtype=np.uint64)
-assert l.lr_debug_attn256_blocks(bk.ctrypes.data_as(C.c_void_p) if False else bk.ctypes.data_as(C.c_void_p), 64 * 16) == 0
+assert l.lr_debug_attn256_blocks(bk.ctypes.data_as(C.c_void_p), 64 * 16) == 0
 bk = bk.reshape(64, 8, 2).astype(np.float64)
 names = ["first", "second", "steady", "third-last", "second-last", "last"]
 print("wave 3, cycles per key block (incl. its barrier) by position in the tile: " +
       ", ".join("%s %.0f (x%.1f per tile)" % (names[i], np.median(bk[:, i, 0] / np.maximum(bk[:, i, 1], 1)), np.median(bk[:, i, 1]) / max(1.0, np.median(ph[:, 1, 5])))
                 for i in range(6)))
+nf = np.maximum(bk[:, 0, 1], 1)
+fl = bk.reshape(64, 16)
+print("wave 3, a tile's first block (not diagonal), cycles: entry code %.0f, into the first statement %.0f, behind the last statement (LDS-read wait) %.0f, "
+      "to the block-end wait %.0f" % tuple(np.median(fl[:, 12 + i] / nf) for i in range(4)))

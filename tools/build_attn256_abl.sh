@@ -8,7 +8,7 @@ C=$R/llamarec_amd/csrc; L=$R/llamarec_amd/lib; mkdir -p $L/abl
 OBJS=$(ls $L/obj/*.o | grep -v llama_attn256.o)
 for name in ${@:-nodma notr nokr noe nomax nobk nowait mfmaonly}; do
   inc=$L/abl/body_$name.inc
-  if [ $name = stamps ]; then A2_STAMPS=1 A2_OUT=$inc python $R/tools/gen_attn256.py; extra="-DA2_STAMPS";
+  if [ $name = stamps ]; then A2_STAMPS=${A2_STAMPS:-1} A2_OUT=$inc python $R/tools/gen_attn256.py; extra="-DA2_STAMPS";
   else A2_ABL=$name A2_OUT=$inc python $R/tools/gen_attn256.py; extra=""; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-variable -Wno-unused-value -fno-slp-vectorize \
      -mllvm -amdgpu-spill-vgpr-to-agpr=0 "-DA2_BODY_INC=\"$inc\"" $extra -c $C/llama_attn256.hip -o $L/abl/attn256_$name.o

@@ -199,6 +199,8 @@ def build():
     if os.environ.get("A2_STAMPS"):   # diagnostic build (tools/build_attn256_abl.sh stamps): where a block's cycles go
         for k in range(8):
             add(8 * k, "s_memtime {0}", [("so", "st_[%d]" % k)], kind="stamp", prio=0)
+        if os.environ.get("A2_STAMPS") == "kwait":   # a first block's K(1) fragment reads, waited for in front of the last stamp
+            add(63, "s_waitcnt lgkmcnt(0)", [], "FIRST", kind="stamp", prio=98)
         add(63, "s_memtime {0}", [("so", "st_[8]")], kind="stamp", prio=99)
     # O[B] of a tile starts at zero: written in the FIRST block, whose PV(B) gaps carry no MFMA
     for dt in range(4):
