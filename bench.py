@@ -522,6 +522,12 @@ def main():
     torch.cuda.synchronize()
     stage1_users_per_s = len(hist) / (time.perf_counter() - t1)
 
+    # placement: every rank on its own device, nothing allocated elsewhere (summed over the ranks)
+    own, elsewhere = D.device_placement(local)
+    place = torch.tensor([own, elsewhere], dtype=torch.int64, device=dev)
+    D.all_reduce_sum_(place)
+    place = [int(v) for v in place.tolist()]
+
     if rank == 0:
         # algorithmic prefill work of the timed region (T * 1.2952e10 + T^2 * 2.62e5 per user), whatever
         # the kernels executed (shared prefix, last-layer pruning)
@@ -531,6 +537,7 @@ def main():
             "metric": "users/sec through retrieve+rerank", "value": users / elapsed, "unit": "users/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "peak_device_mem_gb_rank0": torch.cuda.max_memory_allocated(dev) / 1e9,
+            "placement": {"ranks_on_their_own_device": place[0], "torch_bytes_on_other_devices": place[1], "share_gpu": bool(args.share_gpu)},
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{args.workload} two-stage: LRURec(V={w['V']}, L={w['L']}, D=64, 2 blocks) top-50 with "

@@ -208,6 +208,12 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
   if (attn256) RUN(lr_launch_attn256_items(ws.seg_start, S, n, nh, P, ws.attn_items, ws.attn_items_bytes, st));
   RUN(lr_launch_embed(ids, ws.tok_src, h->embed, c.vocab_size, d, ws.x, n, st));
   bool input_normed = false;   // ws.xn already holds RMSNorm(ws.x) with this layer's input_norm
+#ifdef LR_EXPERIMENTS   // timing-only arm (never in the product library): the row statistics of layer 0 serve every layer
+  static const bool exp_rstd_once = getenv("LR_EXP_RSTD_ONCE") && getenv("LR_EXP_RSTD_ONCE")[0] == '1';
+#define EXP_SKIP_SWEEP (exp_rstd_once && l > 0)
+#else
+#define EXP_SKIP_SWEEP false
+#endif
   for (int l = 0; l < c.num_layers; ++l) {
     const LrLlamaLayerWeights& w = h->layers[l];
     // RMSNorm: either its own pass (read + write every row), or -- folded -- only the row statistic, with the norm
@@ -230,7 +236,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
                          q_w, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, ws.rope16));
       RUN(lr_launch_attention_last(ws.qkv, ws.q_last, ws.att_last, ws.seg_start, seg_host, S, n, nh, nkv, hd, st, P));
     } else if (folded) {
-      RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
+      if (!EXP_SKIP_SWEEP) RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
       RUN(lr_launch_gemm(ws.x, h->wqkv_folded[l], ws.qkv, nullptr, n, qkv_w, d, LR_EPI_ROPE, h->gemm_variant, st, ws.tok_pos,
                          ws.rope, hd, (nh + nkv) * hd, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd, ws.rope16));
     } else {
@@ -283,7 +289,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
                        0, ws.splitk, LR_SPLITK_WS_BYTES, nullptr, nullptr, folded ? nullptr : w.post_norm, ws.xn, c.rms_eps,
                        &post_normed));
     if (folded) {
-      RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
+      if (!EXP_SKIP_SWEEP) RUN(lr_launch_rms_rstd(ws.x, ws.rstd, n, d, c.rms_eps, st));
       RUN(lr_launch_gemm(ws.x, h->wgu_folded[l], ws.hmid, nullptr, n, 2 * f, d, LR_EPI_SWIGLU, h->gemm_variant, st, nullptr,
                          nullptr, 0, 0, ws.splitk, LR_SPLITK_WS_BYTES, ws.rstd));
     } else {
@@ -298,6 +304,7 @@ static int run_body(lr_llama_t* h, const int32_t* ids, const int32_t* cu, const 
                        ws.xn, c.rms_eps, &input_normed));
   }
 #undef RUN
+#undef EXP_SKIP_SWEEP
   *out_ws = ws;
   return LR_OK;
 }

@@ -68,3 +68,20 @@ def broadcast_shard_edges(edges, device=None):
     dist.broadcast(t, src=0)
     t = t.cpu().reshape(-1, 2)
     return [(int(a), int(b)) for a, b in t]
+
+
+def device_placement(local: int):
+    """Where this rank's memory went: (1 if HIP's current device is cuda:`local` else 0, bytes the torch allocator holds on any
+    OTHER visible device). Every allocation of the job names its device (the constructors take `device=`, the C library allocates
+    on HIP's current device, which init_from_env / bench.main set to LOCAL_RANK), so a healthy N-rank run reports (1, 0) on every
+    rank; bench.py sums both over the ranks into its line. Querying the allocator's statistics creates no context on the other
+    devices. The reference leaves placement to accelerate (train_ranker.py:46-47)."""
+    cur = torch.cuda.current_device()
+    elsewhere = 0
+    for d in range(torch.cuda.device_count()):
+        if d != local:
+            try:
+                elsewhere += int(torch.cuda.memory_allocated(d))
+            except Exception:   # a device this process may not query: nothing of ours can be there
+                pass
+    return int(cur == local), elsewhere

@@ -72,6 +72,7 @@ def test_bench_two_ranks_on_one_card_over_gloo():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - counted) < 1e-6 * counted   # value = ALL ranks' users / time
     assert d["metrics"]["retrieve_matches_expected"] is True and d["metrics"]["retrieve_NDCG@10"] > 0
     assert d["roofline"] is not None and 0.0 < d["roofline"]["frac"] < 1.0
+    assert d["placement"]["ranks_on_their_own_device"] == 2 and d["placement"]["torch_bytes_on_other_devices"] == 0
     assert "cpu_baseline" not in d and "roofline_item_gemm" not in d     # N = 1 only
 
 
@@ -93,6 +94,7 @@ def test_bench_four_ranks_on_one_card_over_gloo():
     assert abs(counted - 4 * per_rank) <= 0.3 * per_rank, (counted, per_rank)
     assert d["metrics"]["retrieve_matches_expected"] is True
     assert 0.0 < d["peak_device_mem_gb_rank0"] < 24.0      # one layer + embeddings + head + the 32 768-row workspace
+    assert d["placement"] == {"ranks_on_their_own_device": 4, "torch_bytes_on_other_devices": 0, "share_gpu": True}
 
 
 @pytest.mark.gpu

@@ -494,3 +494,29 @@ def test_bench_expected_metrics_helpers():
     assert abs(m["NDCG@50"] - (1 / np.log2(2) + 1 / np.log2(6) + 1 / np.log2(11) + 1 / np.log2(12) + 1 / np.log2(51)) / 6) < 1e-15
     ranked = np.array([[5, 3, 9], [1, 2, 3]])
     assert abs(b.ndcg_at_10(ranked, [9, 7]) - (1 / np.log2(4) + 0.0) / 2) < 1e-15
+
+
+@pytest.mark.parametrize("local", [0, 3, 7])
+def test_device_placement_census_on_a_mock_eight_gpu_node(monkeypatch, local):
+    """bench.py's placement census (llamarec_amd/dist.py device_placement) on a mock 8-GPU node: under WORLD_SIZE = 8,
+    LOCAL_RANK = r a rank reports (1, 0) when HIP's current device is cuda:r and the allocator holds nothing elsewhere, and
+    names the stray bytes / the wrong current device otherwise -- what the driver's 8-GPU line then carries in `placement`."""
+    import torch
+
+    from llamarec_amd import dist as D
+
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", str(local))
+    monkeypatch.setenv("LOCAL_RANK", str(local))
+    assert D.env_world() == (local, 8, local)
+    held = {d: 0 for d in range(8)}
+    held[local] = 5 << 30
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: local)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: held[d])
+    assert D.device_placement(local) == (1, 0)
+    held[(local + 1) % 8] = 4096                       # a tensor built with a default "cuda:0"-style device
+    assert D.device_placement(local) == (1, 4096)
+    held[(local + 1) % 8] = 0
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: (local + 1) % 8)   # set_device never ran
+    assert D.device_placement(local) == (0, 0)
