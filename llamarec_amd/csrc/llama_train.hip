@@ -389,6 +389,123 @@ __global__ __launch_bounds__(256) void lt_tn_kernel(const u16* __restrict__ T, i
     }
   }
 }
+// The same reduction with both operands staged through LDS: 16-byte global loads in memory order (8 lanes per token row of the
+// wave's 64 columns, 2 lanes per row of T's 16 columns), then ds_read_b64_tr_b16 hands every lane its 8 consecutive TOKENS of one
+// column -- the k-major fragment the 2-byte gathers above assemble with 32 vector loads per 4 MFMAs (rocprofv3, round 5: 166 us
+// per call at 7 k tokens against ~15 us of HBM time for X). Same fragments, same MFMA order: bit-identical sums. The next
+// 32-token step's loads are in flight while this one's products run; the LDS tiles are wave-private (no barrier).
+// Needs 16-byte-aligned rows of X and T (launch_tn checks and otherwise takes the kernel above).
+template <int NJ>
+__global__ __launch_bounds__(256) void lt_tn_lds_kernel(const u16* __restrict__ T, int ldt, int tcol,
+                                                        const u16* __restrict__ X, int ldx, int n, int cols, int chunk,
+                                                        float scale, float* out0, float* out1, int r, int layout, int hd,
+                                                        uint32_t drop_stream, uint32_t drop_thresh, float drop_scale) {
+  constexpr int XS = 144, TS = NJ * 32 + 16;                    // LDS row strides in bytes (16-byte multiples, not 128: banks)
+  __shared__ __attribute__((aligned(16))) char lds[4 * (32 * XS + 32 * TS)];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.x * 256 + wave * 64;
+  if (c0 >= cols) return;                                       // whole waves leave: EXEC stays all ones for the transposed reads
+  const int t0 = blockIdx.y * chunk, t1 = min(n, t0 + chunk);
+  char* const xs = lds + wave * (32 * XS + 32 * TS);
+  char* const ts = xs + 32 * XS;
+  floatx4 acc[NJ][4];
+#pragma unroll
+  for (int a = 0; a < NJ; ++a)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[a][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+  u32x4 xr[4], tr_[NJ];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t row = (size_t)min(k0 + i * 8 + (lane >> 3), n - 1);
+      xr[i] = *reinterpret_cast<const u32x4*>(X + row * ldx + c0 + (lane & 7) * 8);
+    }
+#pragma unroll
+    for (int a = 0; a < NJ; ++a) {
+      const size_t row = (size_t)min(k0 + (lane >> 1), n - 1);
+      tr_[a] = *reinterpret_cast<const u32x4*>(T + row * ldt + tcol + a * 16 + (lane & 1) * 8);
+    }
+  };
+  fetch(t0);
+  for (int k0 = t0; k0 < t1; k0 += 32) {
+    // this step's rows -> LDS (dropout on X and the zero rows of T past the chunk's end applied on the way)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 v = xr[i];
+      if (drop_thresh) {
+        const uint32_t row = (uint32_t)min(k0 + i * 8 + (lane >> 3), n - 1);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int c = c0 + (lane & 7) * 8 + 2 * w;
+          const u16 lo = lt_keep(drop_stream, row, c, drop_thresh) ? f2bf(bf2f((u16)(v[w] & 0xffff)) * drop_scale) : (u16)0;
+          const u16 hi = lt_keep(drop_stream, row, c + 1, drop_thresh) ? f2bf(bf2f((u16)(v[w] >> 16)) * drop_scale) : (u16)0;
+          v[w] = (unsigned)lo | ((unsigned)hi << 16);
+        }
+      }
+      *reinterpret_cast<u32x4*>(xs + (i * 8 + (lane >> 3)) * XS + (lane & 7) * 16) = v;
+    }
+#pragma unroll
+    for (int a = 0; a < NJ; ++a) {
+      const bool ok = k0 + (lane >> 1) < t1;
+      *reinterpret_cast<u32x4*>(ts + (lane >> 1) * TS + a * 32 + (lane & 1) * 16) = ok ? tr_[a] : u32x4{0, 0, 0, 0};
+    }
+    if (k0 + 32 < t1) fetch(k0 + 32);
+    // lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of a 4 x 16 block; lane i receives column i of the 4 rows
+    const int q = li >> 2, p = li & 3;
+    u16x8 tf[NJ], xf[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * g + 4 * h + q;
+#pragma unroll
+      for (int a = 0; a < NJ; ++a) {
+        const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(ts + row * TS + (a * 16 + 4 * p) * 2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tf[a][4 * h + e] = (u16)t4[e];
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const s16x4 x4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(xs + row * XS + (ct * 16 + 4 * p) * 2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xf[ct][4 * h + e] = (u16)x4[e];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NJ; ++a)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[a][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, tf[a]),
+                                                             __builtin_bit_cast(bf16x8, xf[ct]), acc[a][ct], 0, 0, 0);
+  }
+  const int half = hd >> 1;
+#pragma unroll
+  for (int a = 0; a < NJ; ++a) {
+    float* out = a == 0 ? out0 : out1;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int c = c0 + ct * 16 + li;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = g * 4 + i;
+        if (j >= r) continue;
+        size_t at;
+        if (layout == 0) {
+          at = (size_t)j * cols + c;
+        } else if (layout == 1) {
+          at = (size_t)c * r + j;
+        } else {
+          const int head = c / hd, within = c % hd;
+          at = (size_t)(head * hd + (within & 1) * half + (within >> 1)) * r + j;
+        }
+        atomicAdd(out + at, acc[a][ct][i] * scale);
+      }
+    }
+  }
+}
 static int lt_tn_chunk(int n) {
   static int forced = -1;
   if (forced < 0) {
@@ -407,7 +524,19 @@ static int launch_tn(int nj, const u16* T, int ldt, int tcol, const u16* X, int 
   const dim3 grid((cols + 255) / 256, (n + chunk - 1) / chunk);
   const uint32_t th = lt_drop_thresh(drop_p);
   const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-  if (nj == 1)
+  static int gather = -1;   // LR_TN_GATHER=1: the 2-byte gather kernel whatever the alignment (the bit-identity test's other side)
+  if (gather < 0) {
+    const char* e = getenv("LR_TN_GATHER");
+    gather = e && e[0] == '1';
+  }
+  const bool aligned = !gather && ((uintptr_t)X & 15) == 0 && ((uintptr_t)(T + tcol) & 15) == 0 && ldx % 8 == 0 && ldt % 8 == 0;
+  if (aligned && nj == 1)
+    hipLaunchKernelGGL(lt_tn_lds_kernel<1>, grid, dim3(256), 0, st, T, ldt, tcol, X, ldx, n, cols, chunk, scale, out0, out1, r,
+                       layout, hd, drop_stream, th, ds);
+  else if (aligned)
+    hipLaunchKernelGGL(lt_tn_lds_kernel<2>, grid, dim3(256), 0, st, T, ldt, tcol, X, ldx, n, cols, chunk, scale, out0, out1, r,
+                       layout, hd, drop_stream, th, ds);
+  else if (nj == 1)
     hipLaunchKernelGGL(lt_tn_kernel<1>, grid, dim3(256), 0, st, T, ldt, tcol, X, ldx, n, cols, chunk, scale, out0, out1, r,
                        layout, hd, drop_stream, th, ds);
   else

@@ -416,3 +416,40 @@ def test_eight_step_loss_trajectory_follows_the_oracle(golden_dir):
         ref.append(ol)
     assert ref[0] - ref[-1] > 1.0, ref
     assert max(abs(a - b) for a, b in zip(got, ref)) < 3e-2, (got, ref)
+
+
+def test_lds_staged_token_reductions_equal_the_gather_kernel(golden_dir, tmp_path):
+    """d A / d B of every adapter come from lt_tn_lds_kernel (16-byte loads -> LDS -> ds_read_b64_tr_b16) since round 5; the 2-byte
+    gather kernel it replaces builds the same MFMA fragments (incl. the dropout mask and the zero rows past a chunk's end) and is
+    kept for unaligned operands. LR_TN_GATHER=1 (read once per process, hence the child) forces it: every gradient tensor must
+    agree to the order of the fp32 atomics that combine the token chunks."""
+    import subprocess
+    import sys
+
+    z, cfg, sd, names = _load(golden_dir, "tiny_hd128")
+    out = str(tmp_path / "gather.npz")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from tests import test_gpu_llama_train as T\n"
+        f"z, cfg, sd, names = T._load({golden_dir!r}, 'tiny_hd128')\n"
+        "eng = T._engine(z, cfg, sd, names, dropout=0.3, seed=21)\n"
+        "seqs, labels = T._unpack(z, 0)\n"
+        "loss = float(eng.loss_and_grads(seqs, labels))\n"
+        f"np.savez({out!r}, loss=loss, **{{k: v.cpu().numpy() for k, v in eng.named(eng.grads).items()}})\n")
+    env = dict(os.environ, LR_TN_GATHER="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(out)
+    eng = _engine(z, cfg, sd, names, dropout=0.3, seed=21)
+    seqs, labels = _unpack(z, 0)
+    loss = float(eng.loss_and_grads(seqs, labels))
+    assert loss == float(ref["loss"])                       # the forward does not touch either kernel
+    got = eng.named(eng.grads)
+    worst = 0.0
+    for n in names:
+        g = got[n].cpu().numpy()
+        assert np.abs(ref[n]).max() > 0, n
+        worst = max(worst, _rel(g, ref[n]))
+        assert _rel(g, ref[n]) < 2e-6, (n, _rel(g, ref[n]))
+    print(f"LDS-staged vs gather token reductions: worst relative L2 distance {worst:.2e}")
