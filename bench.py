@@ -47,6 +47,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_CEILING_NORMAL_OPERANDS_TFLOPS = 1800.0   # measured, round 5: profiles/r05_mfma_power_ceiling.txt
 STAGE2_TOL = 3e-2          # floor of the |GPU - oracle| bound on the O(1) verbalizer scores; at full width the bound is
                            # 2 x the bf16 oracle's own distance from its fp32 mode on the same sample (tests/test_gpu_llama.py)
 # SURVEY.md section 6 / BASELINE.md section 2: the REFERENCE code's own stage-1 CPU path (model/lru.py + masking +
@@ -507,7 +508,13 @@ def main():
                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                         "traffic": traffic, "traffic_source": traffic_src, "launches": g_n, "avg_launch_ms": g_ms / g_n,
                         "flops_per_launch": g_fl / g_n, "share_of_step_time": g_ms * 1e-3 / elapsed,
-                        "per_shape": shapes, "traffic_per_shape": traffic_shapes}
+                        "per_shape": shapes, "traffic_per_shape": traffic_shapes,
+                        # what the matrix pipe ALONE sustains on operands with the bit activity of real activations and weights
+                        # (tools/diag/mfma_power.hip: nothing but MFMAs from registers; 2 476 TF/s on all-zero operands): the card's
+                        # power-limited ceiling for any bf16 GEMM on such data. `frac` above stays priced against the dense peak.
+                        "power_limited_mfma_ceiling": {"tflops": MFMA_CEILING_NORMAL_OPERANDS_TFLOPS,
+                                                       "frac_of_it": ach / MFMA_CEILING_NORMAL_OPERANDS_TFLOPS,
+                                                       "source": "profiles/r05_mfma_power_ceiling.txt"}}
         extra = {"attention_tflops": (a_fl / (a_ms * 1e-3) / 1e12) if a_n else None,
                  "attention_share_of_step_time": a_ms * 1e-3 / elapsed if a_n else None,
                  "stage1_ms_per_step": (e_ms + k_ms) / max(1, args.steps),

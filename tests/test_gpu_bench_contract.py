@@ -30,6 +30,9 @@ def test_bench_line_contract():
         assert k in ro, k
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
     assert 0.0 < ro["frac"] < 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    pc = ro["power_limited_mfma_ceiling"]          # the measured MFMA-only rate on model-like operands, beside the dense peak
+    assert pc["tflops"] < ro["peak"] and abs(pc["frac_of_it"] - ro["achieved"] / pc["tflops"]) < 1e-9 and os.path.exists(
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), pc["source"]))
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
