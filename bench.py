@@ -789,6 +789,23 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
                                     "optimizer_steps": n_it, "ms_per_step": tr * 1e3, "sequences_per_s": Bt / tr,
                                     "loss_finite": bool(np.isfinite(float(loss_t)))}
     del te
+    # the same step in deterministic mode (lr_lru_train_set_deterministic: fixed-point shadows instead of fp32 atomics) -- its cost,
+    # and that two engines started from the same state report the same bits after the same steps
+    losses = []
+    for _ in range(2):
+        td = LRUTrainEngine(init_lru_state_dict(wb["V"], seed=1), seed=3, use_graph=True).set_deterministic(True)
+        for _ in range(3):
+            td.train_step(tt_, tl_)
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        for _ in range(n_it):
+            loss_d = td.train_step(tt_, tl_)
+        torch.cuda.synchronize()
+        trd = (time.perf_counter() - tr0) / n_it
+        losses.append(float(loss_d))
+        del td
+    out["retriever_train_shape"].update({"ms_per_step_deterministic": trd * 1e3,
+                                         "deterministic_runs_bit_identical": bool(losses[0] == losses[1])})
     return out
 
 

@@ -426,6 +426,14 @@ int lr_lru_train_set_graph(lr_lru_train_t* h, int32_t enable);
  * block: 14 launches for two blocks instead of 42). enable = 0 selects the first form, one generic GEMM launch per
  * product -- same mathematics, other summation order (the cross-check of tests/test_gpu_lru_train.py). Default 1. */
 int lr_lru_train_set_fused(lr_lru_train_t* h, int32_t enable);
+/* Deterministic mode (replaces nothing in the reference: torch's own scatter / index_add backward is atomic too,
+ * trainer/lru.py:20-28; asked for so that two runs of a step can be compared bit for bit). With enable != 0 every fp32 atomic of
+ * the pass -- the loss sum, d x behind the item GEMM, every parameter gradient summed over rows -- adds a 64-bit fixed-point
+ * number into a shadow buffer instead (integer addition commutes; csrc/lr_det.h) and the pass folds the shadows back at fixed
+ * points; the gradient norm of lr_lru_train_apply is summed by one workgroup. Two passes over the same batch then give the same
+ * bits. Needs the row-panel kernels (lr_lru_train_set_fused(h, 1), the default) and a larger workspace: ask
+ * lr_lru_train_workspace_bytes AFTER enabling it. One deterministic engine per process at a time. Default 0. */
+int lr_lru_train_set_deterministic(lr_lru_train_t* h, int32_t enable);
 /* Device pointers of the flat parameter / gradient buffers and their length in floats. */
 int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_t* count);
 /* Offset and length (floats) of a parameter inside those buffers, by its reference state_dict name,

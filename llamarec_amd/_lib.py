@@ -62,6 +62,7 @@ PROTOTYPES = {
     "lr_lru_train_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "lr_lru_train_set_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "lr_lru_train_set_fused": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lr_lru_train_set_deterministic": (C.c_int, [C.c_void_p, C.c_int32]),
     "lr_lru_train_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_size_t)]),
     "lr_lru_train_param_range": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -29,6 +29,8 @@
 #include "lr_profile.h"
 #include "lru_train_blocks.h"
 #include "lru_train_scores.h"
+#include "lr_det.h"
+LR_DET_DEFINE(train)
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -131,6 +133,7 @@ struct lr_lru_train {
   // optional hipGraph replay of the two launch sequences (keyed by every pointer and shape baked into them)
   int use_graph;
   int fused;   // 1: the blocks run as row-panel kernels (lru_train_blocks.hip); 0: one generic GEMM launch per product
+  int deterministic;   // lr_lru_train_set_deterministic: atomic adds go to fixed-point shadows (lr_det.h)
   hipGraphExec_t g_fb, g_opt;
   const void *k_tok, *k_lab, *k_out, *k_ws, *k_norm;
   int k_B, k_L;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* x
         long long id = ids[row];
         if (id < 0 || id > V) id = 0;
         const float v = d * tr_drop_scale(*seedp, site, i, p);
-        if (v != 0.f) atomicAdd(dE + id * 64 + lane, v);
+        if (v != 0.f) lr_det_add(dE + id * 64 + lane, v);
       } else if (res) {
         res[i] = d;
         de[i] = d * tr_drop_scale(*seedp, site, i, p);
@@ -451,8 +454,8 @@ __global__ __launch_bounds__(256) void tr_ln_bwd(const float* dy, const float* x
   sb[wave][lane] = gb;
   __syncthreads();
   if (wave == 0) {
-    atomicAdd(dw + lane, sw[0][lane] + sw[1][lane] + sw[2][lane] + sw[3][lane]);
-    atomicAdd(db + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+    lr_det_add(dw + lane, sw[0][lane] + sw[1][lane] + sw[2][lane] + sw[3][lane]);
+    lr_det_add(db + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
   }
 }
 
@@ -664,8 +667,8 @@ __global__ __launch_bounds__(128) void tr_scan_bwd(float* g, const float* h, con
       }
     }
   }
-  atomicAdd(dlam + c, dr);
-  atomicAdd(dlam + 128 + c, di);
+  lr_det_add(dlam + c, dr);
+  lr_det_add(dlam + 128 + c, di);
 }
 
 // =============================================================================================
@@ -786,6 +789,24 @@ __global__ __launch_bounds__(256) void tr_sumsq_kernel(const float* g, size_t n,
   s = tr_block_reduce(s, false, sh);
   if (threadIdx.x == 0) atomicAdd(out, s);
 }
+// deterministic mode: TR_SUMSQ_PARTS workgroups store their partial sums (plain stores into the spare floats behind the state
+// buffer's scalars and counters), one thread adds them in index order
+#define TR_SUMSQ_PARTS 48
+__global__ __launch_bounds__(256) void tr_sumsq_part_kernel(const float* g, size_t n, float* part, unsigned long long* ctr) {
+  __shared__ float sh[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctr[0] += 1;
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+  s = tr_block_reduce(s, false, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void tr_sumsq_final_kernel(const float* part, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < TR_SUMSQ_PARTS; ++i) s += part[i];
+    *out = s;
+  }
+}
 // scal[2] = sum of squared gradients, scal[4] = learning rate, scal[5] = clipping limit of this step
 __global__ void tr_adamw_kernel(float* p, const float* g, float* m, float* v, const unsigned char* decay, size_t n,
                                 const float* scal, const unsigned long long* ctr, float wd, float b1, float b2,
@@ -823,6 +844,9 @@ struct TrWs {
   float *d64c, *d256b;        // row-panel path: dy0 and da stay live until the block's weight-gradient launch
   float* ce;                  // cross-entropy scratch: the fused path's partials + lse, or the stored logits
   bool materialise;           // small problem: store the [R][V+1] logits (<= 256 MB), three plain GEMM passes over them
+  // deterministic mode (lr_det.h): 64-bit fixed-point shadows of [gradient buffer | derived region | d x | 8 scalars]
+  long long* shadow;
+  size_t derived_floats, shadow_n;
   size_t total;
 };
 
@@ -837,7 +861,7 @@ static bool tr_use_materialised(const LrLruTrainConfig& cfg, int R, int C) {
   return (size_t)R * C <= TR_MATERIALISE_ELEMS;
 }
 
-static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, char* base) {
+static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, char* base, bool det = false) {
   TrWs w;
   size_t o = 0;
   auto take = [&](size_t floats) {
@@ -865,6 +889,7 @@ static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, ch
     d.dlam = dtake(256);
   }
   w.derived = take(doff);
+  w.derived_floats = doff;
   const size_t r = (size_t)R;
   w.x0 = take(r * 64);
   w.xhat0 = take(r * 64);
@@ -903,9 +928,26 @@ static TrWs tr_carve(const TrLayout& lay, const LrLruTrainConfig& cfg, int R, ch
     const size_t generic = (size_t)R * (((size_t)lay.V + 1 + 3) & ~(size_t)3), panels = lr_train_scores_ws_floats(R, lay.V + 1);
     w.ce = take(w.materialise ? (generic > panels ? generic : panels) : lr_train_ce_part_floats(R, lay.V + 1));
   }
+  w.shadow = nullptr;
+  w.shadow_n = det ? lay.total + doff + (size_t)R * 64 + 8 : 0;
+  if (det) w.shadow = (long long*)take(2 * w.shadow_n);
   w.total = o;
   return w;
 }
+
+// turns a shadow back into its float region: f[i] += shadow[i] * 2^-k (regions whose plain writes and whose atomic adds
+// never meet in one element: the float side holds zero, or the plain value, where the shadow holds the sum, or zero)
+__global__ void lr_det_fold_kernel(float* f, const long long* shadow, size_t n, double inv_scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const long long v = shadow[i];
+    if (v) f[i] += (float)((double)v * inv_scale);
+  }
+}
+__global__ void lr_det_zero_kernel(long long* shadow, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) shadow[i] = 0;
+}
+#define LR_DET_GRAD_SCALE 281474976710656.0   // 2^48
+#define LR_DET_SCAL_SCALE 4294967296.0        // 2^32
 
 // =============================================================================================
 // C ABI
@@ -953,6 +995,7 @@ extern "C" int lr_lru_train_create(const LrLruWeightsDesc* init, const LrLruTrai
   h->lay = tr_layout(init->num_items, init->num_blocks);
   h->cfg = *cfg;
   h->fused = 1;
+  h->deterministic = 0;
   if (const char* e = getenv("LR_TRAIN_FUSED")) h->fused = atoi(e) != 0;   // A/B knob; lr_lru_train_set_fused is the API
   const size_t n = h->lay.total;
   h->p = (float*)state_dev;
@@ -1041,9 +1084,31 @@ extern "C" int lr_lru_train_set_fused(lr_lru_train_t* h, int32_t enable) {
   return LR_OK;
 }
 
+static LrDetMap g_det_current = {};   // what the four translation units' constant maps hold (host copy)
+static int tr_det_publish(const LrDetMap& m, hipStream_t st) {
+  if (!memcmp(&m, &g_det_current, sizeof(LrDetMap))) return LR_OK;
+  LR_CHECK_HIP(hipStreamSynchronize(st));   // nothing in flight reads the old map
+  if (lr_det_set_train(&m) || lr_det_set_blocks(&m) || lr_det_set_ce(&m) || lr_det_set_scores(&m))
+    LR_FAIL(LR_EHIP, "deterministic mode: hipMemcpyToSymbol failed");
+  g_det_current = m;
+  return LR_OK;
+}
+
+extern "C" int lr_lru_train_set_deterministic(lr_lru_train_t* h, int32_t enable) {
+  if (!h) LR_FAIL(LR_EINVAL, "lr_lru_train_set_deterministic: null handle");
+  if ((enable != 0) != (h->deterministic != 0)) tr_drop_graphs(h);   // a captured step holds the other launch sequence
+  h->deterministic = enable ? 1 : 0;
+  if (!enable) {
+    LrDetMap off = {};
+    LR_CHECK_HIP(hipDeviceSynchronize());
+    return tr_det_publish(off, nullptr);
+  }
+  return LR_OK;
+}
+
 extern "C" size_t lr_lru_train_workspace_bytes(const lr_lru_train_t* h, int32_t B, int32_t L) {
   if (!h || B < 1 || L < 1) return 0;
-  return tr_carve(h->lay, h->cfg, B * L, nullptr).total;
+  return tr_carve(h->lay, h->cfg, B * L, nullptr, h->deterministic != 0).total;
 }
 
 extern "C" int lr_lru_train_buffers(lr_lru_train_t* h, float** params, float** grads, size_t* count) {
@@ -1078,7 +1143,7 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
                                 float* out_loss, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const TrLayout& lay = h->lay;
   const int R = B * L, V = lay.V, C = V + 1;
-  TrWs ws = tr_carve(lay, h->cfg, R, (char*)workspace);
+  TrWs ws = tr_carve(lay, h->cfg, R, (char*)workspace, h->deterministic != 0);
   if (ws.total > workspace_bytes)
     LR_FAIL(LR_EWORKSPACE, "lr_lru_train_loss_grad: workspace needs %zu bytes, have %zu", ws.total, workspace_bytes);
   const long long* ids = (const long long*)tokens;
@@ -1088,6 +1153,23 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   const float pd = h->cfg.dropout, pa = h->cfg.attn_dropout;
   const unsigned grid_rows = (unsigned)((R + 3) / 4);
   float* dx = ws.d64b;   // gradient of the blocks' output, then of each block's input
+  const bool det = h->deterministic != 0;
+  // shadow layout: [gradient buffer | derived region | d x | scalars]
+  long long* const sh_g = ws.shadow;
+  long long* const sh_d = ws.shadow ? ws.shadow + lay.total : nullptr;
+  long long* const sh_x = ws.shadow ? sh_d + ws.derived_floats : nullptr;
+  long long* const sh_s = ws.shadow ? sh_x + (size_t)R * 64 : nullptr;
+  auto fold = [&](float* f, const long long* sh, size_t n, double scale) {
+    hipLaunchKernelGGL(lr_det_fold_kernel, dim3((unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024)), dim3(256), 0, st, f, sh, n,
+                       1.0 / scale);
+  };
+  if (det) {
+    if (!h->fused)
+      LR_FAIL(LR_EUNSUPPORTED, "lr_lru_train_loss_grad: deterministic mode runs the row-panel kernels only (lr_lru_train_set_fused(h, 1)): "
+                               "the generic GEMM launches split K with atomics into activation buffers");
+    hipLaunchKernelGGL(lr_det_zero_kernel, dim3(1024), dim3(256), 0, st, ws.shadow, ws.shadow_n);
+    LR_CHECK_LAUNCH("lr_det_zero_kernel");
+  }
   {  // seed, zero fills (gradients, derived-weight gradients, d x), label counts
     const TrDerived& d0 = ws.blk[0].d;
     const TrDerived& dl = ws.blk[lay.nb - 1].d;
@@ -1179,6 +1261,11 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     TR_RUN(lr_launch_train_ce(x, P + lay.emb, P + lay.bias, lab, R, C, ws.ce, h->scal, dx, G + lay.emb, G + lay.bias, st));
   }
   // (loss = scal[0] / scal[1] is written to out_loss by the pass's last launch, the embedding LayerNorm's backward)
+  if (det) {   // d x and the loss sum leave their shadows here: the first backward kernel reads d x, the last launch the loss
+    fold(dx, sh_x, (size_t)R * 64, LR_DET_GRAD_SCALE);
+    fold(h->scal, sh_s, 8, LR_DET_SCAL_SCALE);
+    LR_CHECK_LAUNCH("lr_det_fold_kernel");
+  }
 
   // ---- backward through the blocks; dx = gradient of the block's output
   for (int b = lay.nb - 1; b >= 0; --b) {
@@ -1231,6 +1318,10 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
     TR_RUN(tr_linear_bwd_weight(ws.d256, xin, D + W.d.dwi, D + W.d.dbi, R, 256, 64, st));
     TR_RUN(tr_linear_bwd_data(ws.d256, D + W.d.wi, dx, R, 256, 64, 1, st));  // dx_in += du Wi
   }
+  if (det) {   // the derived weights' gradients (d lambda from the scans, d Wi / d Wo and their biases) in front of their reader
+    fold(ws.derived, sh_d, ws.derived_floats, LR_DET_GRAD_SCALE);
+    LR_CHECK_LAUNCH("lr_det_fold_kernel");
+  }
   {  // gradients of the stored parameters from those of the derived weights, every block in one launch
     TrUnprepArgs ua;
     for (int b = 0; b < LR_MAX_LRU_BLOCKS; ++b) {
@@ -1250,6 +1341,10 @@ static int tr_enqueue_loss_grad(lr_lru_train_t* h, const int64_t* tokens, const 
   hipLaunchKernelGGL(tr_ln_bwd, dim3((unsigned)((R + TR_LNB_ROWS - 1) / TR_LNB_ROWS)), dim3(256), 0, st, dx, ws.xhat0, ws.rstd0, P + lay.eln_w, ws.d64a,
                      G + lay.eln_w, G + lay.eln_b, R, nullptr, seed, 0u, pd, ids, V, G + lay.emb, h->scal, out_loss);
   LR_CHECK_LAUNCH("tr_ln_bwd");
+  if (det) {   // the pass's last launch in this mode: every parameter gradient that was summed over rows
+    fold(G, sh_g, lay.total, LR_DET_GRAD_SCALE);
+    LR_CHECK_LAUNCH("lr_det_fold_kernel");
+  }
   (void)grid_rows;
   return LR_OK;
 }
@@ -1289,6 +1384,23 @@ extern "C" int lr_lru_train_loss_grad(lr_lru_train_t* h, const int64_t* tokens, 
                                       void* hip_stream) {
   if (!h || !tokens || !labels || !out_loss || !workspace) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: null argument");
   if (B < 1 || L < 1) LR_FAIL(LR_EINVAL, "lr_lru_train_loss_grad: B=%d L=%d", B, L);
+  if (h->deterministic) {   // the four translation units' maps name THIS pass's buffers (set outside any capture)
+    const TrWs w = tr_carve(h->lay, h->cfg, B * L, (char*)workspace, true);
+    if (w.total > workspace_bytes)
+      LR_FAIL(LR_EWORKSPACE, "lr_lru_train_loss_grad: workspace needs %zu bytes in deterministic mode, have %zu", w.total, workspace_bytes);
+    LrDetMap m = {};
+    const size_t R_ = (size_t)B * L;
+    m.base[0] = h->g;       m.bytes[0] = h->lay.total * 4;       m.shadow[0] = w.shadow;                                     m.scale[0] = (float)LR_DET_GRAD_SCALE;
+    m.base[1] = w.derived;  m.bytes[1] = w.derived_floats * 4;   m.shadow[1] = w.shadow + h->lay.total;                      m.scale[1] = (float)LR_DET_GRAD_SCALE;
+    m.base[2] = w.d64b;     m.bytes[2] = R_ * 64 * 4;            m.shadow[2] = m.shadow[1] + w.derived_floats;               m.scale[2] = (float)LR_DET_GRAD_SCALE;
+    m.base[3] = h->scal;    m.bytes[3] = 8 * 4;                  m.shadow[3] = m.shadow[2] + R_ * 64;                        m.scale[3] = (float)LR_DET_SCAL_SCALE;
+    m.on = 1;
+    if (int rc = tr_det_publish(m, (hipStream_t)hip_stream)) return rc;
+  } else if (g_det_current.on) {   // another engine of this process left its map behind: this pass adds in place
+    LrDetMap off = {};
+    LR_CHECK_HIP(hipDeviceSynchronize());
+    if (int rc = tr_det_publish(off, (hipStream_t)hip_stream)) return rc;
+  }
   const bool key_ok = h->k_tok == tokens && h->k_lab == labels && h->k_out == out_loss && h->k_ws == workspace &&
                       h->k_B == B && h->k_L == L;
   const int rc = tr_run_or_replay(h, &h->g_fb, key_ok, (hipStream_t)hip_stream, [&](hipStream_t st) {
@@ -1320,6 +1432,10 @@ extern "C" int lr_lru_train_apply(lr_lru_train_t* h, float lr, float max_grad_no
     const LrLruTrainConfig& c = h->cfg;
     hipLaunchKernelGGL(tr_zero_kernel, dim3(1), dim3(64), 0, st, h->scal + 2, (size_t)1);
     LR_CHECK_LAUNCH("tr_zero_kernel");
+    if (h->deterministic) {   // partial sums stored and added in index order; the default combines 256 of them through an fp32 atomic
+      hipLaunchKernelGGL(tr_sumsq_part_kernel, dim3(TR_SUMSQ_PARTS), dim3(256), 0, st, h->g, n, h->scal + 16, h->ctr);
+      hipLaunchKernelGGL(tr_sumsq_final_kernel, dim3(1), dim3(64), 0, st, h->scal + 16, h->scal + 2);
+    } else
     hipLaunchKernelGGL(tr_sumsq_kernel, dim3(256), dim3(256), 0, st, h->g, n, h->scal + 2, h->ctr);
     LR_CHECK_LAUNCH("tr_sumsq_kernel");
     hipLaunchKernelGGL(tr_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->p, h->g, h->m, h->v,

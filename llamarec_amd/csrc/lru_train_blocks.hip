@@ -13,6 +13,8 @@
 // of it to MFMA (j, e) -- every k meets its own partner, the sum just runs in another order (fp32 sums are compared with
 // the float64 oracle and the reference's autograd at 3e-4 / 5e-4 relative, tests/test_gpu_lru_train.py).
 #include "lru_train_blocks.h"
+#include "lr_det.h"
+LR_DET_DEFINE(blocks)
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void tb_block_bwd_kernel(TbBlockBwd p) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < TB_ROWS; ++i) s += red[which][i][col];
-    atomicAdd((which ? p.dln2_b : p.dln2_w) + col, s);
+    lr_det_add((which ? p.dln2_b : p.dln2_w) + col, s);
   }
   {  // dg = dz0 w2, then through dropout and GELU: da
     floatx4 acc[4];
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void tb_block_bwd_kernel(TbBlockBwd p) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < TB_ROWS; ++i) s += red[which][i][col];
-    atomicAdd((which ? p.dln1_b : p.dln1_w) + col, s);
+    lr_det_add((which ? p.dln1_b : p.dln1_w) + col, s);
   }
   {  // dh = dy0 wo
     floatx4 acc[4];
@@ -503,7 +505,7 @@ __device__ __forceinline__ void tb_wgrad(const float* __restrict__ P, const floa
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  if (tid < N) atomicAdd(db + tid, bsum);
+  if (tid < N) lr_det_add(db + tid, bsum);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -511,7 +513,7 @@ __device__ __forceinline__ void tb_wgrad(const float* __restrict__ P, const floa
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = (nb0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        atomicAdd(dW + (size_t)m * K + (kb0 + j) * 32 + (lane & 31), acc[i][j][e]);
+        lr_det_add(dW + (size_t)m * K + (kb0 + j) * 32 + (lane & 31), acc[i][j][e]);
       }
 }
 // After the recurrence's backward pass two things are ready to run and independent of each other: the data gradient of

@@ -11,6 +11,8 @@
 #include <stdlib.h>
 
 #include "lr_common.h"
+#include "lr_det.h"
+LR_DET_DEFINE(ce)
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(CeArgs a) {
     if (lane == 0) {
       const float lse = m + logf(l);
       a.lse[row] = lse;
-      atomicAdd(a.scal, lse - (d + a.bias[lab]));
+      lr_det_add(a.scal, lse - (d + a.bias[lab]));
     }
   } else if (lane == 0) {
     a.lse[row] = __builtin_inff();
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void ce_dx_kernel(CeArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(dst + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dacc[j][r]);
+      for (int r = 0; r < 16; ++r) lr_det_add(dst + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dacc[j][r]);
   }
 }
 
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(256) void ce_de_kernel(CeArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(dst + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dacc[j][r]);
-    if (half == 0) atomicAdd(a.dbias + item, db);
+      for (int r = 0; r < 16; ++r) lr_det_add(dst + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dacc[j][r]);
+    if (half == 0) lr_det_add(a.dbias + item, db);
   }
 }
 

@@ -28,6 +28,8 @@
 #include <stdlib.h>
 
 #include "lru_train_scores.h"
+#include "lr_det.h"
+LR_DET_DEFINE(scores)
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(256) void ts_combine_kernel(TsArgs a) {
         lse2 = l2 + log2f(nv);
         const float inv_n = 1.0f / nv;
         a.dX[(size_t)row * 64 + lane] = -inv_n * a.E[(size_t)lab * 64 + lane];
-        atomicAdd(a.dE + (size_t)lab * 64 + lane, -inv_n * a.x[(size_t)row * 64 + lane]);
-        if (lane == 0) atomicAdd(a.dbias + lab, -inv_n);
+        lr_det_add(a.dE + (size_t)lab * 64 + lane, -inv_n * a.x[(size_t)row * 64 + lane]);
+        if (lane == 0) lr_det_add(a.dbias + lab, -inv_n);
       }
     }
     if (lane == 0) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void ts_combine_kernel(TsArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    if (t != 0.f) atomicAdd(a.scal, t);
+    if (t != 0.f) lr_det_add(a.scal, t);
   }
 }
 
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void ts_dx_kernel(TsArgs a) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + e, acc[nb][e]);
+      for (int e = 0; e < 4; ++e) lr_det_add(a.dX + (size_t)row * 64 + 16 * nb + 4 * g + e, acc[nb][e]);
   }
 }
 
@@ -425,10 +427,10 @@ __global__ __launch_bounds__(256) void ts_de_kernel(TsArgs a) {
     if (v0 + item < a.C) {
       const float o = (red[(size_t)item * 64 + d] + red[(size_t)(64 + item) * 64 + d]) +
                       (red[(size_t)(128 + item) * 64 + d] + red[(size_t)(192 + item) * 64 + d]);
-      atomicAdd(a.dE + (size_t)(v0 + item) * 64 + d, o);
+      lr_det_add(a.dE + (size_t)(v0 + item) * 64 + d, o);
     }
   }
-  if (tid < 64 && v0 + tid < a.C) atomicAdd(a.dbias + v0 + tid, (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]));
+  if (tid < 64 && v0 + tid < a.C) lr_det_add(a.dbias + v0 + tid, (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]));
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------

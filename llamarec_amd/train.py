@@ -76,6 +76,14 @@ class LRUTrainEngine:
         """Row-panel kernels for the LRU blocks (default) or one generic GEMM launch per product (the cross-check)."""
         check(lib().lr_lru_train_set_fused(self._h, int(bool(enable))), "lr_lru_train_set_fused")
 
+    def set_deterministic(self, enable=True):
+        """Run-to-run identical bits (include/llamarec_mi355x.h, lr_lru_train_set_deterministic): the pass's fp32 atomics become
+        64-bit fixed-point adds into shadow buffers that are folded back at fixed points. Needs the row-panel kernels (the
+        default) and a larger workspace (re-allocated on the next step). One deterministic engine per process at a time."""
+        check(lib().lr_lru_train_set_deterministic(self._h, int(bool(enable))), "lr_lru_train_set_deterministic")
+        self._tok = self._lab = self._ws = None
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:
@@ -208,6 +216,8 @@ class LRUTrainer:
             eps=getattr(args, "adam_epsilon", 1e-9), max_grad_norm=getattr(args, "max_grad_norm", 5.0),
             dropout=getattr(args, "bert_dropout", 0.2), attn_dropout=getattr(args, "bert_attn_dropout", 0.2),
             seed=getattr(args, "seed", 42) + 7919 * rank, device=device)
+        if getattr(args, "deterministic", False):   # --deterministic: run-to-run identical bits (LRUTrainEngine.set_deterministic)
+            self.engine.set_deterministic(True)
         self.device = device
         self.export_root = export_root
         self.rank, self.world = rank, world

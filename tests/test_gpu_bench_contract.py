@@ -125,6 +125,7 @@ def test_bench_side_fields_carry_the_training_steps():
     assert rt["workload"] == "beauty" and rt["batch"] == 64 and rt["seq_len"] == 50 and rt["dtype"] == "f32"
     assert rt["loss_finite"] is True and 0.0 < rt["ms_per_step"] < 5.0
     assert abs(rt["sequences_per_s"] - 64 / (rt["ms_per_step"] * 1e-3)) < 1e-6 * rt["sequences_per_s"]
+    assert rt["deterministic_runs_bit_identical"] is True and rt["ms_per_step"] * 0.8 < rt["ms_per_step_deterministic"] < 5.0
     lt = d["lora_train_shape"]
     assert lt["loss_finite"] is True and lt["workspace_allocations_in_timed_loop"] == 0 and lt["tokens_per_s"] > 0
     assert d["ml100k_shape"]["users_per_s"] > 0

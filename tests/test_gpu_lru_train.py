@@ -209,3 +209,76 @@ def test_row_panel_and_generic_block_kernels_agree(golden_dir, B, L):
         ga, gb = engines[0].grad_dict(), engines[1].grad_dict()
         for n in names:
             assert rel_err(as_pairs(ga[n]), as_pairs(gb[n])) < 5e-5, (pass_no, n, rel_err(as_pairs(ga[n]), as_pairs(gb[n])))
+
+
+@pytest.mark.parametrize("ce_mode", [1, 2])   # row-panel score kernels over stored logits / fused item GEMM + cross-entropy
+def test_deterministic_mode_is_bit_identical_run_to_run(golden_dir, ce_mode):
+    """lr_lru_train_set_deterministic: every fp32 atomic of the pass becomes a 64-bit fixed-point add into
+    a shadow buffer that is folded back at fixed points (csrc/lr_det.h), the gradient norm is summed by one workgroup. Two engines
+    from the same state -- with dropout, over three optimizer steps, with a batch big enough that dozens of workgroups add into
+    the same gradient entries -- then agree BIT FOR BIT in loss, gradient norm, every gradient tensor and every parameter; with
+    hipGraph replay as without. And the mode changes no value beyond the atomics' rounding: gradients agree with the default
+    mode's to 2e-5 of each tensor's scale."""
+    from llamarec_amd.train import LRUTrainEngine
+
+    z, names = load(golden_dir)
+    init = {n: z["init/" + n] for n in names}
+    rng = np.random.default_rng(3)
+    V = int(z["init/embedding.token.weight"].shape[0]) - 1
+    tok = rng.integers(1, V + 1, size=(48, 50)).astype(np.int64)
+    tok[::3, :17] = 0                                     # left-padded rows
+    lab = np.where(tok > 0, rng.integers(1, V + 1, size=tok.shape), 0).astype(np.int64)
+
+    def run(det, use_graph):
+        eng = LRUTrainEngine(init, dropout=0.2, attn_dropout=0.2, seed=9, use_graph=use_graph, ce_mode=ce_mode)
+        if det:
+            eng.set_deterministic(True)
+        out = []
+        for step in range(3):
+            loss = eng.loss_and_grads(tok, lab)
+            grads = {k: as_pairs(v).copy() for k, v in eng.grad_dict().items()}
+            norm = eng.apply(lr=1e-3, max_grad_norm=0.5)
+            out.append((float(loss), float(norm), grads, {k: as_pairs(v).copy() for k, v in eng.state_dict().items()}))
+        return out
+
+    a, b, c = run(True, False), run(True, False), run(True, True)
+    for other in (b, c):
+        for (la, na, ga, pa), (lb, nb, gb, pb) in zip(a, other):
+            assert la == lb and na == nb, (la, lb, na, nb)
+            for n in names:
+                assert np.array_equal(ga[n], gb[n]), n
+                assert np.array_equal(pa[n], pb[n]), n
+    plain = run(False, False)
+    assert abs(a[0][0] - plain[0][0]) < 1e-5
+    for n in names:
+        assert np.abs(a[0][2][n]).max() > 0, n
+        assert rel_err(a[0][2][n], plain[0][2][n]) < 2e-5, (n, rel_err(a[0][2][n], plain[0][2][n]))
+
+
+def test_deterministic_mode_against_the_float64_oracle_and_the_ignored_rows(golden_dir):
+    """Under deterministic mode the comparisons that had to leave room for the atomics' order get their tight bounds back: loss
+    and gradients against the float64 oracle, and a batch with extra rows whose labels are out of range gives the SAME bits as
+    the batch without them wherever no term changed (the ignored rows add exact zeros to the fixed-point shadows)."""
+    from oracle import lru_train_oracle as TO
+
+    z, names = load(golden_dir)
+    eng = make_engine(z, names).set_deterministic(True)
+    ref = float(eng.loss_and_grads(z["tokens"], z["labels"]))
+    g_ref = {k: as_pairs(v).copy() for k, v in eng.grad_dict().items()}
+    o_loss, o_grads = TO.loss_and_grads({n: z["init/" + n] for n in names}, z["tokens"], z["labels"])
+    assert abs(ref - o_loss) < 2e-5
+    for n in names:
+        assert rel_err(g_ref[n], o_grads[n]) < 3e-4, (n, rel_err(g_ref[n], o_grads[n]))
+    lab, tok = z["labels"].copy(), z["tokens"].copy()
+    lab2 = np.concatenate([lab, np.full((2, lab.shape[1]), 10 ** 6), np.full((1, lab.shape[1]), -5)])
+    tok2 = np.concatenate([tok, tok[:3]])
+    loss = float(eng.loss_and_grads(tok2, lab2))
+    assert eng.bad_labels == 3 * lab.shape[1]
+    assert np.isclose(loss, ref, rtol=1e-4, atol=1e-7)
+    got = eng.grad_dict()
+    for n in names:
+        assert np.allclose(as_pairs(got[n]), g_ref[n], rtol=1e-4, atol=1e-7), n
+    # the generic (one GEMM launch per product) path splits K with atomics into activation buffers: refused, loudly
+    eng.set_fused(False)
+    with pytest.raises(RuntimeError, match="deterministic mode"):
+        eng.loss_and_grads(z["tokens"], z["labels"])

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--deterministic", type=int, default=0)   # lr_lru_train_set_deterministic
 a = ap.parse_args()
 for name, B in (("beauty", 64), ("games", 64), ("ml-100k", 16), ("synth-1m", 64)):
     if a.only and name != a.only:
@@ -32,6 +33,8 @@ for name, B in (("beauty", 64), ("games", 64), ("ml-100k", 16), ("synth-1m", 64)
         tokens[i, : L - n] = 0
         labels[i, : L - n - 1] = 0
     eng = LRUTrainEngine(init_lru_state_dict(V, seed=1), seed=3, use_graph=bool(a.graph))
+    if a.deterministic:
+        eng.set_deterministic(True)
     t = torch.from_numpy(tokens).cuda()
     l = torch.from_numpy(labels).cuda()
     for _ in range(3):
