@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hi = lane >> 5;
   const int stride = (nh + 2 * nkv) * hd;
-  const float sl2 = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+  // (the softmax scale 1/sqrt(128) * log2(e) = 0.12754 = 0x3e0293ee is an immediate of the generated stream)
   const unsigned lds0 = (unsigned)(size_t)(a2_lds*)smem;
   const int2* items = reinterpret_cast<const int2*>(ws_ro + A2_HDR_INTS + A2_CTR_INTS);
 
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
   Tile nxt = decode(__builtin_amdgcn_readfirstlane(ctrl[1]));
   for (int tile_no = 0; cur.valid; ++tile_no) {
     int item_nn = -1;      // the tile after next (drawn by wave 0 in its slack behind its last key block)
-    const int T = cur.T, P = cur.P, row0 = cur.row0, kb_wg = cur.kb_wg, vtok0 = cur.vtok0;
+    const int P = cur.P, row0 = cur.row0, kb_wg = cur.kb_wg, vtok0 = cur.vtok0;
     const int q0 = row0 + 64 * wave;
     const bool dead = q0 + 63 < P;                                // no live row in this wave
     const int n_full = q0 >= 0 ? (q0 + 1) >> 6 : 0;               // blocks every row of the wave sees unmasked
