@@ -311,7 +311,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
-  float l_run[2] = {0.f, 0.f};
+  // Row sums of P through the matrix pipe (round 5): one more A row of ones beside V^T gives l = sum_k P[k][row] as an MFMA
+  // accumulator -- every lane of a row's column holds the complete sum of the bf16 P the numerator uses -- instead of 16
+  // v_add_f32 per half and block plus two cross-lane exchanges at the end (the block loop is bound by what a SIMD ISSUES: an
+  // MFMA costs it ~8 cycles, 16 adds ~70).
+  floatx4 l_acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones_f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones_f[i] = (__bf16)1.0f;
 
   const int q_last = min(qb * FA_QROWS + FA_QROWS - 1, T - 1);   // (LASTQ: qb is the tile of row T - 1, so this is T - 1)
   const int kb_last = q_last / FA_KB;
@@ -456,26 +463,24 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
         const float cand = mx * sl2;
         const bool grew = cand > m_run[qt] + FA_DEFER;
         const float m_new = grew ? cand : m_run[qt];
-        float ps = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             // exp2(s*scale*log2e - m): one fma + one exp per score
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][nt][r], sl2, -m_new));
-            ps += p;
             pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
           }
         if (__any(grew)) {  // rescale l and O only when some row's reference moved (alpha == 1 for the other rows)
           const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-          l_run[qt] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) l_acc[qt][r] *= alpha;
 #pragma unroll
           for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
         }
         m_run[qt] = m_new;
-        l_run[qt] += ps;
       }
 
       if (STAMP) asm volatile("" ::"v"(pa[0][0]), "v"(pa[1][1]));
@@ -485,6 +490,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
       // depend on ks2 or the +16, so row0's address differs from vb_off[dt] by the immediate 8192 ks2 (+ 4096)
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pa[qt][ks2], l_acc[qt], 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
           const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   // ---- normalise and store: lane owns query row li, d = dt*16 + 4*quad + r
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    const float l = fa_sum_xor16_32(l_run[qt]);
+    const float l = l_acc[qt][0];   // (every register of the tile, in every lane of the row's column, holds the row's sum)
     const float inv = 1.0f / l;
     if (!LASTQ && qabs[qt] < T && qabs[qt] >= P && lse && quad == 0)  // natural-log log-sum-exp of the scaled scores (backward pass)
       lse[(size_t)(vtok0 + qabs[qt]) * nh + h] = (m_run[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
