@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) ot[qt][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
+  float mthr[2] = {-__builtin_inff(), -__builtin_inff()};   // (m + FA_DEFER) / scale of the lane's row, in raw-score units
   // Row sums of P through the matrix pipe (round 5): one more A row of ones beside V^T gives l = sum_k P[k][row] as an MFMA
   // accumulator -- every lane of a row's column holds the complete sum of the bf16 P the numerator uses -- instead of 16
   // v_add_f32 per half and block plus two cross-lane exchanges at the end (the block loop is bound by what a SIMD ISSUES: an
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
   const int kb_last = q_last / FA_KB;
   const int wave_q_last = LASTQ ? T - 1 : qb * FA_QROWS + wave * 32 + 31;  // last query row this wave owns
   const float sl2 = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+  const float inv_sl2 = 1.0f / sl2;
 
   // ---- DMA staging: 16 pieces per tile (4 rows each); wave w moves pieces 4w..4w+3 of K and of V
   const int prow = lane >> 4, ppos = lane & 15;
@@ -453,16 +455,32 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
           mx = fa_max3(mx, st[qt][nt][1], st[qt][nt][2]);
           if (nt < 3) mx = fa_max3(mx, st[qt][nt][3], st[qt][nt + 1][0]);
         }
-        mx = fa_max2(mx, st[qt][3][3]);
-        mx = fa_max_xor16_32(mx);
+        mx = fa_max2(mx, st[qt][3][3]);      // this lane's 16 keys of the row
         // Deferred maximum (round 5, as in llama_attn256.hip): a row's reference value m moves only when a score exceeds it by
         // more than FA_DEFER in the exp2 domain, so P stays below 2^FA_DEFER (exact in fp32 sums, 8 significant bits in bf16
         // whatever its scale) and O / l are rescaled in a tile's first block and then almost never -- with the running maximum
         // some row of the 16 moved in most blocks of a 600-1 100-token prompt (32 multiplies + an exp2 per half and block).
         // The decision is per row: a row's bits do not depend on its tile mates (alpha is exactly 1 for a row that keeps m).
-        const float cand = mx * sl2;
-        const bool grew = cand > m_run[qt] + FA_DEFER;
-        const float m_new = grew ? cand : m_run[qt];
+        // Common path: no lane of this half sees a score above its row's cached RAW threshold (m + FA_DEFER) / scale -- one compare
+        // and a wave-uniform branch; the row maximum across the four lanes of a row, the new reference, alpha and the rescale
+        // run only behind it (a row's own decision is the same either way: its maximum exceeds the threshold iff one of its
+        // lanes' does, and a row that keeps m multiplies by exactly 1).
+        if (__any(mx > mthr[qt])) {
+          const float rmx = fa_max_xor16_32(mx);
+          const bool grew = rmx > mthr[qt];   // the SAME predicate as the lanes' test, on the row maximum: a row moves iff one of
+                                              // its own lanes asked for it, whatever the other rows of the wave do
+          const float m_new = grew ? rmx * sl2 : m_run[qt];
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) l_acc[qt][r] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
+          m_run[qt] = m_new;
+          mthr[qt] = (m_new + FA_DEFER) * inv_sl2;
+        }
+        const float m_new = m_run[qt];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -471,16 +489,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma128_kernel(const u16* __restr
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][nt][r], sl2, -m_new));
             pa[qt][nt >> 1][(nt & 1) * 4 + r] = (__bf16)p;
           }
-        if (__any(grew)) {  // rescale l and O only when some row's reference moved (alpha == 1 for the other rows)
-          const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) l_acc[qt][r] *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ot[qt][dt][r] *= alpha;
-        }
-        m_run[qt] = m_new;
       }
 
       if (STAMP) asm volatile("" ::"v"(pa[0][0]), "v"(pa[1][1]));

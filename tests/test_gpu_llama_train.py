@@ -444,7 +444,7 @@ def test_lds_staged_token_reductions_equal_the_gather_kernel(golden_dir, tmp_pat
     eng = _engine(z, cfg, sd, names, dropout=0.3, seed=21)
     seqs, labels = _unpack(z, 0)
     loss = float(eng.loss_and_grads(seqs, labels))
-    assert loss == float(ref["loss"])                       # the forward does not touch either kernel
+    assert abs(loss - float(ref["loss"])) < 2e-6            # the forward touches neither kernel (the loss is a sum of fp32 atomics: 1 ulp)
     got = eng.named(eng.grads)
     worst = 0.0
     for n in names:
