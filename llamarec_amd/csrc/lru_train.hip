@@ -1086,7 +1086,11 @@ extern "C" int lr_lru_train_set_fused(lr_lru_train_t* h, int32_t enable) {
 
 static LrDetMap g_det_current = {};   // what the four translation units' constant maps hold (host copy)
 static int tr_det_publish(const LrDetMap& m, hipStream_t st) {
-  if (!memcmp(&m, &g_det_current, sizeof(LrDetMap))) return LR_OK;
+  bool same = m.on == g_det_current.on;   // (field by field: the struct has padding that a memcmp would see)
+  for (int k = 0; k < LR_DET_REGIONS && same; ++k)
+    same = m.base[k] == g_det_current.base[k] && m.bytes[k] == g_det_current.bytes[k] && m.shadow[k] == g_det_current.shadow[k] &&
+           m.scale[k] == g_det_current.scale[k];
+  if (same) return LR_OK;
   LR_CHECK_HIP(hipStreamSynchronize(st));   // nothing in flight reads the old map
   if (lr_det_set_train(&m) || lr_det_set_blocks(&m) || lr_det_set_ce(&m) || lr_det_set_scores(&m))
     LR_FAIL(LR_EHIP, "deterministic mode: hipMemcpyToSymbol failed");
