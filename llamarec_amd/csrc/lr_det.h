@@ -6,7 +6,8 @@
 // buffer at fixed points of the launch sequence (lr_det_fold_kernel: behind the cross-entropy for d x and the loss, in front
 // of tr_unprep_kernel for the derived weights' gradients, by the pass's last launch for the gradient buffer).
 // An addend v becomes round(v * 2^k) exactly (a power-of-two scaling of a float, then an integer that a 64-bit register
-// holds): k = 48 for gradients (range +-32768, resolution 3.6e-15), k = 32 for the loss sum / the squared gradient norm.
+// holds): k = 48 for gradients (range +-32768, resolution 3.6e-15), k = 32 for the loss sum / the squared gradient norm. An addend
+// that is not finite, or outside that range, takes the plain fp32 atomic instead: a NaN stays a NaN in the buffer.
 // One map per translation unit in constant memory (LR_DET_DEFINE), set by the host in front of a pass: a process runs ONE
 // deterministic engine at a time.
 #pragma once
@@ -32,8 +33,10 @@ struct LrDetMap {
       _Pragma("unroll") for (int k = 0; k < LR_DET_REGIONS; ++k) {                                           \
         const unsigned long long off = (unsigned long long)((uintptr_t)p - (uintptr_t)g_lr_det.base[k]);      \
         if (off < g_lr_det.bytes[k]) {                                                                        \
+          const float sv = v * g_lr_det.scale[k];                                                             \
+          if (!(fabsf(sv) < 9.0e18f)) break;   /* NaN, inf or out of the fixed-point range: the float add keeps it visible */ \
           atomicAdd(reinterpret_cast<unsigned long long*>(g_lr_det.shadow[k] + (off >> 2)),                   \
-                    (unsigned long long)__float2ll_rn(v * g_lr_det.scale[k]));                                \
+                    (unsigned long long)__float2ll_rn(sv));                                                   \
           return;                                                                                             \
         }                                                                                                     \
       }                                                                                                       \

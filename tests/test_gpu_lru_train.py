@@ -282,3 +282,21 @@ def test_deterministic_mode_against_the_float64_oracle_and_the_ignored_rows(gold
     eng.set_fused(False)
     with pytest.raises(RuntimeError, match="deterministic mode"):
         eng.loss_and_grads(z["tokens"], z["labels"])
+
+
+def test_deterministic_mode_does_not_hide_a_non_finite_gradient(golden_dir):
+    """A NaN in the parameters must surface as a non-finite loss in deterministic mode as it does in the default mode: an addend that
+    is not finite (or outside the fixed-point range) takes the plain fp32 atomic instead of the shadow (csrc/lr_det.h)."""
+    from llamarec_amd.train import LRUTrainEngine
+
+    z, names = load(golden_dir)
+    init = {n: z["init/" + n].copy() for n in names}
+    init["embedding.token.weight"][5, 3] = np.nan
+    for det in (False, True):
+        eng = LRUTrainEngine(init, dropout=0.0, attn_dropout=0.0)
+        if det:
+            eng.set_deterministic(True)
+        tok = z["tokens"].copy()
+        tok[0, -1] = 5                                   # the poisoned item is in the batch
+        loss = float(eng.loss_and_grads(tok, z["labels"]))
+        assert not np.isfinite(loss), (det, loss)
