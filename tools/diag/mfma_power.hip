@@ -23,7 +23,9 @@ __device__ inline unsigned short rnd_bf16(uint32_t& s, int kind) {
   return (unsigned short)(__builtin_bit_cast(uint32_t, u * 1.7f) >> 16);
 }
 
-template <int SHAPE>   // 0: 16x16x32, 1: 32x32x16
+// ORDER (16x16x32 only): which operand changes between consecutive MFMAs. 0: A every MFMA, B every fourth (a register-blocked tile walked
+// along its rows); 1: both every MFMA; 2: both only every fourth MFMA (the same pair issued four times into different accumulators)
+template <int SHAPE, int ORDER = 0>   // 0: 16x16x32, 1: 32x32x16
 __global__ __launch_bounds__(256) void spin(float* sink, int iters, int kind) {
   uint32_t s = threadIdx.x * 747796405u + blockIdx.x * 2891336453u + 1u;
   u16x8 a_[4], b_[4];
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void spin(float* sink, int iters, int kind) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_[i & 3]), __builtin_bit_cast(bf16x8, b_[i >> 2]), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_[ORDER == 2 ? (i >> 2) : (i & 3)]),
+                                                         __builtin_bit_cast(bf16x8, b_[ORDER == 1 ? ((i + (i >> 2)) & 3) : (i >> 2)]), acc[i], 0, 0, 0);
     }
     float t = 0;
     for (int i = 0; i < 16; ++i) t += acc[i][0] + acc[i][3];
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void spin(float* sink, int iters, int kind) {
   }
 }
 
-template <int SHAPE>
+template <int SHAPE, int ORDER = 0>
 void run(const char* name, int waves_per_simd, int kind, float* sink) {
   const int iters = 400000;
   const double flops_per_iter_wave = SHAPE == 0 ? 16.0 * 2 * 16 * 16 * 32 : 8.0 * 2 * 32 * 32 * 16;
@@ -64,7 +67,7 @@ void run(const char* name, int waves_per_simd, int kind, float* sink) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {   // the third repetition is the reported one: the clock has settled
     hipEventRecord(e0);
-    for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(spin<SHAPE>, grid, block, 0, 0, sink, iters, kind);
+    for (int k = 0; k < 12; ++k) hipLaunchKernelGGL((spin<SHAPE, ORDER>), grid, block, 0, 0, sink, iters, kind);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -83,5 +86,10 @@ int main() {
       run<0>("v_mfma_f32_16x16x32_bf16", w, kind, sink);
       run<1>("v_mfma_f32_32x32x16_bf16", w, kind, sink);
     }
+  // operand order, 16x16x32, two waves per SIMD, normal operands
+  run<0, 0>("16x16x32, A changes every MFMA, B every fourth", 2, 1, sink);
+  run<0, 1>("16x16x32, A and B change every MFMA        ", 2, 1, sink);
+  run<0, 2>("16x16x32, A and B change every fourth MFMA  ", 2, 1, sink);
+  run<0, 0>("16x16x32, A changes every MFMA, B every fourth", 2, 1, sink);
   return 0;
 }
