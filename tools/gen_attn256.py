@@ -61,6 +61,12 @@ def clob(lo, n):
                        # own in an accumulator register across any of them (it does, given the chance: llama_attn256.hip)
 
 
+# gaps of the block's 8 LDS-DMA pieces (K, V alternating). A2_DMA_GAPS="g0,g1,..,g7" overrides (timing experiments: a piece costs the
+# stream ~48 cycles where eight follow each other in gaps 1..8; hipBLASLt's 256 x 256 kernel spreads its 16 over the K tile)
+DMA_GAPS = [int(x) for x in os.environ.get("A2_DMA_GAPS", "1,2,3,4,5,6,7,8").split(",")]
+assert len(DMA_GAPS) == 8 and all(0 <= g <= 62 for g in DMA_GAPS)
+
+
 def O_(h, dt):
     return (4 * h + dt) * 16
 
@@ -194,8 +200,8 @@ def build():
     # ---------------- LDS-DMA of K(kb + 2) and V(kb + 1): early in the block, in the lightest gaps
     dma = "s_mov_b32 m0, {0}\n\ts_nop 0\n\tbuffer_load_dwordx4 {1}, {2}, {3} offen lds"
     for i in range(4):
-        add(1 + 2 * i, dma, [("s", "dst_k + %d" % (1024 * i)), ("i", "koff_x"), ("s", "rs_k"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
-        add(2 + 2 * i, dma, [("s", "dst_v + %d" % (4096 * i)), ("i", "voff_x"), ("s", "rs_v"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
+        add(DMA_GAPS[2 * i], dma, [("s", "dst_k + %d" % (1024 * i)), ("i", "koff_x"), ("s", "rs_k"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
+        add(DMA_GAPS[2 * i + 1], dma, [("s", "dst_v + %d" % (4096 * i)), ("i", "voff_x"), ("s", "rs_v"), ("s", "soff[%d]" % i)], kind="dma", prio=9)
     if os.environ.get("A2_STAMPS"):   # diagnostic build (tools/build_attn256_abl.sh stamps): where a block's cycles go
         for k in range(8):
             add(8 * k, "s_memtime {0}", [("so", "st_[%d]" % k)], kind="stamp", prio=0)
