@@ -61,9 +61,11 @@ def clob(lo, n):
                        # own in an accumulator register across any of them (it does, given the chance: llama_attn256.hip)
 
 
-# gaps of the block's 8 LDS-DMA pieces (K, V alternating). A2_DMA_GAPS="g0,g1,..,g7" overrides (timing experiments: a piece costs the
-# stream ~48 cycles where eight follow each other in gaps 1..8; hipBLASLt's 256 x 256 kernel spreads its 16 over the K tile)
-DMA_GAPS = [int(x) for x in os.environ.get("A2_DMA_GAPS", "1,2,3,4,5,6,7,8").split(",")]
+# gaps of the block's 8 LDS-DMA pieces (K, V alternating). A2_DMA_GAPS="g0,g1,..,g7" overrides (tools/build_attn256_dma.sh). A piece
+# costs the stream ~48 cycles where eight follow each other (gaps 1..8: the first placement); every other gap behind the transposed V
+# reads they are nearly free: 4 x 8 192 tokens 2 183 -> 2 095 us, 16 x 1 000 tokens 276 -> 266 us, same box (round 5). hipBLASLt's
+# 256 x 256 GEMM spreads its 16 pieces over the K tile the same way.
+DMA_GAPS = [int(x) for x in os.environ.get("A2_DMA_GAPS", "41,43,45,47,49,51,53,55").split(",")]
 assert len(DMA_GAPS) == 8 and all(0 <= g <= 62 for g in DMA_GAPS)
 
 
