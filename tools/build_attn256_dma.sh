@@ -13,7 +13,8 @@ build() {
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/abl/libllamarec_dma_$1.so $OBJS $L/abl/attn256_dma_$1.o
   echo "built dma_$1 ($2)"
 }
-build spread8 2,10,18,26,34,42,50,58
-build spread4 1,5,9,13,17,21,25,29
-build late 41,43,45,47,49,51,53,55
-build pairs 1,2,9,10,17,18,25,26
+build first8 1,2,3,4,5,6,7,8
+build mid 9,11,13,15,17,19,20,21
+build split 9,12,15,18,44,47,50,53
+build every3 41,44,47,50,53,56,59,62
+build late1 48,49,50,51,52,53,54,55
