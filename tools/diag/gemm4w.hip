@@ -20,6 +20,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define STAGE_BYTES 65536
+#ifndef G4_DMA_EARLY
+#define G4_DMA_EARLY 0   // where phase B issues the next-but-one tile's 16 LDS-DMA pieces: 0 = one per 4-MFMA group (round 4), 1 / 2: see the loop
+#endif
 #ifndef G4_ABL
 #define G4_ABL 0   // ablations (wrong results, timings only): 1 = no DMA after the prologue, 2 = no fragment reads after the first
 #endif
@@ -135,7 +138,13 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const u16* __restrict__ A, 
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       MF4(a1, b1, c >> 1, c & 1)
+#if G4_DMA_EARLY == 1      // the 16 pieces in the first 8 groups (two per group): the last one has 1.5 phases until its reader, not 1
+      if (more2 && !(G4_ABL & 1) && c < 8) { DMA(2 * c, kt + 2); DMA(2 * c + 1, kt + 2); }
+#elif G4_DMA_EARLY == 2    // one per group in groups 0..7, then the rest two per group: a compromise between spacing and slack
+      if (more2 && !(G4_ABL & 1)) { if (c < 8) { DMA(c, kt + 2); } else if (c < 12) { DMA(8 + 2 * (c - 8), kt + 2); DMA(9 + 2 * (c - 8), kt + 2); } }
+#else
       if (more2 && !(G4_ABL & 1)) DMA(c, kt + 2);
+#endif
       if (more && !(G4_ABL & 2)) {
         if (c < 8) { RD_A(a0, nxt, c, fo0); } else { RD_B(b0, nxt, c - 8, fo0); }
       }
