@@ -169,3 +169,18 @@ def test_attn256_accumulator_file_is_left_alone(tmp_path):
             assert any(re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", x) for x in body[max(0, i - 3):i]), (ln, body[max(0, i - 3):i])
     for key in ("vgpr_spill_count", "sgpr_spill_count"):
         pass   # (spills outside the key-block loop are allowed: they go to scratch, never to the accumulator file)
+
+
+def test_attn256_body_is_what_the_generator_emits(tmp_path):
+    """csrc/llama_attn256_body.inc is generated (tools/gen_attn256.py) and committed: the committed file must be the generator's
+    current default output, so that a change of the generator (or a hand edit of the .inc) cannot drift unnoticed."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "body.inc")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("A2_")}
+    env["A2_OUT"] = out
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_attn256.py")], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert open(out).read() == open(os.path.join(root, "llamarec_amd", "csrc", "llama_attn256_body.inc")).read()
