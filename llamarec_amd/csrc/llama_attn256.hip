@@ -197,32 +197,13 @@ __device__ __forceinline__ void a2_glds16(const void* sbase, unsigned voff, unsi
 #define A2_BARRIER_24() asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
 #define A2_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory", A2_ALLA)
 
-#ifdef A2_STAMPS   // diagnostic build only (tools/build_attn256_abl.sh stamps): per-block s_memtime deltas, wave 0 of 64 workgroups
-__device__ unsigned long long g_a256_stamps[64 * 24];   // [workgroup][steady | first blocks][12]
-extern "C" int lr_debug_attn256_stamps(unsigned long long* out, int n) {
-  if (!out || n < 1 || n > 64 * 24) LR_FAIL(LR_EINVAL, "lr_debug_attn256_stamps: bad arguments");
-  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_stamps), (size_t)n * sizeof(unsigned long long)));
-  return LR_OK;
-}
-__device__ unsigned long long g_a256_blocks[64 * 16];      // wave 3: [bucket][cycles, count]: first, second, steady, third-last, second-last, last
-__device__ unsigned long long g_a256_phases[64 * 2 * 8];   // [workgroup][wave 0 | wave 3][prologue, blocks, drain+idle, epilogue, seam, tiles]
-extern "C" int lr_debug_attn256_blocks(unsigned long long* out, int n) {
-  if (!out || n < 1 || n > 64 * 16) LR_FAIL(LR_EINVAL, "lr_debug_attn256_blocks: bad arguments");
-  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_blocks), (size_t)n * sizeof(unsigned long long)));
-  return LR_OK;
-}
-extern "C" int lr_debug_attn256_phases(unsigned long long* out, int n) {
-  if (!out || n < 1 || n > 64 * 16) LR_FAIL(LR_EINVAL, "lr_debug_attn256_phases: bad arguments");
-  LR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a256_phases), (size_t)n * sizeof(unsigned long long)));
-  return LR_OK;
-}
-#define A2_PHASE(i)                                                                          \
-  {                                                                                          \
-    unsigned long long t_;                                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory", A2_ALLA);      \
-    ph_acc[i] += t_ - ph_prev;                                                               \
-    ph_prev = t_;                                                                            \
-  }
+#ifdef A2_STAMPS   // diagnostic build only (tools/build_attn256_abl.sh stamps): the stamping code lives in tools/diag/attn256_stamps.inc
+#ifndef A2_STAMPS_INC
+#define A2_STAMPS_INC "../../tools/diag/attn256_stamps.inc"
+#endif
+#define A2_STAMP_DECL
+#include A2_STAMPS_INC
+#undef A2_STAMP_DECL
 #else
 #define A2_PHASE(i)
 #endif
@@ -292,11 +273,9 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     for (int s = 0; s < 4; ++s) Vf[dt][s] = a2_i64x2{0, 0};
 
 #ifdef A2_STAMPS
-  unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_blk0 = 0;
-  unsigned long long stF_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_prev, bk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_prev)::"memory");
+#define A2_STAMP_STATE
+#include A2_STAMPS_INC
+#undef A2_STAMP_STATE
 #endif
   // ---- tickets. Own XCD's stream first (the tiles of one (segment, head) follow each other there: their K/V blocks meet in
   // that XCD's L2), then the neighbours' leftovers. A workgroup always knows its current AND its next tile (the K / V / Q stream
@@ -490,8 +469,9 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         thr[1] = max(q0 + 32 + r, 0) - kb * A2_KB - 4 * hi;
       }
 #ifdef A2_STAMPS
-      unsigned long long tB_ = 0, tA_ = 0;
-      if constexpr (FIRST && !DIAG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_)::"memory", A2_ALLA);
+#define A2_STAMP_BLOCK_ENTRY
+#include A2_STAMPS_INC
+#undef A2_STAMP_BLOCK_ENTRY
 #endif
       if constexpr (FIRST && DIAG) {
 #define A2_EMIT_BODY_11
@@ -511,33 +491,9 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
 #undef A2_EMIT_BODY_00
       }
 #ifdef A2_STAMPS
-      if constexpr (FIRST && !DIAG) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tA_)::"memory", A2_ALLA);
-        bk_acc[12] += tB_ - t_blk0;     // block entry: the request descriptors and addresses (compiler code)
-        bk_acc[13] += st_[0] - tB_;     // into the first statement
-        bk_acc[14] += tA_ - st_[8];     // behind the last statement: the wait for its LDS reads
-      }
-      if constexpr (!DIAG) {   // [0..7] eight-gap segments, [8] waits + barrier, [9] blocks; first blocks in the second set
-        unsigned long long te_;
-        if (FIRST && had_epilogue) {
-          unsigned long long ta_, tb_;
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(24)\n\ts_memtime %2\n\ts_waitcnt lgkmcnt(0)\n\t"
-                       "s_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&s"(te_), "=&s"(ta_), "=&s"(tb_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
-                         "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
-          bk_acc[15] += ta_ - tA_;
-          stF_acc[11] += (tb_ - ta_) + ((te_ - tb_) << 32);   // low word: the vmcnt(24) wait alone; high word: the barrier alone
-        } else
-          asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&s"(te_), "+s"(st_[0]), "+s"(st_[1]), "+s"(st_[2]), "+s"(st_[3]), "+s"(st_[4]), "+s"(st_[5]), "+s"(st_[6]),
-                         "+s"(st_[7]), "+s"(st_[8]) :: "memory", A2_ALLA);
-        unsigned long long* acc_ = FIRST ? stF_acc : st_acc;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc_[i] += st_[i + 1] - st_[i];
-        acc_[8] += te_ - st_[8];
-        acc_[9] += 1;
-        acc_[10] += te_ - st_[0];
-      } else
+#define A2_STAMP_BLOCK_END   // (ends in a dangling `else` in front of the barrier below)
+#include A2_STAMPS_INC
+#undef A2_STAMP_BLOCK_END
 #endif
       if (FIRST && had_epilogue) A2_BARRIER_24(); else A2_BARRIER_8();
     };
@@ -576,19 +532,9 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
       A2_PHASE(2)
     } else {
 #ifdef A2_STAMPS
-      auto timed = [&](int kb, auto&& fn) {
-        unsigned long long t0_, t1_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory", A2_ALLA);
-        t_blk0 = t0_;
-        fn();
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory", A2_ALLA);
-        const int b = kb == 0 ? 0 : (kb_wg - kb <= 2 ? 5 - (kb_wg - kb) : (kb == 1 ? 1 : 2));
-        bk_acc[2 * b] += t1_ - t0_;
-        bk_acc[2 * b + 1] += 1;
-      };
-      timed(0, [&]() { if (n_full == 0) body(BT{}, BT{}, 0); else body(BT{}, BF{}, 0); });
-      for (int kb = 1; kb < n_full; ++kb) timed(kb, [&]() { body(BF{}, BF{}, kb); });
-      for (int kb = max(n_full, 1); kb <= kl; ++kb) timed(kb, [&]() { body(BF{}, BT{}, kb); });
+#define A2_STAMP_TIMED
+#include A2_STAMPS_INC
+#undef A2_STAMP_TIMED
 #else
       if (n_full == 0) body(BT{}, BT{}, 0); else body(BT{}, BF{}, 0);
       for (int kb = 1; kb < n_full; ++kb) body(BF{}, BF{}, kb);               // the steady state: ONE instance, a self-loop
@@ -654,11 +600,7 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
         for (int k = 0; k < 8; ++k) {
           const int row = 4 * k + (prow | z_), q = q0 + 32 * hf + row;
           const a2_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) a2_u32x4*>(obase + row * 256 + ((ppos ^ (row & 15)) << 4));
-#ifdef A2_NOSTORE   // timing-only diagnostic: every output row is dropped by the descriptor's range check
-          const unsigned off = 0xfffffff0u;
-#else
           const unsigned off = q >= P ? (unsigned)(((vtok0 + q) * nh * hd + cur.hcol + ppos * 8) * 2) : 0xfffffff0u;
-#endif
           __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -688,19 +630,15 @@ __global__ __launch_bounds__(256) void attn_mfma256_kernel(const u16* __restrict
     nxt = decode(__builtin_amdgcn_readfirstlane(ctrl[tile_no & 1]));
     A2_PHASE(4)   // ticket + rendezvous
 #ifdef A2_STAMPS
-    ph_acc[5] += 1;
+#define A2_STAMP_TILE_END
+#include A2_STAMPS_INC
+#undef A2_STAMP_TILE_END
 #endif
   }
 #ifdef A2_STAMPS
-  if (blockIdx.x < 64 && tid == 192)   // wave 3
-    for (int i = 0; i < 12; ++i) {
-      g_a256_stamps[blockIdx.x * 24 + i] = st_acc[i];
-      g_a256_stamps[blockIdx.x * 24 + 12 + i] = stF_acc[i];
-    }
-  if (blockIdx.x < 64 && tid == 192)
-    for (int i = 0; i < 16; ++i) g_a256_blocks[blockIdx.x * 16 + i] = bk_acc[i];
-  if (blockIdx.x < 64 && (tid == 0 || tid == 192))
-    for (int i = 0; i < 8; ++i) g_a256_phases[(blockIdx.x * 2 + (tid == 192)) * 8 + i] = ph_acc[i];
+#define A2_STAMP_STORE
+#include A2_STAMPS_INC
+#undef A2_STAMP_STORE
 #endif
   // ---- the last workgroup to leave re-arms the counters for the next launch over the same item list
   if (tid == 0) {
