@@ -10,8 +10,13 @@ wb = WORKLOADS["beauty"]
 rng = np.random.default_rng(0)
 Bt, Lt = 64, wb["L"]
 seq = rng.integers(1, wb["V"] + 1, size=(Bt, Lt + 1))
-toks, labs = torch.from_numpy(seq[:, :-1].copy()).cuda(), torch.from_numpy(seq[:, 1:].copy()).cuda()
-for det in (0, 1, 0, 1):
+toks_h, labs_h = seq[:, :-1].copy(), seq[:, 1:].copy()
+if len(sys.argv) > 1 and sys.argv[1] == "padded":   # bench.py's batch: half of the rows left-padded like short users
+    for i, n in enumerate(rng.integers(2, Lt, size=Bt // 2)):
+        toks_h[i, : Lt - n] = 0
+        labs_h[i, : Lt - n - 1] = 0
+toks, labs = torch.from_numpy(toks_h).cuda(), torch.from_numpy(labs_h).cuda()
+for det in ((1, 1, 1) if (len(sys.argv) > 2 and sys.argv[2] == "detdet") else (0, 1, 0, 1)):
     e = LRUTrainEngine(init_lru_state_dict(wb["V"], seed=1), seed=3, use_graph=True)
     if det:
         e.set_deterministic(True)
