@@ -127,9 +127,15 @@ extern "C" int lr_llama_lora_create(lr_llama_t* base, const LrLlamaWeightsTDesc*
   h->work_per_layer = 2 * (size_t)LT_RP * c.hidden_size + (size_t)LT_RP * (h->qcols + h->vcols);
   const char* ov = getenv("LR_LORA_OVERLAP");
   if (!ov || ov[0] != '0') {
-    int lo = 0, hi = 0;
+    // NORMAL priority (round 5). The side stream used to be created with the device's lowest priority, so that the rank-r products
+    // never took a CU from the GEMM they run beside. But a lowest-priority stream -- alive or destroyed -- makes this HIP runtime
+    // map some LATER normal-priority streams of the process onto its hardware queue: every third or fourth torch stream created
+    // afterwards ran the same captured graph 2-3 x slower (tools/diag/stream_index_probe.py: 0.50 -> 0.94-1.56 ms; a normal-priority
+    // stream has no such effect). LR_LORA_SIDE_PRIORITY=low restores the old behaviour for A/B runs.
+    int lo = 0, hi = 0, prio = 0;
+    const char* sp = getenv("LR_LORA_SIDE_PRIORITY");
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, (sp && sp[0] == 'l') ? lo : prio) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
       free(h->layers_t);
