@@ -804,9 +804,9 @@ def side_measurements(args, ranker, label_ids, dev, steps, shared):
         trds.append((time.perf_counter() - tr0) / n_it)
         losses.append(float(loss_d))
         del td
-    # (the faster of the two engines: in this process the second engine's stream has been seen to run the SAME captured graph on the same
-    # buffers 2-3 x slower than the first one's -- 0.54 against 0.9-1.3 ms of GPU time per pass, host time 0.05 ms in both; three
-    # consecutive engines in a stand-alone script all take 0.60 ms, tools/diag/det_step_time.py. Both are reported.)
+    # (both engines' times are reported, the faster is the mode's cost: until the LoRA engine's side stream stopped being a lowest-priority
+    # stream, the second engine's torch stream here was one of those the runtime then mapped onto that stream's hardware queue and ran the
+    # same captured graph 2-3 x slower -- docs/EXPERIMENTS.md, tools/diag/stream_index_probe.py)
     out["retriever_train_shape"].update({"ms_per_step_deterministic": min(trds) * 1e3,
                                          "ms_per_step_deterministic_each_engine": [t * 1e3 for t in trds],
                                          "deterministic_runs_bit_identical": bool(losses[0] == losses[1])})
